@@ -1,0 +1,166 @@
+/*
+ * sea_hip.h -- C ABI of libsea_hip.so: SEA sparse-attention hot path on MI355X (gfx950).
+ *
+ * Drop-in boundary for the reference's operator package
+ *   src/models/perlin_attention/ops/__init__.py:1-7   (7 exported operators)
+ * and for the sparse branch of PerlinAttention.forward
+ *   src/models/perlin_attention/attention.py:774-947  (grouped top-k)
+ *   src/models/perlin_attention/attention.py:1034-1042 (mask -> flat CSR)
+ *   src/models/perlin_attention/attention.py:1158-1173 (SDDMM/softmax/elmul/SpMM)
+ *   src/models/perlin_attention/attention.py:1236-1244 (average-pool mix)
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is DEVICE memory owned by the caller;
+ *   - the library allocates nothing persistent, frees nothing, keeps no global state except a
+ *     thread-local last-error string; every call is asynchronous on `stream` (a hipStream_t);
+ *   - return 0 on success, negative SEA_E* otherwise (no exception crosses the ABI);
+ *   - tensors are addressed by ELEMENT strides; the innermost (feature / pixel) stride must be 1;
+ *   - "flat CSR" is the reference's wire format (causal_resize_m_to_t.py:757-762): one CSR row per
+ *     (batch, query) with column id = head*T_src + key, entries of a row grouped by ascending head,
+ *     pixels ascending inside a head, keys DESCENDING inside a pixel (causal_resize_m_to_t.py:569).
+ *     Internally indices are int32; `idx_bytes` = 8 selects int64 at the API edge (torch CSR).
+ */
+#ifndef SEA_HIP_H
+#define SEA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SEA_ABI_VERSION 1
+
+enum sea_dtype { SEA_F32 = 0, SEA_F16 = 1, SEA_BF16 = 2 };
+
+enum sea_error {
+  SEA_OK = 0,
+  SEA_EINVAL = -1,      /* bad argument (null pointer, bad dtype, stride) */
+  SEA_EUNSUPPORTED = -2,/* shape outside what the kernels are built for */
+  SEA_ELAUNCH = -3      /* HIP launch error (see sea_last_error) */
+};
+
+typedef void* sea_stream_t; /* hipStream_t */
+
+int sea_version(void);
+const char* sea_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * a6  grouped top-k selection.
+ * Replaces: PerlinAttention.forward "mask" region, attention.py:774-947 (torch.sort + int64 rank
+ * scatter + compare) and the kernel-test helper ops/kernels/causal_topk_masking.py:3-77.
+ *
+ * For every (n, t) keep the keep[n*keep_stride_n + t] largest of the H*T_m pooled values
+ * probs[n, :, t, :] (ties: lower flat index h*T_m+b first).  Writes
+ *   bits      (N, T_dst, W) uint32, W = ceil(H*T_m/32): bit f of a row = pixel f kept;
+ *   mask_out  optional (N, H, T_dst, T_m) fp32 0/1, contiguous  (= partial_attention_mask_before_interp);
+ * and, for the interpolation that follows (target widths as causal_resize_m_to_t.py:951-955,
+ * boundaries round_half_away(b*fp32(w/T_m)), per-pixel count clamped to max_k, :657-659),
+ *   row_nnz   (N, T_dst) int32      entries row t will emit,
+ *   head_off  (N, T_dst, H+1) int32 exclusive per-head offsets inside the row.
+ * Limits: H*T_m <= 16384, T_m % 4 == 0.
+ */
+int sea_topk_select(const void* probs, int dtype,
+                    int64_t N, int64_t H, int64_t T_dst, int64_t T_m,
+                    int64_t stride_n, int64_t stride_h, int64_t stride_t,
+                    const int32_t* keep, int64_t keep_stride_n,
+                    int64_t T_src, int is_causal, int max_k,
+                    uint32_t* bits, float* mask_out,
+                    int32_t* row_nnz, int32_t* head_off,
+                    sea_stream_t stream);
+
+/* Same outputs as sea_topk_select, but from an existing 0/1 mask (N,H,T_dst,T_m) of `dtype`
+ * (nonzero = kept).  Replaces the `n_pixels` pass of scan_col, causal_resize_m_to_t.py:657-659. */
+int sea_mask_to_bits(const void* mask, int dtype,
+                     int64_t N, int64_t H, int64_t T_dst, int64_t T_m,
+                     int64_t stride_n, int64_t stride_h, int64_t stride_t,
+                     int64_t T_src, int is_causal, int max_k,
+                     uint32_t* bits, int32_t* row_nnz, int32_t* head_off,
+                     sea_stream_t stream);
+
+/* crow[n, 0..T_dst] = exclusive scan of row_nnz[n, :]  (replaces cumsum + `crow_indices[:,1:] = ...`,
+ * causal_resize_m_to_t.py:664,672).  crow is int32 or int64 per idx_bytes. */
+int sea_csr_row_scan(const int32_t* row_nnz, int64_t N, int64_t T_dst,
+                     void* crow, int idx_bytes, sea_stream_t stream);
+
+/* a7  emit the column indices (replaces nonzero() + __scan_col_4_compute,
+ * causal_resize_m_to_t.py:493-572,724-746).  col has room for z_cap entries per batch item
+ * (col_stride_n elements apart); entries at or beyond crow[n,T_dst] are left untouched.
+ * values_out (optional, fp32, same shape as col) receives 1.0 for every emitted entry. */
+int sea_csr_emit(const uint32_t* bits, const void* crow, const int32_t* head_off,
+                 int64_t N, int64_t H, int64_t T_dst, int64_t T_m,
+                 int64_t T_src, int is_causal, int max_k,
+                 void* col, int idx_bytes, int64_t col_stride_n, int64_t z_cap,
+                 float* values_out,
+                 sea_stream_t stream);
+
+/* Per-(row, head) offsets of a foreign flat CSR whose rows are grouped by ascending head
+ * (replaces __flat_csr_sdbmm_tch_compute, flat_csr_sdbmm.py:48-127). */
+int sea_csr_head_offsets(const void* crow, const void* col, int idx_bytes,
+                         int64_t N, int64_t H, int64_t T_dst, int64_t T_src,
+                         int64_t col_stride_n, int32_t* head_off, sea_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * a9..a12  the four unfused CSR operators (1:1 with ops/__init__.py), values are fp32 (N, Z).
+ */
+/* flat_csr_masked_bmm, flat_csr_masked_bmm.py:137-195: values[n,e] = q[n,h,row,:] . k[n,h,key,:] */
+int sea_csr_sddmm(const void* q, const void* k, int dtype,
+                  int64_t N, int64_t H, int64_t T_dst, int64_t T_src, int64_t D,
+                  const int64_t* q_strides /*[n,h,t]*/, const int64_t* k_strides /*[n,h,t]*/,
+                  const void* crow, const void* col, int idx_bytes, int64_t col_stride_n,
+                  float* values, sea_stream_t stream);
+
+/* flat_csr_softmax, flat_csr_softmax.py:127-176: softmax over each (row, head) group of entries. */
+int sea_csr_softmax(const float* in_values, float* out_values,
+                    int64_t N, int64_t H, int64_t T_dst, int64_t T_src,
+                    const void* crow, const void* col, int idx_bytes, int64_t col_stride_n,
+                    sea_stream_t stream);
+
+/* flat_csr_elmul, flat_csr_elmul.py:110-162: values[n,e] *= other[n,h,row,key]  (element strides,
+ * stride 0 allowed -- the module passes a row-broadcast view, attention.py:1170-1171). */
+int sea_csr_elmul(const float* in_values, float* out_values,
+                  const void* other, int dtype, const int64_t* other_strides /*[n,h,t,s]*/,
+                  int64_t N, int64_t H, int64_t T_dst, int64_t T_src,
+                  const void* crow, const void* col, int idx_bytes, int64_t col_stride_n,
+                  sea_stream_t stream);
+
+/* flat_csr_sdbmm, flat_csr_sdbmm.py:323-439: out[n,h,row,:] = sum_e values[e] * v[n,h,key,:];
+ * out is fp32 (N,H,T_dst,D) contiguous, as the reference (`torch.zeros` w/o dtype, :347). */
+int sea_csr_spmm(const float* values, const void* v, int dtype,
+                 int64_t N, int64_t H, int64_t T_dst, int64_t T_src, int64_t D,
+                 const int64_t* v_strides /*[n,h,t]*/,
+                 const void* crow, const void* col, int idx_bytes, int64_t col_stride_n,
+                 const int32_t* head_off,
+                 float* out, sea_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused row-indexed sparse attention (the hot kernel): SDDMM + per-(row,head) softmax +
+ * row scale + SpMM (+ optional average-pool mix) in one pass, one wavefront per (n, h, t).
+ * Replaces the four launches of attention.py:1158-1173 and, with `avg`/`mix`, :1236-1237.
+ *
+ *   out[n,h,t,:] = rs * sum_e softmax_e(q.k_e) v_e            rs  = row_scale[n,h,t]  (or 1)
+ *   if mix:  out = out*a + (1-a)*avg[n,h,t,:]                  a   = mix[n,h,t]
+ *
+ * crow/col are int32 (internal format), head_off as produced by sea_topk_select.
+ * out has dtype out_dtype and arbitrary [n,h,t] element strides (so it can be written straight
+ * into the (N, T, H*D) layout of attention.py:1279-1282).
+ */
+int sea_sparse_attention(const void* q, const void* k, const void* v, int dtype,
+                         int64_t N, int64_t H, int64_t T_dst, int64_t T_src, int64_t D,
+                         const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                         const int32_t* crow, const int32_t* col, int64_t col_stride_n,
+                         const int32_t* head_off,
+                         const float* row_scale, /* (N,H,T_dst) contiguous or NULL */
+                         const void* avg, const int64_t* avg_strides, /* dtype `dtype`, or NULL */
+                         const float* mix,       /* (N,H,T_dst) contiguous or NULL */
+                         void* out, int out_dtype, const int64_t* out_strides,
+                         sea_stream_t stream);
+
+/* Algorithmic bytes of one sea_sparse_attention launch:
+ * Z*(2*D*s + 4) + N*H*T_dst*(2*D*s + 4).  Host-side helper, no device work. */
+int64_t sea_sparse_attention_bytes(int64_t Z, int64_t N, int64_t H, int64_t T_dst, int64_t D, int elem_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SEA_HIP_H */

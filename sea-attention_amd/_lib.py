@@ -1,0 +1,97 @@
+"""ctypes binding of libsea_hip.so (include/sea_hip.h).  The HIP library IS the product path:
+if it is missing this module raises -- there is no CPU or eager fallback."""
+import ctypes
+import os
+from ctypes import c_int, c_int32, c_int64, c_void_p, c_char_p, POINTER
+
+import torch
+
+from . import _build
+
+SEA_F32, SEA_F16, SEA_BF16 = 0, 1, 2
+_DTYPES = {torch.float32: SEA_F32, torch.float16: SEA_F16, torch.bfloat16: SEA_BF16}
+
+_lib = None
+
+i64 = c_int64
+ptr = c_void_p
+_i64p = POINTER(c_int64)
+
+_SIGNATURES = {
+    "sea_version": ([], c_int),
+    "sea_last_error": ([], c_char_p),
+    "sea_topk_select": ([ptr, c_int, i64, i64, i64, i64, i64, i64, i64, ptr, i64, i64, c_int, c_int,
+                         ptr, ptr, ptr, ptr, ptr], c_int),
+    "sea_mask_to_bits": ([ptr, c_int, i64, i64, i64, i64, i64, i64, i64, i64, c_int, c_int,
+                          ptr, ptr, ptr, ptr], c_int),
+    "sea_csr_row_scan": ([ptr, i64, i64, ptr, c_int, ptr], c_int),
+    "sea_csr_emit": ([ptr, ptr, ptr, i64, i64, i64, i64, i64, c_int, c_int, ptr, c_int, i64, i64, ptr, ptr], c_int),
+    "sea_csr_head_offsets": ([ptr, ptr, c_int, i64, i64, i64, i64, i64, ptr, ptr], c_int),
+    "sea_csr_sddmm": ([ptr, ptr, c_int, i64, i64, i64, i64, i64, _i64p, _i64p, ptr, ptr, c_int, i64, ptr, ptr], c_int),
+    "sea_csr_softmax": ([ptr, ptr, i64, i64, i64, i64, ptr, ptr, c_int, i64, ptr], c_int),
+    "sea_csr_elmul": ([ptr, ptr, ptr, c_int, _i64p, i64, i64, i64, i64, ptr, ptr, c_int, i64, ptr], c_int),
+    "sea_csr_spmm": ([ptr, ptr, c_int, i64, i64, i64, i64, i64, _i64p, ptr, ptr, c_int, i64, ptr, ptr, ptr], c_int),
+    "sea_sparse_attention": ([ptr, ptr, ptr, c_int, i64, i64, i64, i64, i64, _i64p, _i64p, _i64p,
+                              ptr, ptr, i64, ptr, ptr, ptr, _i64p, ptr, ptr, c_int, _i64p, ptr], c_int),
+    "sea_sparse_attention_bytes": ([i64, i64, i64, i64, i64, c_int], i64),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def library_path():
+    return _build.LIB_PATH
+
+
+def load(build_if_missing=True):
+    """Load (building first if the .so is absent and hipcc is available).  Raises if impossible."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.LIB_PATH
+    if not os.path.exists(path):
+        if not build_if_missing:
+            raise RuntimeError(f"{path} not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
+        _build.build_library()
+    lib = ctypes.CDLL(path)
+    for name, (argtypes, restype) in _SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is not exported
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _lib = lib
+    return lib
+
+
+def dtype_code(dt):
+    try:
+        return _DTYPES[dt]
+    except KeyError:
+        raise TypeError(f"unsupported dtype {dt}; the HIP kernels take float32 / float16 / bfloat16")
+
+
+def strides3(t):
+    """element strides [n, h, t] of a (N,H,T,D) tensor whose last stride is 1, as a C int64[3]."""
+    assert t.stride(-1) == 1, "innermost stride must be 1"
+    return (c_int64 * 3)(t.stride(0), t.stride(1), t.stride(2))
+
+
+def strides4(t):
+    return (c_int64 * 4)(*t.stride())
+
+
+def stream_ptr():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().sea_last_error()
+        raise RuntimeError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def require_gpu(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "sea_attention_amd operators run only on an MI355X device tensor through libsea_hip.so; "
+                "got a CPU tensor (there is deliberately no CPU fallback)")

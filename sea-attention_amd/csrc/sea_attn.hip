@@ -1,0 +1,514 @@
+// Row-indexed sparse attention on the flat CSR, hand-written for gfx950 (wave64).
+//
+// Replaces (reference, src/models/perlin_attention/ops/kernels/):
+//   flat_csr_masked_bmm.py:39-125   SDDMM  (1-warp programs, scalar entry loop)
+//   flat_csr_softmax.py:55-125      per-(row, head) softmax (H masked passes over the whole row)
+//   flat_csr_elmul.py:42-108        row-scale multiply through a stride-0 (N,H,T,T) view
+//   flat_csr_sdbmm.py:48-127,141-313  head-count pass + SpMM
+// and the mix of attention.py:1236-1237.
+//
+// Mapping: ONE WAVEFRONT PER (n, h, t) QUERY ROW.  The 64 lanes form 64/LPR groups of LPR lanes; a
+// group reads one whole K (or V) row per instruction as LPR x 16 B, so every gathered row is a
+// run of full, contiguous 16-byte lane loads (a 128 B bf16 d=64 row = 8 lanes).  q stays in
+// registers; the dot product is reduced inside the group with DPP; every group keeps its own
+// online-softmax state (m, l, acc[VEC]) so the key loop has no cross-group traffic, and the
+// groups are merged once at the end (flash-decoding style).  No LDS, no barriers.
+//
+// HBM / L2: K and V of one (n, h) are T_src*D*2*s bytes (1 MiB at OPT-1.3B T=4096 bf16), so the
+// gathers are served by L2 when the workgroups of a head run on one XCD: blockIdx is remapped so
+// that the (n, h) pair index is congruent to the XCD label blockIdx % 8 (speed only).
+#include "sea_common.hpp"
+
+namespace sea {
+
+template <int CTRL> __device__ inline float dpp_f(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, true));
+}
+
+// sum over the LPR lanes of an aligned group; result in every lane of the group
+template <int LPR> __device__ inline float group_sum(float x) {
+#ifndef SEA_NO_DPP
+  if (LPR >= 2) x += dpp_f<0xB1>(x);    // quad_perm [1,0,3,2]
+  if (LPR >= 4) x += dpp_f<0x4E>(x);    // quad_perm [2,3,0,1]
+  if (LPR >= 8) x += dpp_f<0x141>(x);   // row_half_mirror (values are quad-uniform here)
+  if (LPR >= 16) x += dpp_f<0x140>(x);  // row_mirror      (values are 8-uniform here)
+#else
+  if (LPR >= 2) x += __shfl_xor(x, 1);
+  if (LPR >= 4) x += __shfl_xor(x, 2);
+  if (LPR >= 8) x += __shfl_xor(x, 4);
+  if (LPR >= 16) x += __shfl_xor(x, 8);
+#endif
+  if (LPR >= 32) x += __shfl_xor(x, 16);
+  if (LPR >= 64) x += __shfl_xor(x, 32);
+  return x;
+}
+
+struct AttnParams {
+  const void *q, *k, *v;
+  int64_t qs[3], ks[3], vs[3];
+  int N, H, T_dst, T_src, D;
+  const int32_t* crow;
+  const int32_t* col;
+  int64_t col_stride_n;
+  const int32_t* head_off;
+  const float* row_scale;
+  const void* avg;
+  int64_t as[3];
+  const float* mix;
+  void* out;
+  int64_t os[3];
+  int TB;  // row blocks per (n, h): ceil(T_dst / 4)
+};
+
+template <typename TO, int VEC> __device__ inline void store_frag(TO* dst, const float* f);
+template <> __device__ inline void store_frag<float, 4>(float* dst, const float* f) {
+  *reinterpret_cast<float4*>(dst) = make_float4(f[0], f[1], f[2], f[3]);
+}
+template <> __device__ inline void store_frag<float, 8>(float* dst, const float* f) {
+  *reinterpret_cast<float4*>(dst) = make_float4(f[0], f[1], f[2], f[3]);
+  *reinterpret_cast<float4*>(dst + 4) = make_float4(f[4], f[5], f[6], f[7]);
+}
+template <> __device__ inline void store_frag<__hip_bfloat16, 8>(__hip_bfloat16* dst, const float* f) {
+  union { uint4 u; __hip_bfloat16 h[8]; } r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.h[i] = __float2bfloat16(f[i]);
+  *reinterpret_cast<uint4*>(dst) = r.u;
+}
+template <> __device__ inline void store_frag<__half, 8>(__half* dst, const float* f) {
+  union { uint4 u; __half h[8]; } r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.h[i] = __float2half(f[i]);
+  *reinterpret_cast<uint4*>(dst) = r.u;
+}
+template <> __device__ inline void store_frag<__hip_bfloat16, 4>(__hip_bfloat16* dst, const float* f) {
+  union { uint2 u; __hip_bfloat16 h[4]; } r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.h[i] = __float2bfloat16(f[i]);
+  *reinterpret_cast<uint2*>(dst) = r.u;
+}
+template <> __device__ inline void store_frag<__half, 4>(__half* dst, const float* f) {
+  union { uint2 u; __half h[4]; } r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.h[i] = __float2half(f[i]);
+  *reinterpret_cast<uint2*>(dst) = r.u;
+}
+
+// (n, h, row-block) from blockIdx, XCD-aware: blocks b and b+8 share an XCD (observed dispatch
+// order; only affects L2 locality).  Returns false if this block has no work.
+__device__ inline bool map_block(int NH, int TB, int* pair, int* tb) {
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int pl = slot / TB;
+  *tb = slot - pl * TB;
+  *pair = pl * 8 + xcd;
+  return *pair < NH;
+}
+
+template <typename T, typename TO, int LPR, int U>
+__global__ __launch_bounds__(256) void sparse_attn_kernel(AttnParams p) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int KPI = 64 / LPR;  // keys per wave-instruction
+  int pair, tb;
+  if (!map_block(p.N * p.H, p.TB, &pair, &tb)) return;
+  const int n = pair / p.H, h = pair - n * p.H;
+  const int t = tb * 4 + (threadIdx.x >> 6);
+  if (t >= p.T_dst) return;
+  const int lane = threadIdx.x & 63;
+  const int grp = lane / LPR, sub = lane - grp * LPR;
+  const bool dact = sub * VEC < p.D;
+
+  const T* qp = reinterpret_cast<const T*>(p.q) + n * p.qs[0] + h * p.qs[1] + t * p.qs[2] + sub * VEC;
+  const T* kb = reinterpret_cast<const T*>(p.k) + n * p.ks[0] + h * p.ks[1] + sub * VEC;
+  const T* vb = reinterpret_cast<const T*>(p.v) + n * p.vs[0] + h * p.vs[1] + sub * VEC;
+
+  float qf[VEC];
+  {
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (dact) r = *reinterpret_cast<const uint4*>(qp);
+    unpack16<T>(r, qf);
+  }
+  const int row_beg = p.crow[(int64_t)n * (p.T_dst + 1) + t];
+  const int32_t* ho = p.head_off + ((int64_t)n * p.T_dst + t) * (p.H + 1);
+  const int beg = row_beg + ho[h], end = row_beg + ho[h + 1];
+  const int32_t* col = p.col + n * p.col_stride_n;
+  const int hcol = h * p.T_src;
+
+  float m = -INFINITY, l = 0.f;
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+
+  for (int e0 = beg; e0 < end; e0 += KPI * U) {
+    bool ok[U];
+    uint4 kr[U], vr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = e0 + u * KPI + grp;
+      ok[u] = e < end;
+      const int key = ok[u] ? (col[e] - hcol) : 0;
+      kr[u] = make_uint4(0, 0, 0, 0);
+      vr[u] = make_uint4(0, 0, 0, 0);
+      if (dact) {
+        kr[u] = *reinterpret_cast<const uint4*>(kb + (int64_t)key * p.ks[2]);
+        vr[u] = *reinterpret_cast<const uint4*>(vb + (int64_t)key * p.vs[2]);
+      }
+    }
+    float s[U];
+    float mnew = m;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float kf[VEC];
+      unpack16<T>(kr[u], kf);
+      float d = 0.f;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) d = fmaf(qf[j], kf[j], d);
+      d = group_sum<LPR>(d);
+      s[u] = ok[u] ? d : -INFINITY;
+      mnew = fmaxf(mnew, s[u]);
+    }
+    if (mnew == -INFINITY) continue;  // this group has seen no entry yet
+    const float alpha = __expf(m - mnew);
+    l *= alpha;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] *= alpha;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float pu = __expf(s[u] - mnew);
+      float vf[VEC];
+      unpack16<T>(vr[u], vf);
+      l += pu;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] = fmaf(pu, vf[j], acc[j]);
+    }
+    m = mnew;
+  }
+
+  // merge the KPI groups (lanes with equal `sub` hold the same feature slice)
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) {
+    const float mo = __shfl_xor(m, o);
+    const float lo = __shfl_xor(l, o);
+    const float M = fmaxf(m, mo);
+    const float a = (m == -INFINITY) ? 0.f : __expf(m - M);
+    const float b = (mo == -INFINITY) ? 0.f : __expf(mo - M);
+    l = l * a + lo * b;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float ao = __shfl_xor(acc[j], o);
+      acc[j] = acc[j] * a + ao * b;
+    }
+    m = M;
+  }
+
+  if (grp == 0 && dact) {
+    const int64_t ridx = ((int64_t)n * p.H + h) * p.T_dst + t;
+    float scale = (l > 0.f) ? (1.0f / l) : 0.f;
+    if (p.row_scale) scale *= p.row_scale[ridx];
+    float o[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o[j] = acc[j] * scale;
+    if (p.mix) {
+      const float a = p.mix[ridx];
+      const T* ap = reinterpret_cast<const T*>(p.avg) + n * p.as[0] + h * p.as[1] + t * p.as[2] + sub * VEC;
+      float af[VEC];
+      unpack16<T>(*reinterpret_cast<const uint4*>(ap), af);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] = o[j] * a + (1.0f - a) * af[j];
+    }
+    TO* op = reinterpret_cast<TO*>(p.out) + n * p.os[0] + h * p.os[1] + t * p.os[2] + sub * VEC;
+    store_frag<TO, VEC>(op, o);
+  }
+}
+
+// ---- unfused SDDMM: one wave per (n, t) row, all heads -----------------------------------------------
+struct SddmmParams {
+  const void *q, *k;
+  int64_t qs[3], ks[3];
+  int N, H, T_dst, T_src, D;
+  const void* crow;
+  const void* col;
+  int64_t col_stride_n;
+  float* values;
+};
+
+template <typename T, typename I, int LPR>
+__global__ __launch_bounds__(256) void csr_sddmm_kernel(SddmmParams p) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int KPI = 64 / LPR;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)p.N * p.T_dst) return;
+  const int n = (int)(row / p.T_dst), t = (int)(row - (int64_t)n * p.T_dst);
+  const int lane = threadIdx.x & 63;
+  const int grp = lane / LPR, sub = lane - grp * LPR;
+  const bool dact = sub * VEC < p.D;
+  const I* crow = reinterpret_cast<const I*>(p.crow) + (int64_t)n * (p.T_dst + 1);
+  const I* col = reinterpret_cast<const I*>(p.col) + n * p.col_stride_n;
+  float* vals = p.values + n * p.col_stride_n;
+  const int64_t beg = crow[t], end = crow[t + 1];
+  const T* qb = reinterpret_cast<const T*>(p.q) + n * p.qs[0] + t * p.qs[2] + sub * VEC;
+  const T* kb = reinterpret_cast<const T*>(p.k) + n * p.ks[0] + sub * VEC;
+  for (int64_t e0 = beg; e0 < end; e0 += KPI) {
+    const int64_t e = e0 + grp;
+    const bool ok = e < end;
+    int64_t c = ok ? (int64_t)col[e] : 0;
+    const int h = (int)(c / p.T_src);
+    const int key = (int)(c - (int64_t)h * p.T_src);
+    uint4 qr = make_uint4(0, 0, 0, 0), kr = make_uint4(0, 0, 0, 0);
+    if (dact) {
+      qr = *reinterpret_cast<const uint4*>(qb + h * p.qs[1]);
+      kr = *reinterpret_cast<const uint4*>(kb + h * p.ks[1] + (int64_t)key * p.ks[2]);
+    }
+    float qf[VEC], kf[VEC];
+    unpack16<T>(qr, qf);
+    unpack16<T>(kr, kf);
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) d = fmaf(qf[j], kf[j], d);
+    d = group_sum<LPR>(d);
+    if (ok && sub == 0) vals[e] = d;
+  }
+}
+
+// ---- unfused SpMM: one wave per (n, h, t), needs head_off --------------------------------------------
+struct SpmmParams {
+  const float* values;
+  const void* v;
+  int64_t vs[3];
+  int N, H, T_dst, T_src, D;
+  const void* crow;
+  const void* col;
+  int64_t col_stride_n;
+  const int32_t* head_off;
+  float* out;
+  int TB;
+};
+
+template <typename T, typename I, int LPR>
+__global__ __launch_bounds__(256) void csr_spmm_kernel(SpmmParams p) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int KPI = 64 / LPR;
+  int pair, tb;
+  if (!map_block(p.N * p.H, p.TB, &pair, &tb)) return;
+  const int n = pair / p.H, h = pair - n * p.H;
+  const int t = tb * 4 + (threadIdx.x >> 6);
+  if (t >= p.T_dst) return;
+  const int lane = threadIdx.x & 63;
+  const int grp = lane / LPR, sub = lane - grp * LPR;
+  const bool dact = sub * VEC < p.D;
+  const I* crow = reinterpret_cast<const I*>(p.crow) + (int64_t)n * (p.T_dst + 1);
+  const I* col = reinterpret_cast<const I*>(p.col) + n * p.col_stride_n;
+  const float* vals = p.values + n * p.col_stride_n;
+  const int32_t* ho = p.head_off + ((int64_t)n * p.T_dst + t) * (p.H + 1);
+  const int64_t beg = (int64_t)crow[t] + ho[h], end = (int64_t)crow[t] + ho[h + 1];
+  const T* vb = reinterpret_cast<const T*>(p.v) + n * p.vs[0] + h * p.vs[1] + sub * VEC;
+  const int64_t hcol = (int64_t)h * p.T_src;
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  for (int64_t e0 = beg; e0 < end; e0 += KPI) {
+    const int64_t e = e0 + grp;
+    const bool ok = e < end;
+    const int64_t key = ok ? ((int64_t)col[e] - hcol) : 0;
+    const float pv = ok ? vals[e] : 0.f;
+    uint4 vr = make_uint4(0, 0, 0, 0);
+    if (dact) vr = *reinterpret_cast<const uint4*>(vb + key * p.vs[2]);
+    float vf[VEC];
+    unpack16<T>(vr, vf);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = fmaf(pv, vf[j], acc[j]);
+  }
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] += __shfl_xor(acc[j], o);
+  }
+  if (grp == 0 && dact) {
+    float* op = p.out + (((int64_t)n * p.H + h) * p.T_dst + t) * p.D + sub * VEC;
+    store_frag<float, VEC>(op, acc);
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------
+static int lanes_per_row(int D, int vec) {
+  const int need = (D + vec - 1) / vec;
+  int l = 1;
+  while (l < need) l *= 2;
+  return l < 4 ? 4 : l;
+}
+
+static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+static bool strides_ok(const int64_t* s, int vec) { return s[0] % vec == 0 && s[1] % vec == 0 && s[2] % vec == 0; }
+
+template <typename T, typename TO>
+static int launch_attn(const AttnParams& p, hipStream_t s) {
+  constexpr int VEC = Elem<T>::VEC;
+  const int lpr = lanes_per_row(p.D, VEC);
+  const int NH = p.N * p.H;
+  const int64_t blocks = (int64_t)8 * ((NH + 7) / 8) * p.TB;
+  dim3 grid((unsigned)blocks), block(256);
+  switch (lpr) {
+    case 4: hipLaunchKernelGGL((sparse_attn_kernel<T, TO, 4, 2>), grid, block, 0, s, p); break;
+    case 8: hipLaunchKernelGGL((sparse_attn_kernel<T, TO, 8, 4>), grid, block, 0, s, p); break;
+    case 16: hipLaunchKernelGGL((sparse_attn_kernel<T, TO, 16, 4>), grid, block, 0, s, p); break;
+    case 32: hipLaunchKernelGGL((sparse_attn_kernel<T, TO, 32, 4>), grid, block, 0, s, p); break;
+    case 64: hipLaunchKernelGGL((sparse_attn_kernel<T, TO, 64, 4>), grid, block, 0, s, p); break;
+    default: return SEA_EUNSUPPORTED;
+  }
+  return SEA_OK;
+}
+
+template <typename T, typename I>
+static int launch_sddmm(const SddmmParams& p, hipStream_t s) {
+  const int lpr = lanes_per_row(p.D, Elem<T>::VEC);
+  const int64_t rows = (int64_t)p.N * p.T_dst;
+  dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+  switch (lpr) {
+    case 4: hipLaunchKernelGGL((csr_sddmm_kernel<T, I, 4>), grid, block, 0, s, p); break;
+    case 8: hipLaunchKernelGGL((csr_sddmm_kernel<T, I, 8>), grid, block, 0, s, p); break;
+    case 16: hipLaunchKernelGGL((csr_sddmm_kernel<T, I, 16>), grid, block, 0, s, p); break;
+    case 32: hipLaunchKernelGGL((csr_sddmm_kernel<T, I, 32>), grid, block, 0, s, p); break;
+    case 64: hipLaunchKernelGGL((csr_sddmm_kernel<T, I, 64>), grid, block, 0, s, p); break;
+    default: return SEA_EUNSUPPORTED;
+  }
+  return SEA_OK;
+}
+
+template <typename T, typename I>
+static int launch_spmm(const SpmmParams& p, hipStream_t s) {
+  const int lpr = lanes_per_row(p.D, Elem<T>::VEC);
+  const int NH = p.N * p.H;
+  const int64_t blocks = (int64_t)8 * ((NH + 7) / 8) * p.TB;
+  dim3 grid((unsigned)blocks), block(256);
+  switch (lpr) {
+    case 4: hipLaunchKernelGGL((csr_spmm_kernel<T, I, 4>), grid, block, 0, s, p); break;
+    case 8: hipLaunchKernelGGL((csr_spmm_kernel<T, I, 8>), grid, block, 0, s, p); break;
+    case 16: hipLaunchKernelGGL((csr_spmm_kernel<T, I, 16>), grid, block, 0, s, p); break;
+    case 32: hipLaunchKernelGGL((csr_spmm_kernel<T, I, 32>), grid, block, 0, s, p); break;
+    case 64: hipLaunchKernelGGL((csr_spmm_kernel<T, I, 64>), grid, block, 0, s, p); break;
+    default: return SEA_EUNSUPPORTED;
+  }
+  return SEA_OK;
+}
+
+}  // namespace sea
+
+using namespace sea;
+
+static int check_dtype(const char* name, int dtype) {
+  SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_F16 || dtype == SEA_BF16, SEA_EINVAL, "%s: bad dtype %d", name, dtype);
+  return SEA_OK;
+}
+
+extern "C" int sea_sparse_attention(const void* q, const void* k, const void* v, int dtype, int64_t N, int64_t H,
+                                    int64_t T_dst, int64_t T_src, int64_t D, const int64_t* q_strides,
+                                    const int64_t* k_strides, const int64_t* v_strides, const int32_t* crow,
+                                    const int32_t* col, int64_t col_stride_n, const int32_t* head_off,
+                                    const float* row_scale, const void* avg, const int64_t* avg_strides,
+                                    const float* mix, void* out, int out_dtype, const int64_t* out_strides,
+                                    sea_stream_t stream) {
+  const char* nm = "sea_sparse_attention";
+  SEA_REQUIRE(q && k && v && crow && col && head_off && out && q_strides && k_strides && v_strides && out_strides,
+              SEA_EINVAL, "%s: null pointer", nm);
+  if (int e = check_dtype(nm, dtype)) return e;
+  SEA_REQUIRE(out_dtype == SEA_F32 || out_dtype == dtype, SEA_EUNSUPPORTED, "%s: out dtype must be fp32 or the input dtype", nm);
+  SEA_REQUIRE((mix == nullptr) == (avg == nullptr), SEA_EINVAL, "%s: avg and mix go together", nm);
+  SEA_REQUIRE(!avg || avg_strides, SEA_EINVAL, "%s: avg_strides is null", nm);
+  SEA_REQUIRE(N > 0 && H > 0 && T_dst > 0 && T_src > 0 && D > 0, SEA_EINVAL, "%s: bad shape", nm);
+  const int vec = dtype == SEA_F32 ? 4 : 8;
+  SEA_REQUIRE(D % vec == 0 && D <= 64 * vec, SEA_EUNSUPPORTED, "%s: D=%lld must be a multiple of %d and <= %d", nm,
+              (long long)D, vec, 64 * vec);
+  SEA_REQUIRE(aligned16(q) && aligned16(k) && aligned16(v) && (!avg || aligned16(avg)) && aligned16(out), SEA_EUNSUPPORTED,
+              "%s: tensors must be 16-byte aligned", nm);
+  SEA_REQUIRE(strides_ok(q_strides, vec) && strides_ok(k_strides, vec) && strides_ok(v_strides, vec) &&
+                  strides_ok(out_strides, vec) && (!avg || strides_ok(avg_strides, vec)),
+              SEA_EUNSUPPORTED, "%s: row strides must be multiples of %d elements", nm, vec);
+  SEA_REQUIRE(N * H * ((T_dst + 3) / 4) < (1ll << 28), SEA_EUNSUPPORTED, "%s: grid too large", nm);
+  AttnParams p;
+  p.q = q; p.k = k; p.v = v;
+  for (int i = 0; i < 3; ++i) {
+    p.qs[i] = q_strides[i]; p.ks[i] = k_strides[i]; p.vs[i] = v_strides[i]; p.os[i] = out_strides[i];
+    p.as[i] = avg ? avg_strides[i] : 0;
+  }
+  p.N = (int)N; p.H = (int)H; p.T_dst = (int)T_dst; p.T_src = (int)T_src; p.D = (int)D;
+  p.crow = crow; p.col = col; p.col_stride_n = col_stride_n; p.head_off = head_off;
+  p.row_scale = row_scale; p.avg = avg; p.mix = mix; p.out = out;
+  p.TB = (int)((T_dst + 3) / 4);
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (dtype == SEA_F32) rc = launch_attn<float, float>(p, s);
+  else if (dtype == SEA_F16) rc = out_dtype == SEA_F32 ? launch_attn<__half, float>(p, s) : launch_attn<__half, __half>(p, s);
+  else rc = out_dtype == SEA_F32 ? launch_attn<__hip_bfloat16, float>(p, s) : launch_attn<__hip_bfloat16, __hip_bfloat16>(p, s);
+  SEA_REQUIRE(rc == SEA_OK, rc, "%s: unsupported head size %lld", nm, (long long)D);
+  SEA_CHECK_LAUNCH(nm);
+  return SEA_OK;
+}
+
+extern "C" int64_t sea_sparse_attention_bytes(int64_t Z, int64_t N, int64_t H, int64_t T_dst, int64_t D, int elem_bytes) {
+  return Z * (2 * D * elem_bytes + 4) + N * H * T_dst * (2 * D * elem_bytes + 4);
+}
+
+extern "C" int sea_csr_sddmm(const void* q, const void* k, int dtype, int64_t N, int64_t H, int64_t T_dst, int64_t T_src,
+                             int64_t D, const int64_t* q_strides, const int64_t* k_strides, const void* crow,
+                             const void* col, int idx_bytes, int64_t col_stride_n, float* values, sea_stream_t stream) {
+  const char* nm = "sea_csr_sddmm";
+  SEA_REQUIRE(q && k && crow && col && values && q_strides && k_strides, SEA_EINVAL, "%s: null pointer", nm);
+  if (int e = check_dtype(nm, dtype)) return e;
+  SEA_REQUIRE(idx_bytes == 4 || idx_bytes == 8, SEA_EINVAL, "%s: idx_bytes must be 4 or 8", nm);
+  const int vec = dtype == SEA_F32 ? 4 : 8;
+  SEA_REQUIRE(D % vec == 0 && D <= 64 * vec, SEA_EUNSUPPORTED, "%s: D=%lld must be a multiple of %d", nm, (long long)D, vec);
+  SEA_REQUIRE(aligned16(q) && aligned16(k) && strides_ok(q_strides, vec) && strides_ok(k_strides, vec), SEA_EUNSUPPORTED,
+              "%s: q/k rows must be 16-byte aligned", nm);
+  SddmmParams p;
+  p.q = q; p.k = k;
+  for (int i = 0; i < 3; ++i) { p.qs[i] = q_strides[i]; p.ks[i] = k_strides[i]; }
+  p.N = (int)N; p.H = (int)H; p.T_dst = (int)T_dst; p.T_src = (int)T_src; p.D = (int)D;
+  p.crow = crow; p.col = col; p.col_stride_n = col_stride_n; p.values = values;
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (idx_bytes == 4) {
+    if (dtype == SEA_F32) rc = launch_sddmm<float, int32_t>(p, s);
+    else if (dtype == SEA_F16) rc = launch_sddmm<__half, int32_t>(p, s);
+    else rc = launch_sddmm<__hip_bfloat16, int32_t>(p, s);
+  } else {
+    if (dtype == SEA_F32) rc = launch_sddmm<float, int64_t>(p, s);
+    else if (dtype == SEA_F16) rc = launch_sddmm<__half, int64_t>(p, s);
+    else rc = launch_sddmm<__hip_bfloat16, int64_t>(p, s);
+  }
+  SEA_REQUIRE(rc == SEA_OK, rc, "%s: unsupported head size", nm);
+  SEA_CHECK_LAUNCH(nm);
+  return SEA_OK;
+}
+
+extern "C" int sea_csr_spmm(const float* values, const void* v, int dtype, int64_t N, int64_t H, int64_t T_dst,
+                            int64_t T_src, int64_t D, const int64_t* v_strides, const void* crow, const void* col,
+                            int idx_bytes, int64_t col_stride_n, const int32_t* head_off, float* out,
+                            sea_stream_t stream) {
+  const char* nm = "sea_csr_spmm";
+  SEA_REQUIRE(values && v && crow && col && head_off && out && v_strides, SEA_EINVAL, "%s: null pointer", nm);
+  if (int e = check_dtype(nm, dtype)) return e;
+  SEA_REQUIRE(idx_bytes == 4 || idx_bytes == 8, SEA_EINVAL, "%s: idx_bytes must be 4 or 8", nm);
+  const int vec = dtype == SEA_F32 ? 4 : 8;
+  SEA_REQUIRE(D % vec == 0 && D <= 64 * vec, SEA_EUNSUPPORTED, "%s: D=%lld must be a multiple of %d", nm, (long long)D, vec);
+  SEA_REQUIRE(aligned16(v) && aligned16(out) && strides_ok(v_strides, vec), SEA_EUNSUPPORTED,
+              "%s: v rows must be 16-byte aligned", nm);
+  SpmmParams p;
+  p.values = values; p.v = v;
+  for (int i = 0; i < 3; ++i) p.vs[i] = v_strides[i];
+  p.N = (int)N; p.H = (int)H; p.T_dst = (int)T_dst; p.T_src = (int)T_src; p.D = (int)D;
+  p.crow = crow; p.col = col; p.col_stride_n = col_stride_n; p.head_off = head_off; p.out = out;
+  p.TB = (int)((T_dst + 3) / 4);
+  hipStream_t s = (hipStream_t)stream;
+  int rc;
+  if (idx_bytes == 4) {
+    if (dtype == SEA_F32) rc = launch_spmm<float, int32_t>(p, s);
+    else if (dtype == SEA_F16) rc = launch_spmm<__half, int32_t>(p, s);
+    else rc = launch_spmm<__hip_bfloat16, int32_t>(p, s);
+  } else {
+    if (dtype == SEA_F32) rc = launch_spmm<float, int64_t>(p, s);
+    else if (dtype == SEA_F16) rc = launch_spmm<__half, int64_t>(p, s);
+    else rc = launch_spmm<__hip_bfloat16, int64_t>(p, s);
+  }
+  SEA_REQUIRE(rc == SEA_OK, rc, "%s: unsupported head size", nm);
+  SEA_CHECK_LAUNCH(nm);
+  return SEA_OK;
+}

@@ -1,0 +1,117 @@
+// Shared device/host helpers for libsea_hip.so (gfx950 only: wave64, DPP, 160 KB LDS).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <hip/hip_bf16.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/sea_hip.h"
+
+namespace sea {
+
+constexpr int WAVE = 64;
+
+void set_error(const char* fmt, ...);
+
+#define SEA_REQUIRE(cond, code, ...)        \
+  do {                                      \
+    if (!(cond)) {                          \
+      ::sea::set_error(__VA_ARGS__);        \
+      return (code);                        \
+    }                                       \
+  } while (0)
+
+#define SEA_CHECK_LAUNCH(name)                                              \
+  do {                                                                      \
+    hipError_t _e = hipGetLastError();                                      \
+    if (_e != hipSuccess) {                                                 \
+      ::sea::set_error("%s: launch failed: %s", name, hipGetErrorString(_e)); \
+      return SEA_ELAUNCH;                                                   \
+    }                                                                       \
+  } while (0)
+
+// ---- element access ------------------------------------------------------------------------
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int VEC = 4;  // elements per 16-byte lane load
+  __device__ static inline float to_f(float x) { return x; }
+};
+template <> struct Elem<__half> {
+  static constexpr int VEC = 8;
+  __device__ static inline float to_f(__half x) { return __half2float(x); }
+};
+template <> struct Elem<__hip_bfloat16> {
+  static constexpr int VEC = 8;
+  __device__ static inline float to_f(__hip_bfloat16 x) { return __bfloat162float(x); }
+};
+
+__device__ inline float bf16_bits_to_f(uint32_t hi16) { return __uint_as_float(hi16 << 16); }
+
+// Unpack one 16-byte lane fragment into VEC floats.
+template <typename T> __device__ inline void unpack16(const uint4& r, float* f);
+template <> __device__ inline void unpack16<float>(const uint4& r, float* f) {
+  f[0] = __uint_as_float(r.x); f[1] = __uint_as_float(r.y);
+  f[2] = __uint_as_float(r.z); f[3] = __uint_as_float(r.w);
+}
+template <> __device__ inline void unpack16<__hip_bfloat16>(const uint4& r, float* f) {
+  f[0] = __uint_as_float(r.x << 16); f[1] = __uint_as_float(r.x & 0xffff0000u);
+  f[2] = __uint_as_float(r.y << 16); f[3] = __uint_as_float(r.y & 0xffff0000u);
+  f[4] = __uint_as_float(r.z << 16); f[5] = __uint_as_float(r.z & 0xffff0000u);
+  f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+template <> __device__ inline void unpack16<__half>(const uint4& r, float* f) {
+  const __half2* h = reinterpret_cast<const __half2*>(&r);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    float2 t = __half22float2(h[i]);
+    f[2 * i] = t.x; f[2 * i + 1] = t.y;
+  }
+}
+
+template <typename T> __device__ inline T from_f(float x);
+template <> __device__ inline float from_f<float>(float x) { return x; }
+template <> __device__ inline __half from_f<__half>(float x) { return __float2half(x); }
+template <> __device__ inline __hip_bfloat16 from_f<__hip_bfloat16>(float x) { return __float2bfloat16(x); }
+
+// ---- wave-level primitives -----------------------------------------------------------------
+__device__ inline int lane_id() { return threadIdx.x & 63; }
+
+template <typename T> __device__ inline T wave_sum(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+template <typename T> __device__ inline T wave_max(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { T t = __shfl_xor(v, o); v = t > v ? t : v; }
+  return v;
+}
+template <typename T> __device__ inline T wave_min(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { T t = __shfl_xor(v, o); v = t < v ? t : v; }
+  return v;
+}
+// inclusive scan over the 64 lanes
+template <typename T> __device__ inline T wave_incl_scan(T v) {
+  const int l = lane_id();
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) { T t = __shfl_up(v, o); if (l >= o) v += t; }
+  return v;
+}
+
+// index load at the API edge: int32 internally, int64 for torch CSR tensors
+template <int IB> struct Idx;
+template <> struct Idx<4> { using type = int32_t; };
+template <> struct Idx<8> { using type = int64_t; };
+
+// ---- interpolation boundaries ---------------------------------------------------------------
+// Reference: scales = target_width / T_m (int64/int -> fp32 true division,
+// causal_resize_m_to_t.py:642); v = round_half_away(b * scale) in fp32 (:654-655, libdevice roundf).
+__device__ inline float interp_scale(int w, int T_m) { return __fdiv_rn((float)w, (float)T_m); }
+__device__ inline float interp_bound(int b, float scale) { return roundf(__fmul_rn((float)b, scale)); }
+__device__ inline int row_width(int t, int T_dst, int T_src, int is_causal) {
+  // target_width = arange(1, T_src+1)[-T_dst:] (causal) or T_src (causal_resize_m_to_t.py:951-955)
+  return is_causal ? (T_src - T_dst + t + 1) : T_src;
+}
+
+}  // namespace sea

@@ -1,0 +1,555 @@
+// Grouped top-k selection + mask interpolation to flat CSR, hand-written for gfx950.
+//
+// Replaces (reference, src/models/perlin_attention/):
+//   attention.py:774-947                     full torch.sort + int64 rank scatter + compare
+//   ops/kernels/causal_resize_m_to_t.py:631-762   n_pixels / cumsum / nonzero / __scan_col_4_compute
+//
+// Pipeline (three launches, no host synchronisation):
+//   topk_select_kernel   one 256-thread workgroup per (n, t) row: the H*T_m pooled probabilities of
+//                        the row live in registers (EPT per thread); an adaptive MSB radix select with
+//                        an LDS histogram finds the K-th largest key; survivors are written as a bit
+//                        mask, and the per-head / per-row entry counts of the interpolated row follow
+//                        from the closed-form pixel widths.
+//   row_scan_kernel      crow = exclusive scan of the row counts (one workgroup per batch item).
+//   csr_emit_kernel      one workgroup per row: expand every kept pixel to its key columns.
+//
+// Everything here is HBM-bound integer/compare work; LDS holds the score histogram only.
+#include "sea_common.hpp"
+
+namespace sea {
+
+constexpr int TK_THREADS = 256;
+constexpr int TK_WAVES = TK_THREADS / WAVE;
+constexpr int TK_MAX_BINS = 2048;  // 11-bit digits
+
+// float -> order-preserving uint32 (larger float <=> larger key); -0.0 is folded onto +0.0
+__device__ inline uint32_t f2key(float f) {
+  f = f + 0.0f;
+  uint32_t u = __float_as_uint(f);
+  return u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);
+}
+
+struct TopkParams {
+  const void* src;  // probs or mask
+  int64_t sn, sh, st;
+  int H, T_dst, T_m, T_src;
+  int is_causal, max_k;
+  int M;          // H*T_m
+  int nchunks;    // M/4
+  int W;          // ceil(M/32)
+  int G;          // lanes per aligned group that share one head
+  const int32_t* keep;
+  int64_t keep_stride_n;
+  uint32_t* bits;
+  float* mask_out;
+  int32_t* row_nnz;
+  int32_t* head_off;
+};
+
+template <typename T> __device__ inline void load4(const T* p, float* f);
+template <> __device__ inline void load4<float>(const float* p, float* f) {
+  float4 v = *reinterpret_cast<const float4*>(p);
+  f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+}
+template <> __device__ inline void load4<__hip_bfloat16>(const __hip_bfloat16* p, float* f) {
+  uint2 v = *reinterpret_cast<const uint2*>(p);
+  f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+  f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+template <> __device__ inline void load4<__half>(const __half* p, float* f) {
+  uint2 v = *reinterpret_cast<const uint2*>(p);
+  const __half2* h = reinterpret_cast<const __half2*>(&v);
+  float2 a = __half22float2(h[0]), b = __half22float2(h[1]);
+  f[0] = a.x; f[1] = a.y; f[2] = b.x; f[3] = b.y;
+}
+
+// Block-wide exclusive scan of one int per thread (256 threads); returns exclusive prefix, total in *total.
+__device__ inline int block_excl_scan(int v, int* s_wave /*[TK_WAVES]*/, int* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  int incl = wave_incl_scan(v);
+  if (lane == 63) s_wave[w] = incl;
+  __syncthreads();
+  int base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < TK_WAVES; ++i) {
+    int x = s_wave[i];
+    if (i < w) base += x;
+    tot += x;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
+template <typename T, int EPT, bool FROM_MASK>
+__global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(TopkParams p) {
+  constexpr int R = EPT / 4;  // chunk rounds
+  __shared__ int s_hist[TK_MAX_BINS];
+  __shared__ int s_head[1024];
+  __shared__ int s_wave[TK_WAVES];
+  __shared__ uint32_t s_red[2 * TK_WAVES];
+  __shared__ int s_bcast[4];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
+  const int row = blockIdx.x;
+  const int n = row / p.T_dst, t = row - n * p.T_dst;
+  const T* base = reinterpret_cast<const T*>(p.src) + n * p.sn + t * p.st;
+
+  // ---- load the row: chunk c = j*256 + tid covers flat pixels 4c..4c+3 (head-major) ------------
+  uint32_t key[EPT];
+  unsigned long long sel = 0;  // bit (4*j + e): element e of round j is kept
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int c = j * TK_THREADS + tid;
+    float f[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool valid = c < p.nchunks;
+    if (valid) {
+      const int f0 = c * 4;
+      const int h = f0 / p.T_m, b0 = f0 - h * p.T_m;
+      load4<T>(base + h * p.sh + b0, f);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (FROM_MASK) {
+        if (valid && f[e] != 0.f) sel |= 1ull << (4 * j + e);
+        key[4 * j + e] = 0;
+      } else {
+        key[4 * j + e] = valid ? f2key(f[e]) : 0u;
+      }
+    }
+  }
+
+  if (!FROM_MASK) {
+    const int K = p.keep[n * p.keep_stride_n + t];
+    if (K >= p.M) {
+#pragma unroll
+      for (int j = 0; j < R; ++j)
+        if (j * TK_THREADS + tid < p.nchunks) sel |= 0xFull << (4 * j);
+    } else if (K > 0) {
+      // ---- common leading bits of all keys: skip them (keeps the LDS histogram spread out) ------
+      uint32_t umin = 0xFFFFFFFFu, umax = 0u;
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        if (j * TK_THREADS + tid < p.nchunks) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            umin = min(umin, key[4 * j + e]);
+            umax = max(umax, key[4 * j + e]);
+          }
+        }
+      }
+      umin = wave_min(umin);
+      umax = wave_max(umax);
+      if (lane == 0) { s_red[wv] = umin; s_red[TK_WAVES + wv] = umax; }
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < TK_WAVES; ++i) { umin = min(umin, s_red[i]); umax = max(umax, s_red[TK_WAVES + i]); }
+      __syncthreads();
+
+      uint32_t prefix = umax;          // the decided high bits (low bits are don't-care until decided)
+      int bits_left = (umax == umin) ? 0 : (32 - __clz(umax ^ umin));
+      int kth = K;                      // rank still to locate among the candidates
+      int n_eq = p.M;                   // keys equal to the final threshold (all, if every key is equal)
+      // ---- MSB radix passes, 11 bits at a time -------------------------------------------------
+      while (bits_left > 0) {
+        const int d = bits_left < 11 ? bits_left : 11;
+        const int shift = bits_left - d;
+        const int nb = 1 << d;
+        const int hi = shift + d;  // bits above the digit; candidates agree with `prefix` on them
+        for (int i = tid; i < nb; i += TK_THREADS) s_hist[i] = 0;
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+          const uint32_t u = key[i];
+          const bool cand = (hi >= 32) ? true : ((u >> hi) == (prefix >> hi));
+          const bool valid = ((i >> 2) * TK_THREADS + tid) < p.nchunks;
+          if (cand && valid) {
+            const int rb = nb - 1 - (int)((u >> shift) & (uint32_t)(nb - 1));  // descending bins
+            atomicAdd(&s_hist[rb], 1);
+          }
+        }
+        __syncthreads();
+        // locate the descending bin that holds rank `kth`: thread i owns bins [i*per, (i+1)*per)
+        const int per = (nb + TK_THREADS - 1) / TK_THREADS;
+        int mine = 0;
+        for (int i = 0; i < per; ++i) {
+          const int bi = tid * per + i;
+          if (bi < nb) mine += s_hist[bi];
+        }
+        int total;
+        const int excl = block_excl_scan(mine, s_wave, &total);
+        if (excl < kth && kth <= excl + mine) {
+          int run = excl;
+          for (int i = 0; i < per; ++i) {
+            const int bi = tid * per + i;
+            const int c = s_hist[bi];
+            if (kth <= run + c) { s_bcast[0] = bi; s_bcast[1] = run; s_bcast[2] = c; break; }
+            run += c;
+          }
+        }
+        __syncthreads();
+        const int rb = s_bcast[0];
+        kth -= s_bcast[1];
+        n_eq = s_bcast[2];
+        const uint32_t digit = (uint32_t)(nb - 1 - rb);
+        const uint32_t dmask = (uint32_t)(nb - 1) << shift;
+        prefix = (prefix & ~dmask) | (digit << shift);
+        bits_left = shift;
+        __syncthreads();
+      }
+      const uint32_t tau = prefix;
+      const int r = kth;  // how many of the keys == tau are kept (lowest flat index first)
+      if (n_eq == r) {
+#pragma unroll
+        for (int i = 0; i < EPT; ++i) {
+          const bool valid = ((i >> 2) * TK_THREADS + tid) < p.nchunks;
+          if (valid && key[i] >= tau) sel |= 1ull << i;
+        }
+      } else {
+        int seen = 0;  // ties in earlier rounds (flat order = round-major, then thread, then element)
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const bool valid = (j * TK_THREADS + tid) < p.nchunks;
+          int cnt = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) cnt += (valid && key[4 * j + e] == tau) ? 1 : 0;
+          int total;
+          int rank = seen + block_excl_scan(cnt, s_wave, &total);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t u = key[4 * j + e];
+            if (valid && u > tau) sel |= 1ull << (4 * j + e);
+            if (valid && u == tau) {
+              if (rank < r) sel |= 1ull << (4 * j + e);
+              ++rank;
+            }
+          }
+          seen += total;
+        }
+      }
+    }
+  }
+
+  // ---- outputs ----------------------------------------------------------------------------------
+  for (int i = tid; i < p.H; i += TK_THREADS) s_head[i] = 0;
+  __syncthreads();
+
+  const int w_t = row_width(t, p.T_dst, p.T_src, p.is_causal);
+  const float scale = interp_scale(w_t, p.T_m);
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int c = j * TK_THREADS + tid;
+    const bool valid = c < p.nchunks;
+    const uint32_t nib = (uint32_t)(sel >> (4 * j)) & 0xFu;
+    // bit mask: 8 consecutive lanes own one 32-bit word
+    uint32_t word = nib << (4 * (lane & 7));
+    word |= __shfl_xor(word, 1);
+    word |= __shfl_xor(word, 2);
+    word |= __shfl_xor(word, 4);
+    if ((lane & 7) == 0 && (c >> 3) < p.W) p.bits[(int64_t)row * p.W + (c >> 3)] = word;
+
+    int h = 0, b0 = 0;
+    if (valid) { const int f0 = c * 4; h = f0 / p.T_m; b0 = f0 - h * p.T_m; }
+    if (p.mask_out != nullptr && valid) {
+      float4 m;
+      m.x = (nib & 1u) ? 1.f : 0.f; m.y = (nib & 2u) ? 1.f : 0.f;
+      m.z = (nib & 4u) ? 1.f : 0.f; m.w = (nib & 8u) ? 1.f : 0.f;
+      *reinterpret_cast<float4*>(p.mask_out + (((int64_t)n * p.H + h) * p.T_dst + t) * p.T_m + b0) = m;
+    }
+    // entries this chunk will emit: sum over kept pixels of min(v_end - v_start, max_k)
+    int cnt = 0;
+    if (nib) {
+      float prev = interp_bound(b0, scale);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float nxt = interp_bound(b0 + e + 1, scale);
+        int w = (int)(nxt - prev);
+        w = w < p.max_k ? w : p.max_k;
+        if (nib & (1u << e)) cnt += w;
+        prev = nxt;
+      }
+    }
+    for (int o = 1; o < p.G; o <<= 1) cnt += __shfl_xor(cnt, o);
+    if (valid && (lane & (p.G - 1)) == 0 && cnt) atomicAdd(&s_head[h], cnt);
+  }
+  __syncthreads();
+  // exclusive scan over heads (first wave, 64 heads per step)
+  if (wv == 0) {
+    int carry = 0;
+    int32_t* ho = p.head_off + (int64_t)row * (p.H + 1);
+    for (int h0 = 0; h0 < p.H; h0 += 64) {
+      const int h = h0 + lane;
+      const int v = h < p.H ? s_head[h] : 0;
+      const int incl = wave_incl_scan(v);
+      if (h < p.H) ho[h] = carry + incl - v;
+      carry += __shfl(incl, 63);
+    }
+    if (lane == 0) { ho[p.H] = carry; p.row_nnz[row] = carry; }
+  }
+}
+
+// ---- crow = exclusive scan of row_nnz ------------------------------------------------------------
+template <typename I>
+__global__ __launch_bounds__(1024) void row_scan_kernel(const int32_t* row_nnz, int T_dst, I* crow) {
+  __shared__ int s_w[16];
+  const int n = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int32_t* src = row_nnz + (int64_t)n * T_dst;
+  I* dst = crow + (int64_t)n * (T_dst + 1);
+  long long carry = 0;
+  for (int t0 = 0; t0 < T_dst; t0 += 1024) {
+    const int t = t0 + tid;
+    const int v = t < T_dst ? src[t] : 0;
+    const int incl = wave_incl_scan(v);
+    if (lane == 63) s_w[w] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { const int x = s_w[i]; if (i < w) base += x; tot += x; }
+    __syncthreads();
+    if (t < T_dst) dst[t] = (I)(carry + base + incl - v);
+    carry += tot;
+  }
+  if (tid == 0) dst[T_dst] = (I)carry;
+}
+
+// ---- emit column indices ----------------------------------------------------------------------------
+struct EmitParams {
+  const uint32_t* bits;
+  const void* crow;
+  int H, T_dst, T_m, T_src, is_causal, max_k, W;
+  void* col;
+  int64_t col_stride_n, z_cap;
+  float* values_out;
+};
+
+template <typename I>
+__global__ __launch_bounds__(TK_THREADS) void csr_emit_kernel(EmitParams p) {
+  __shared__ int s_wave[TK_WAVES];
+  const int tid = threadIdx.x;
+  const int row = blockIdx.x;
+  const int n = row / p.T_dst, t = row - n * p.T_dst;
+  const I* crow = reinterpret_cast<const I*>(p.crow) + (int64_t)n * (p.T_dst + 1);
+  const int64_t row_beg = (int64_t)crow[t];
+  const int64_t row_end = (int64_t)crow[t + 1];
+  if (row_end == row_beg) return;
+  I* col = reinterpret_cast<I*>(p.col) + n * p.col_stride_n;
+  float* vals = p.values_out ? p.values_out + n * p.col_stride_n : nullptr;
+  const uint32_t* bits = p.bits + (int64_t)row * p.W;
+  const int w_t = row_width(t, p.T_dst, p.T_src, p.is_causal);
+  const float scale = interp_scale(w_t, p.T_m);
+
+  int carry = 0;
+  for (int w0 = 0; w0 < p.W; w0 += TK_THREADS) {
+    const int wi = w0 + tid;
+    uint32_t word = wi < p.W ? bits[wi] : 0u;
+    // pass 1: entries produced by this thread's 32 pixels
+    int mine = 0;
+    {
+      uint32_t m = word;
+      while (m) {
+        const int bit = __ffs(m) - 1;
+        m &= m - 1;
+        const int f = wi * 32 + bit;
+        const int b = f % p.T_m;
+        int w = (int)(interp_bound(b + 1, scale) - interp_bound(b, scale));
+        mine += w < p.max_k ? w : p.max_k;
+      }
+    }
+    int total;
+    int off = carry + block_excl_scan(mine, s_wave, &total);
+    carry += total;
+    // pass 2: write them (keys descending inside a pixel, causal_resize_m_to_t.py:569)
+    uint32_t m = word;
+    while (m) {
+      const int bit = __ffs(m) - 1;
+      m &= m - 1;
+      const int f = wi * 32 + bit;
+      const int h = f / p.T_m, b = f - h * p.T_m;
+      const float vs = interp_bound(b, scale), ve = interp_bound(b + 1, scale);
+      const int width = (int)(ve - vs);
+      const int cnt = width < p.max_k ? width : p.max_k;
+      if (cnt <= 0) continue;
+      const float hbase = (float)(h * p.T_src);
+      const float rs = vs + hbase, re = ve + hbase;
+      const float step = __fdiv_rn(re - rs, (float)cnt);
+      const int64_t o = row_beg + off;
+      for (int i = 0; i < cnt; ++i) {
+        const float c = (re - (float)(int)__fmul_rn((float)i, step)) - 1.0f;
+        if (o + i < p.z_cap) {
+          col[o + i] = (I)c;
+          if (vals) vals[o + i] = 1.0f;
+        }
+      }
+      off += cnt;
+    }
+  }
+}
+
+// ---- per-(row, head) offsets of a foreign flat CSR (rows grouped by ascending head) ----------------
+template <typename I>
+__global__ __launch_bounds__(TK_THREADS) void head_offsets_kernel(const I* crow_all, const I* col_all, int H, int T_dst,
+                                                                 int T_src, int64_t col_stride_n, int32_t* head_off) {
+  __shared__ int s_head[1024];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int row = blockIdx.x;
+  const int n = row / T_dst, t = row - n * T_dst;
+  const I* crow = crow_all + (int64_t)n * (T_dst + 1);
+  const I* col = col_all + n * col_stride_n;
+  const int64_t beg = crow[t], end = crow[t + 1];
+  for (int i = tid; i < H; i += TK_THREADS) s_head[i] = 0;
+  __syncthreads();
+  for (int64_t e0 = beg; e0 < end; e0 += TK_THREADS) {
+    const int64_t e = e0 + tid;
+    int h = -1;
+    if (e < end) h = (int)(col[e] / T_src);
+    // aggregate equal heads inside the wave (entries are grouped, so 1-3 rounds)
+    unsigned long long active = __ballot(h >= 0);
+    while (active) {
+      const int src_lane = __ffsll((long long)active) - 1;
+      const int h0 = __shfl(h, src_lane);
+      const unsigned long long same = __ballot(h == h0);
+      if (lane == src_lane) atomicAdd(&s_head[h0], __popcll(same));
+      active &= ~same;
+    }
+  }
+  __syncthreads();
+  if (wv == 0) {
+    int carry = 0;
+    int32_t* ho = head_off + (int64_t)row * (H + 1);
+    for (int h0 = 0; h0 < H; h0 += 64) {
+      const int h = h0 + lane;
+      const int v = h < H ? s_head[h] : 0;
+      const int incl = wave_incl_scan(v);
+      if (h < H) ho[h] = carry + incl - v;
+      carry += __shfl(incl, 63);
+    }
+    if (lane == 0) ho[H] = carry;
+  }
+}
+
+// ---- host side -----------------------------------------------------------------------------------
+static int group_lanes(int T_m) {
+  int q = T_m / 4, g = 1;
+  while (g < 64 && (q % (g * 2)) == 0) g *= 2;
+  return g;
+}
+
+template <typename T, bool FROM_MASK>
+static int launch_select(const TopkParams& p, int64_t rows, hipStream_t s) {
+  const int ept = ((p.nchunks + TK_THREADS - 1) / TK_THREADS) * 4;
+  dim3 grid((unsigned)rows), block(TK_THREADS);
+  if (ept <= 4) hipLaunchKernelGGL((topk_select_kernel<T, 4, FROM_MASK>), grid, block, 0, s, p);
+  else if (ept <= 8) hipLaunchKernelGGL((topk_select_kernel<T, 8, FROM_MASK>), grid, block, 0, s, p);
+  else if (ept <= 16) hipLaunchKernelGGL((topk_select_kernel<T, 16, FROM_MASK>), grid, block, 0, s, p);
+  else if (ept <= 32) hipLaunchKernelGGL((topk_select_kernel<T, 32, FROM_MASK>), grid, block, 0, s, p);
+  else if (ept <= 40) hipLaunchKernelGGL((topk_select_kernel<T, 40, FROM_MASK>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((topk_select_kernel<T, 64, FROM_MASK>), grid, block, 0, s, p);
+  return 0;
+}
+
+template <bool FROM_MASK>
+static int select_common(const char* name, const void* src, int dtype, int64_t N, int64_t H, int64_t T_dst, int64_t T_m,
+                         int64_t sn, int64_t sh, int64_t st, const int32_t* keep, int64_t keep_stride_n, int64_t T_src,
+                         int is_causal, int max_k, uint32_t* bits, float* mask_out, int32_t* row_nnz, int32_t* head_off,
+                         hipStream_t s) {
+  SEA_REQUIRE(src && bits && row_nnz && head_off, SEA_EINVAL, "%s: null pointer", name);
+  SEA_REQUIRE(FROM_MASK || keep, SEA_EINVAL, "%s: keep is null", name);
+  SEA_REQUIRE(N > 0 && H > 0 && T_dst > 0 && T_m > 0 && T_src >= T_dst, SEA_EINVAL, "%s: bad shape", name);
+  SEA_REQUIRE(T_m % 4 == 0, SEA_EUNSUPPORTED, "%s: T_m=%lld must be a multiple of 4", name, (long long)T_m);
+  SEA_REQUIRE(H * T_m <= 16384 && H <= 1024, SEA_EUNSUPPORTED, "%s: H*T_m=%lld > 16384", name, (long long)(H * T_m));
+  SEA_REQUIRE(N * T_dst < (1ll << 31), SEA_EUNSUPPORTED, "%s: too many rows", name);
+  const int esz = dtype == SEA_F32 ? 4 : 2;
+  SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_F16 || dtype == SEA_BF16, SEA_EINVAL, "%s: bad dtype %d", name, dtype);
+  SEA_REQUIRE(((uintptr_t)src % (4 * esz)) == 0 && sn % 4 == 0 && sh % 4 == 0 && st % 4 == 0, SEA_EUNSUPPORTED,
+              "%s: rows must be 4-element aligned", name);
+  SEA_REQUIRE(max_k > 0, SEA_EINVAL, "%s: max_k must be positive", name);
+  TopkParams p;
+  p.src = src; p.sn = sn; p.sh = sh; p.st = st;
+  p.H = (int)H; p.T_dst = (int)T_dst; p.T_m = (int)T_m; p.T_src = (int)T_src;
+  p.is_causal = is_causal; p.max_k = max_k;
+  p.M = (int)(H * T_m); p.nchunks = p.M / 4; p.W = (p.M + 31) / 32; p.G = group_lanes((int)T_m);
+  p.keep = keep; p.keep_stride_n = keep_stride_n;
+  p.bits = bits; p.mask_out = mask_out; p.row_nnz = row_nnz; p.head_off = head_off;
+  const int64_t rows = N * T_dst;
+  if (dtype == SEA_F32) launch_select<float, FROM_MASK>(p, rows, s);
+  else if (dtype == SEA_F16) launch_select<__half, FROM_MASK>(p, rows, s);
+  else launch_select<__hip_bfloat16, FROM_MASK>(p, rows, s);
+  SEA_CHECK_LAUNCH(name);
+  return SEA_OK;
+}
+
+}  // namespace sea
+
+using namespace sea;
+
+extern "C" int sea_topk_select(const void* probs, int dtype, int64_t N, int64_t H, int64_t T_dst, int64_t T_m,
+                               int64_t stride_n, int64_t stride_h, int64_t stride_t, const int32_t* keep,
+                               int64_t keep_stride_n, int64_t T_src, int is_causal, int max_k, uint32_t* bits,
+                               float* mask_out, int32_t* row_nnz, int32_t* head_off, sea_stream_t stream) {
+  return select_common<false>("sea_topk_select", probs, dtype, N, H, T_dst, T_m, stride_n, stride_h, stride_t, keep,
+                              keep_stride_n, T_src, is_causal, max_k, bits, mask_out, row_nnz, head_off,
+                              (hipStream_t)stream);
+}
+
+extern "C" int sea_mask_to_bits(const void* mask, int dtype, int64_t N, int64_t H, int64_t T_dst, int64_t T_m,
+                                int64_t stride_n, int64_t stride_h, int64_t stride_t, int64_t T_src, int is_causal,
+                                int max_k, uint32_t* bits, int32_t* row_nnz, int32_t* head_off, sea_stream_t stream) {
+  return select_common<true>("sea_mask_to_bits", mask, dtype, N, H, T_dst, T_m, stride_n, stride_h, stride_t, nullptr, 0,
+                             T_src, is_causal, max_k, bits, nullptr, row_nnz, head_off, (hipStream_t)stream);
+}
+
+extern "C" int sea_csr_row_scan(const int32_t* row_nnz, int64_t N, int64_t T_dst, void* crow, int idx_bytes,
+                                sea_stream_t stream) {
+  SEA_REQUIRE(row_nnz && crow, SEA_EINVAL, "sea_csr_row_scan: null pointer");
+  SEA_REQUIRE(idx_bytes == 4 || idx_bytes == 8, SEA_EINVAL, "sea_csr_row_scan: idx_bytes must be 4 or 8");
+  SEA_REQUIRE(N > 0 && T_dst > 0, SEA_EINVAL, "sea_csr_row_scan: bad shape");
+  hipStream_t s = (hipStream_t)stream;
+  if (idx_bytes == 4)
+    hipLaunchKernelGGL((row_scan_kernel<int32_t>), dim3((unsigned)N), dim3(1024), 0, s, row_nnz, (int)T_dst, (int32_t*)crow);
+  else
+    hipLaunchKernelGGL((row_scan_kernel<int64_t>), dim3((unsigned)N), dim3(1024), 0, s, row_nnz, (int)T_dst, (int64_t*)crow);
+  SEA_CHECK_LAUNCH("sea_csr_row_scan");
+  return SEA_OK;
+}
+
+extern "C" int sea_csr_emit(const uint32_t* bits, const void* crow, const int32_t* head_off, int64_t N, int64_t H,
+                            int64_t T_dst, int64_t T_m, int64_t T_src, int is_causal, int max_k, void* col, int idx_bytes,
+                            int64_t col_stride_n, int64_t z_cap, float* values_out, sea_stream_t stream) {
+  (void)head_off;  // offsets follow from the flat (head-major) emission order; kept in the ABI for symmetry
+  SEA_REQUIRE(bits && crow && col, SEA_EINVAL, "sea_csr_emit: null pointer");
+  SEA_REQUIRE(idx_bytes == 4 || idx_bytes == 8, SEA_EINVAL, "sea_csr_emit: idx_bytes must be 4 or 8");
+  SEA_REQUIRE(N > 0 && H > 0 && T_dst > 0 && T_m > 0 && max_k > 0, SEA_EINVAL, "sea_csr_emit: bad shape");
+  SEA_REQUIRE(H * T_src < (1ll << 24), SEA_EUNSUPPORTED, "sea_csr_emit: H*T_src must stay below 2^24 (fp32-exact ids)");
+  if (z_cap == 0) return SEA_OK;
+  EmitParams p;
+  p.bits = bits; p.crow = crow;
+  p.H = (int)H; p.T_dst = (int)T_dst; p.T_m = (int)T_m; p.T_src = (int)T_src;
+  p.is_causal = is_causal; p.max_k = max_k; p.W = (int)((H * T_m + 31) / 32);
+  p.col = col; p.col_stride_n = col_stride_n; p.z_cap = z_cap; p.values_out = values_out;
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)(N * T_dst)), block(TK_THREADS);
+  if (idx_bytes == 4) hipLaunchKernelGGL((csr_emit_kernel<int32_t>), grid, block, 0, s, p);
+  else hipLaunchKernelGGL((csr_emit_kernel<int64_t>), grid, block, 0, s, p);
+  SEA_CHECK_LAUNCH("sea_csr_emit");
+  return SEA_OK;
+}
+
+extern "C" int sea_csr_head_offsets(const void* crow, const void* col, int idx_bytes, int64_t N, int64_t H,
+                                    int64_t T_dst, int64_t T_src, int64_t col_stride_n, int32_t* head_off,
+                                    sea_stream_t stream) {
+  SEA_REQUIRE(crow && col && head_off, SEA_EINVAL, "sea_csr_head_offsets: null pointer");
+  SEA_REQUIRE(idx_bytes == 4 || idx_bytes == 8, SEA_EINVAL, "sea_csr_head_offsets: idx_bytes must be 4 or 8");
+  SEA_REQUIRE(H > 0 && H <= 1024, SEA_EUNSUPPORTED, "sea_csr_head_offsets: H must be in 1..1024");
+  hipStream_t s = (hipStream_t)stream;
+  dim3 grid((unsigned)(N * T_dst)), block(TK_THREADS);
+  if (idx_bytes == 4)
+    hipLaunchKernelGGL((head_offsets_kernel<int32_t>), grid, block, 0, s, (const int32_t*)crow, (const int32_t*)col, (int)H,
+                       (int)T_dst, (int)T_src, col_stride_n, head_off);
+  else
+    hipLaunchKernelGGL((head_offsets_kernel<int64_t>), grid, block, 0, s, (const int64_t*)crow, (const int64_t*)col, (int)H,
+                       (int)T_dst, (int)T_src, col_stride_n, head_off);
+  SEA_CHECK_LAUNCH("sea_csr_head_offsets");
+  return SEA_OK;
+}

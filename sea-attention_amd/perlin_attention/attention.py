@@ -1,0 +1,488 @@
+"""PerlinAttention -- the SEA attention module, MI355X build.
+
+Drop-in for the reference class of the same name (src/models/perlin_attention/attention.py:133-1359):
+same constructor, same `forward` signature (:333-347), same parameter / buffer names (trained
+checkpoints load), same `benchmarking` mode switch (:152), same `PerlinAttentionOutput` (:84-106),
+same timing-region and temp-buffer names (they are the reference's parity probes,
+src/main/tests/test_perlin_opt_consist.py:198-232).
+
+Two modes, as in the reference:
+
+* `benchmarking = False` (default; training / PPL evaluation): dense T x T scores with an additive
+  mask (:1061-1133).  Plain torch, runs on CPU too -- this is the reference's own CPU-runnable path.
+* `benchmarking = True`: the sparse path.  Steps H..K of SURVEY.md section 3B run as hand-written HIP
+  kernels through libsea_hip.so:
+      grouped top-k + interpolation -> flat CSR      (ops.topk_to_csr;   replaces :774-947, :1034-1042)
+      SDDMM + softmax + scale + SpMM + avg-pool mix   (ops.sparse_attention; replaces :1158-1173, :1236-1237)
+  with no host synchronisation between them.  There is no fallback: without the library or on a CPU
+  tensor this mode raises.
+
+Scope of this round: the causal configuration (`pconfig.causal=True`, `k_flatten_dim='causal_batch'`,
+the only one the OPT/LLaMA path constructs -- perlin_opt.py:224-239) without kv-cache.
+"""
+import math
+import os
+import warnings
+from typing import NamedTuple, Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from ..utils import get_bench
+from .config import PerlinAttentionConfig, get_default_config
+from .modules import CausalConv2d, KeepRes, UpsampleFP32
+from .performer import FastAttention, ProjectionUpdater
+from . import ops
+
+timer = lambda name: get_bench().region(name)
+mem = lambda name: get_bench().mem_region(name)
+
+
+def _safe_to(t, d):
+    return t.to(d) if isinstance(t, torch.Tensor) else t
+
+
+class PerlinAttentionOutput(NamedTuple):
+    loss: torch.Tensor
+    context_layer: torch.Tensor
+    partial_attention_probs: torch.Tensor
+    partial_attention_mask: torch.Tensor
+    estimated_attention_probs_m: torch.Tensor
+    estimated_attention_probs: torch.Tensor
+    dense_attention_probs: torch.Tensor
+    key_for_score: torch.Tensor
+    state: object
+
+    def to(self, device):
+        return PerlinAttentionOutput(*[_safe_to(f, device) for f in self])
+
+
+class ModuleBenchmark(nn.Module):
+    """Named timing wrapper; keeps the `.module` nesting of the reference's state dict (:108-121)."""
+
+    def __init__(self, name, module, disabled=False):
+        super().__init__()
+        self.name = name
+        self.module = module
+        self.disabled = disabled
+
+    def forward(self, x):
+        if self.disabled:
+            return self.module(x)
+        with timer(self.name):
+            return self.module(x)
+
+
+class ChannelSplit(nn.Module):
+    """(N, C, H, W) -> (N, C*split, H, W/split): the decoder row is cut into `split` conv channels (:123-131)."""
+
+    def __init__(self, split):
+        super().__init__()
+        self.split = split
+
+    def forward(self, x):
+        N, C, H, W = x.shape
+        s = self.split
+        return x.view(N, C, H, s, W // s).permute(0, 1, 3, 2, 4).reshape(N, C * s, H, W // s)
+
+
+def _kl_and_mse(est_scores, truth_scores, causal_mask, fp_min):
+    """KD terms of the causal path (:741-763 / :1086-1103): 0.1*KL(batchmean) + MSE on fp32 softmaxes."""
+    dead = causal_mask < -1
+    W = est_scores.shape[-1]
+    logp = F.log_softmax(est_scores.masked_fill(dead, fp_min).float(), dim=-1).view(-1, W)
+    tgt = F.softmax(truth_scores.masked_fill(dead, fp_min).float(), dim=-1).view(-1, W)
+    kl = F.kl_div(logp, tgt, reduction='batchmean') * 0.1
+    mse = F.mse_loss(F.softmax(est_scores.masked_fill(dead, fp_min).float(), dim=-1).view(-1, W), tgt)
+    return kl + mse
+
+
+class PerlinAttention(nn.Module):
+    def __init__(self, config, perlin_config: PerlinAttentionConfig = None):
+        super().__init__()
+        self.config = config
+        self.pconfig = perlin_config if perlin_config is not None else get_default_config()
+
+        self.num_attention_heads = config.num_attention_heads
+        self.attention_head_size = int(config.hidden_size / config.num_attention_heads)
+        self.all_head_size = self.num_attention_heads * self.attention_head_size
+        self._warning_messages = ""
+
+        # mode switch, set from outside by walking model.modules() (benchmark_bert.py:172-173)
+        self.benchmarking = False
+        # dtype of context_layer in sparse mode; None = the reference's behaviour (fp32, sdbmm.py:347)
+        self.context_layer_dtype = None
+        # sparse mode: None = decide by inspecting the mask (one host sync, as the reference does at :434);
+        # True/False = the caller already knows whether the batch carries padding
+        self.assume_not_padded = None
+        # sparse mode: return the mask as a torch.sparse_csr_tensor (int64, one host sync for Z) instead of
+        # the internal int32 FlatCSR handle
+        self.materialize_csr = False
+
+        d, H = self.attention_head_size, self.num_attention_heads
+        pc = self.pconfig
+
+        # ---- estimator: Performer -----------------------------------------------------------------
+        self.performer_nb_features = int(d * math.log(d) / pc.performer_nb_factor)
+        self.performer = FastAttention(dim_heads=d, nb_features=self.performer_nb_features,
+                                       causal=pc.causal, generalized_attention=pc.causal)
+        self.performer_proj_updater = ProjectionUpdater(self.performer, 1000)
+
+        # ---- predictor: MLP encoder, row decoder, CNN ---------------------------------------------
+        pv = d * 3
+        self.register_buffer('attention_predictor_enc_head_embd', torch.eye(H))
+        self.attention_predictor_enc_per_layer = nn.Sequential(
+            nn.Linear(pv * H, d * 2 * H), nn.LayerNorm(d * 2 * H), nn.GELU())
+        self.attention_predictor_enc = nn.Sequential(nn.Linear(pv, d * 2), nn.LayerNorm(d * 2), nn.GELU())
+        T_M = pc.attention_predictor_length
+        if not pc.causal:
+            self.attention_predictor_dec_row_down_scale = 2
+            self.attention_predictor_dec_row_splits = 4
+            self.attention_predictor_dec_row_out_ch = (T_M // 2) * 4
+            self.attention_predictor_dec_row = nn.Sequential(
+                nn.Linear(d * 2, self.attention_predictor_dec_row_out_ch), ChannelSplit(4))
+            self.attention_predictor_cnn = nn.Sequential(KeepRes(
+                nn.Conv2d(4 * H, 4 * H, 3, padding=1, stride=(2, 1)), nn.ReLU(),
+                nn.Conv2d(4 * H, 4 * H, 3, padding=1), nn.ReLU(),
+                UpsampleFP32((2, 1), torch.float16),
+                nn.Conv2d(4 * H, H, 3, padding=1),
+                output_width=T_M))
+        else:
+            inner = int(os.environ.get("PERLIN_HOTFIX_OPT_INNER_CH", "2"))
+            if inner != 2:
+                self._warning_messages += f'WARN, you are using hotfix backend. PERLIN_HOTFIX_OPT_INNER_CH {inner}\n'
+            self.attention_predictor_dec_row_down_scale = 4
+            self.attention_predictor_dec_row_splits = inner
+            self.attention_predictor_dec_row_out_ch = (T_M // 4) * inner
+            self.attention_predictor_dec_row = nn.Sequential(
+                nn.Linear(d * 2, self.attention_predictor_dec_row_out_ch), ChannelSplit(inner))
+            deeper = int(os.environ.get("PERLIN_HOTFIX_OPT_DEEPER", "0")) == 1
+            if deeper:
+                self._warning_messages += 'WARN, you are using hotfix backend. PERLIN_HOTFIX_OPT_DEEPER\n'
+            conv = lambda name: ModuleBenchmark(
+                name, CausalConv2d(inner * H, inner * H, 3, padding=2, dilation=2, stride=(1, 1), causal=True))
+            body = [conv('cnn.keepres.conv1'), nn.ReLU(), conv('cnn.keepres.conv2'), nn.ReLU()]
+            if deeper:
+                body += [conv('cnn.keepres.conv3'), nn.ReLU()]
+            body += [ModuleBenchmark('cnn.keepres.upsam', UpsampleFP32((1, 4), torch.float16)),
+                     ModuleBenchmark('cnn.keepres.conv4', CausalConv2d(inner * H, H, 1, padding=1, causal=True))]
+            self.attention_predictor_cnn = nn.Sequential(
+                ModuleBenchmark('cnn.lnorm1', nn.LayerNorm(T_M // 4)),
+                ModuleBenchmark('cnn.keepres', KeepRes(*body, output_width=T_M)),
+                ModuleBenchmark('cnn.lnorm2', nn.LayerNorm(T_M)))        # keeps the causal model from exploding
+        self.attention_predictor_dec_scaler = nn.Sequential(nn.Linear(d * 2, 2))
+
+        if pc.attention_predictor_method == 'comp':
+            raise NotImplementedError("attention_predictor_method='comp' (attention.py:293-312) is outside this build")
+
+        # ---- output ------------------------------------------------------------------------------
+        self.norm_performer = nn.LayerNorm(config.hidden_size)
+        self.norm_partial = nn.LayerNorm(config.hidden_size)
+        self.norm_random = nn.LayerNorm(config.hidden_size)
+        self.norm = nn.LayerNorm(config.hidden_size)
+        self.register_buffer('_v_eye', None, persistent=False)
+        self.v_eye_learned = nn.Parameter(torch.rand((1, 1, d, d)))
+        max_pos = getattr(config, 'max_position_embeddings', 2048)
+        self.v_eye_learned_causal = nn.Parameter(torch.randn((1, 1, max_pos, d)))
+
+        self._keep_cache = {}
+
+    # ------------------------------------------------------------------------------------------------
+    def _keep_table(self, H, T_dst, T_src, T_M, device):
+        """K_t (int32, device) + analytic CSR capacity, cached per shape (host work only once)."""
+        k, os_ = self.pconfig.k, self.pconfig.k_oversample
+        key = (H, T_dst, T_src, T_M, k, os_, str(device))
+        hit = self._keep_cache.get(key)
+        if hit is None:
+            keep_cpu = ops.keep_table_causal(H, T_dst, T_M, k, os_)
+            z_cap = ops.z_capacity(keep_cpu, H, T_dst, T_src, T_M, int(k), True)
+            hit = (keep_cpu.to(device), z_cap)
+            self._keep_cache[key] = hit
+        return hit
+
+    def _estimate(self, q, k, v, q_for_atten, k_for_atten, v_for_atten, dst_attention_mask, not_padded, T_SRC):
+        """Steps A..G: value augmentation, Performer, predictor MLP + CNN, softmax over T_M."""
+        bench = get_bench()
+        with timer("vmask"):
+            with timer("vmask.cat_fill"):
+                pos = self.v_eye_learned_causal[:, :, :T_SRC, :]
+                v_for_atten = torch.cat([pos.expand(v_for_atten.shape).to(v_for_atten.dtype), v_for_atten], dim=-1)
+                bench.register_temp_buffer('v_for_atten', v_for_atten)
+                if not not_padded:
+                    v_for_atten = v_for_atten.masked_fill(dst_attention_mask < -1, 0)
+                    v = v.masked_fill(dst_attention_mask < -1, 0)
+        with timer("performer"):
+            # the estimator always runs in fp32 (attention.py:520-534)
+            performer_context_layer = self.performer(q_for_atten.float(), k_for_atten.float(), v_for_atten.float())
+            performer_context_layer = performer_context_layer.to(q_for_atten.dtype)
+            bench.register_temp_buffer('performer_context_layer', performer_context_layer)
+        with timer("performer_value"):
+            performer_value = torch.cat([performer_context_layer, v], dim=-1)
+            bench.register_temp_buffer('performer_value', performer_value)
+        with timer("predictor"):
+            query_skips = int(os.environ.get('QUERY_SKIPS', '1'))
+            with timer("predictor.enc"):
+                if self.pconfig.attention_predictor_enc_per_layer:
+                    N, H, T, D3 = performer_value.shape
+                    x = performer_value.permute(0, 2, 1, 3).reshape(N, T, H * D3)
+                    t_attention_predictor = self.attention_predictor_enc_per_layer(x)
+                    t_attention_predictor = t_attention_predictor.view(N, T, H, -1).permute(0, 2, 1, 3)
+                else:
+                    x = performer_value
+                    if query_skips > 1:
+                        assert (x.shape[-2] % query_skips) == 0
+                        x = x[:, :, ::query_skips, :]
+                    t_attention_predictor = self.attention_predictor_enc(x)
+            with timer("predictor.dec_row"):
+                estimated_attention_score = self.attention_predictor_dec_row(t_attention_predictor)
+                bench.register_temp_buffer('estimated_attention_score_dec_row', estimated_attention_score)
+            with timer("predictor.cnn"):
+                estimated_attention_score = self.attention_predictor_cnn(estimated_attention_score)
+                if query_skips > 1:
+                    estimated_attention_score = estimated_attention_score.repeat_interleave(query_skips, dim=-2)
+                    t_attention_predictor = t_attention_predictor.repeat_interleave(query_skips, dim=-2)
+            bench.register_temp_buffer('t_attention_predictor', t_attention_predictor)
+        with timer("mask_softmax"):
+            estimated_attention_probs = torch.softmax(estimated_attention_score.float(), dim=-1) \
+                .to(estimated_attention_score.dtype)
+        bench.register_temp_buffer('estimated_attention_score', estimated_attention_score)
+        bench.register_temp_buffer('estimated_attention_probs', estimated_attention_probs)
+        return v, t_attention_predictor, estimated_attention_score, estimated_attention_probs
+
+    # ------------------------------------------------------------------------------------------------
+    def forward(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor,
+                q_for_atten: torch.Tensor, k_for_atten: torch.Tensor, v_for_atten: torch.Tensor,
+                q_for_score: torch.Tensor, k_for_score: torch.Tensor,
+                attention_mask: torch.Tensor, attention_scores_truth: torch.Tensor,
+                context_layer_truth: torch.Tensor, last_state=None):
+        bench = get_bench()
+        dynamic_k = int(os.environ.get('DYNAMIC_K', '0'))
+        if dynamic_k > 0:
+            warnings.warn(f'dynamic k {dynamic_k}')
+            self.pconfig.k = dynamic_k
+        if self._warning_messages:
+            print(self._warning_messages)
+            self._warning_messages = ''
+        if not self.pconfig.causal:
+            raise NotImplementedError("non-causal (BERT) SEA is outside this build's scope (SURVEY.md 2.1 #12)")
+        if self.pconfig.use_cache or last_state is not None:
+            raise NotImplementedError("kv-cache decoding state (attention_state.py) is a next-tier item (SURVEY.md 8f-3)")
+
+        if context_layer_truth is not None:
+            if callable(context_layer_truth):
+                with torch.no_grad():
+                    context_layer_truth = context_layer_truth()
+            context_layer_truth = context_layer_truth.to(q.device, non_blocking=True)
+            if callable(attention_scores_truth):
+                with torch.no_grad():
+                    attention_scores_truth = attention_scores_truth()
+            attention_scores_truth = attention_scores_truth.to(q.device, non_blocking=True)
+
+        if q.dtype in (torch.float16, torch.bfloat16):
+            FP_MIN = torch.finfo(torch.float16).min / 2        # fp16 floor even for bf16 (:395-396)
+        elif q.dtype == torch.float32:
+            FP_MIN = torch.finfo(torch.float32).min / 2
+        else:
+            raise Exception('unknown type')
+
+        N, H1, T_DST, T_SRC = attention_mask.shape
+        assert T_DST == T_SRC
+        assert H1 == 1
+        causal_attention_mask = attention_mask
+        attention_mask = attention_mask[:, :, :, :1].transpose(-1, -2)
+        dst_attention_mask = causal_attention_mask[:, :, :, :1]
+        if self.benchmarking and self.assume_not_padded is not None:
+            not_padded = bool(self.assume_not_padded)          # caller knows; skips the reference's sync (:434)
+        else:
+            not_padded = bool((attention_mask > -1).all().item())
+
+        bench.register_temp_buffer('q', q)
+        bench.register_temp_buffer('k', k)
+        bench.register_temp_buffer('v', v)
+        bench.register_temp_buffer('attention_mask', attention_mask)
+
+        with timer("perlin"):
+            N, H, T, HID = q.shape
+            v, t_attention_predictor, estimated_attention_score, estimated_attention_probs = self._estimate(
+                q, k, v, q_for_atten, k_for_atten, v_for_atten, dst_attention_mask, not_padded, T_SRC)
+            T_M = estimated_attention_probs.shape[-1]
+            assert estimated_attention_probs.shape[-2] == T_DST
+
+            def resize_dense(x, fill, handle_oversample=True):
+                return ops.resize_from_m_to_t(
+                    x=x, masked_fill_value=fill, attention_mask=causal_attention_mask, target_width=T_SRC,
+                    training=self.training and self.pconfig.causal, is_causal=True, k=self.pconfig.k,
+                    oversampled=self.pconfig.k_oversample if handle_oversample else 1.0)
+
+            loss = 0
+            estimated_attention_probs_resized = None
+            if not self.benchmarking and attention_scores_truth is not None:
+                estimated_attention_probs_resized = resize_dense(estimated_attention_probs, 0, False)
+                estimated_attention_score_resized = resize_dense(estimated_attention_score, FP_MIN, False).float()
+                loss = loss + _kl_and_mse(estimated_attention_score_resized, attention_scores_truth,
+                                          causal_attention_mask, FP_MIN)
+                bench.register_temp_buffer('estimated_attention_probs_resized', estimated_attention_probs_resized)
+                bench.register_temp_buffer('estimated_attention_score_resized', estimated_attention_score_resized)
+
+            if not not_padded:
+                estimated_attention_probs = estimated_attention_probs * (dst_attention_mask > -1)
+            bench.register_temp_buffer('masked_estimated_attention_probs', estimated_attention_probs)
+
+            if self.benchmarking:
+                out = self._forward_sparse(q, v, q_for_score, k_for_score, t_attention_predictor,
+                                           estimated_attention_probs, dst_attention_mask, not_padded, T_SRC, T_M)
+                partial_context_layer, partial_attention_probs, partial_attention_mask = out
+                attention_probs_dense = None
+            else:
+                out = self._forward_dense(q, v, q_for_score, k_for_score, t_attention_predictor,
+                                          estimated_attention_probs, causal_attention_mask, dst_attention_mask,
+                                          attention_scores_truth, FP_MIN, T_SRC, T_M, resize_dense)
+                partial_context_layer, partial_attention_probs, partial_attention_mask, attention_probs_dense, l2 = out
+                loss = loss + l2
+
+            bench.register_temp_buffer('partial_context_layer_sparse', partial_context_layer)
+            if self.pconfig.context_output_method != 'mix':
+                raise Exception("only context_output_method='mix' is live in the reference (:1286-1314)")
+
+            if not self.benchmarking and context_layer_truth is not None:
+                loss = loss + F.mse_loss(context_layer_truth, partial_context_layer)
+
+            estimated_for_output = estimated_attention_probs if self.benchmarking else estimated_attention_probs_resized
+            bench.register_temp_buffer('partial_context_layer', partial_context_layer)
+            assert partial_context_layer.shape[-2] == q.shape[-2]
+
+            return PerlinAttentionOutput(
+                loss=loss,
+                context_layer=partial_context_layer,
+                partial_attention_probs=partial_attention_probs,
+                partial_attention_mask=partial_attention_mask,
+                estimated_attention_probs_m=estimated_attention_probs,
+                estimated_attention_probs=estimated_for_output,
+                dense_attention_probs=attention_probs_dense,
+                key_for_score=k_for_score,
+                state=None,
+            )
+
+    # ------------------------------------------------------------------------------------------------
+    def _forward_sparse(self, q, v, q_for_score, k_for_score, t_attention_predictor, probs, dst_attention_mask,
+                        not_padded, T_SRC, T_M):
+        """Steps H..L on HIP: no host sync, no (N,T,H*T_M) sort, no dense (N,H,T,T) tensor."""
+        bench = get_bench()
+        N, H, T, HID = q.shape
+        probing = bench.activate_temp_buffers
+        with timer("mask"):
+            keep, z_cap = self._keep_table(H, T, T_SRC, T_M, q.device)
+            bench.register_temp_buffer('per_item_top_k', None, lazy=lambda: keep.float().view(1, T, 1))
+        with timer("interp"):
+            if probs.stride(-1) != 1:
+                probs = probs.contiguous()
+            if not not_padded:
+                # padded query rows keep nothing (the reference zeroes those mask rows, :927-931)
+                keep = (keep.view(1, T) * (dst_attention_mask.view(N, T) > -1).to(torch.int32)).contiguous()
+            csr, mask_m = ops.topk_to_csr(probs, keep, int(self.pconfig.k), target_width=T_SRC, is_causal=True,
+                                          z_cap=z_cap, want_mask=probing)
+        if probing:
+            bench.register_temp_buffer('partial_attention_mask_before_interp', mask_m)
+            bench.register_temp_buffer('partial_attention_mask', None,
+                                       lazy=lambda: ops.flat_csr_to_dense(csr, T_SRC, H))
+        bench.register_temp_buffer('q_for_score', q_for_score)
+        bench.register_temp_buffer('k_for_score', k_for_score)
+
+        with timer("attention"):
+            with timer('attention.sparse.scaler'):
+                estimated_scales = self.attention_predictor_dec_scaler(t_attention_predictor)      # (N,H,T,2)
+                sig = torch.sigmoid(estimated_scales.float())
+                row_scale = sig[..., 0].contiguous() if self.pconfig.partial_attention_scaler else None
+                average_scale = sig[..., 1].contiguous()
+            with timer("attention.avg_pool"):
+                avg_v = v if not_padded else v * (dst_attention_mask > -1)
+                denom = torch.arange(1, T + 1, device=v.device).view(1, 1, -1, 1)
+                average_context_layer = (avg_v.cumsum(-2) / denom).to(v.dtype)
+            out_dtype = self.context_layer_dtype or torch.float32
+            qs = q_for_score if q_for_score.stride(-1) == 1 else q_for_score.contiguous()
+            ks = k_for_score if k_for_score.stride(-1) == 1 else k_for_score.contiguous()
+            vs = v if v.stride(-1) == 1 else v.contiguous()
+            if ks.dtype != qs.dtype:
+                ks = ks.to(qs.dtype)
+            if vs.dtype != qs.dtype:
+                vs = vs.to(qs.dtype)
+            if average_context_layer.dtype != qs.dtype:
+                average_context_layer = average_context_layer.to(qs.dtype)
+            with timer('attention.sparse.fused'):
+                if probing:
+                    p1 = ops.sparse_attention(qs, ks, vs, csr, row_scale=row_scale)               # fp32 (N,H,T,D)
+                    bench.register_temp_buffer('partial_context_layer_1', p1)
+                    a = average_scale.unsqueeze(-1)
+                    p2 = p1 * a + (1 - a) * average_context_layer
+                    bench.register_temp_buffer('estimated_scales', estimated_scales)
+                    bench.register_temp_buffer('average_scale', a)
+                    bench.register_temp_buffer('average_context_layer', average_context_layer)
+                    bench.register_temp_buffer('partial_context_layer_2', p2)
+                    with timer("context_permute"):
+                        ctx = p2.permute(0, 2, 1, 3).contiguous().view(N, T, H * HID).to(out_dtype)
+                else:
+                    # write straight into the (N, T, H*D) layout of :1279-1282
+                    ctx = torch.empty((N, T, H * HID), dtype=out_dtype, device=q.device)
+                    ops.sparse_attention(qs, ks, vs, csr, row_scale=row_scale, avg=average_context_layer,
+                                         mix=average_scale, out=ctx.view(N, T, H, HID).permute(0, 2, 1, 3))
+        csr_out = csr.to_sparse_csr() if self.materialize_csr else csr
+        return ctx, None, csr_out
+
+    # ------------------------------------------------------------------------------------------------
+    def _forward_dense(self, q, v, q_for_score, k_for_score, t_attention_predictor, probs, causal_attention_mask,
+                       dst_attention_mask, attention_scores_truth, FP_MIN, T_SRC, T_M, resize_dense):
+        """The reference's dense branch (:774-947 sort-based top-k, :948-959 gather resize, :1061-1133)."""
+        bench = get_bench()
+        N, H, T, HID = q.shape
+        k_, os_ = self.pconfig.k, self.pconfig.k_oversample
+        loss = 0
+        with timer("mask"):
+            t = probs.transpose(1, 2).reshape(N, T, H * T_M)
+            ctl = torch.arange(1, T + 1, dtype=torch.long, device=q.device).view(1, T, 1)
+            per_item_top_k = torch.clamp_min(torch.round(H * (k_ * os_ * T_M / ctl)), 1)
+            bench.register_temp_buffer('per_item_top_k', per_item_top_k)
+            with timer("mask.topk"):
+                _, indices = torch.sort(t.float(), dim=-1, descending=True, stable=True)
+            rank = torch.empty_like(indices)
+            rank.scatter_(-1, indices, torch.arange(H * T_M, device=q.device).view(1, 1, -1).expand_as(indices))
+            t_dead_mask = rank >= per_item_top_k
+            bench.register_temp_buffer('t_dead_mask', None, lambda: t_dead_mask.float())
+            partial_attention_mask = (t_dead_mask.to(q.dtype) * FP_MIN).view(N, T, H, T_M).transpose(1, 2)
+            partial_attention_mask = partial_attention_mask.masked_fill(dst_attention_mask < -1, FP_MIN)
+        bench.register_temp_buffer('partial_attention_mask_before_interp', partial_attention_mask)
+        with timer("interp"):
+            partial_attention_mask = resize_dense(partial_attention_mask, FP_MIN, True)
+            partial_attention_mask = partial_attention_mask.masked_fill(causal_attention_mask < -1, FP_MIN)
+        bench.register_temp_buffer('partial_attention_mask', partial_attention_mask)
+        bench.register_temp_buffer('q_for_score', q_for_score)
+        bench.register_temp_buffer('k_for_score', k_for_score)
+        with timer("attention"):
+            attention_scores_dense = torch.matmul(q_for_score, k_for_score.transpose(-1, -2))
+            if attention_scores_truth is not None:
+                loss = loss + _kl_and_mse(attention_scores_dense, attention_scores_truth, causal_attention_mask, FP_MIN)
+            bench.register_temp_buffer('attention_scores_dense', attention_scores_dense)
+            attention_probs_dense = torch.softmax((attention_scores_dense + causal_attention_mask).float(), -1) \
+                .to(attention_scores_dense.dtype)
+            partial_attention_scores = attention_scores_dense + partial_attention_mask
+            partial_attention_probs = torch.softmax(partial_attention_scores.float(), -1).to(partial_attention_scores.dtype)
+            partial_attention_probs = partial_attention_probs.masked_fill(partial_attention_mask < -1, 0)
+            bench.register_temp_buffer('partial_attention_scores', partial_attention_scores)
+            bench.register_temp_buffer('attention_matrix', partial_attention_probs)
+            estimated_scales = self.attention_predictor_dec_scaler(t_attention_predictor)
+            if self.pconfig.partial_attention_scaler:
+                partial_attention_probs = partial_attention_probs * torch.sigmoid(estimated_scales[..., 0:1])
+            partial_context_layer = torch.matmul(partial_attention_probs, v)
+            bench.register_temp_buffer('partial_context_layer_1', partial_context_layer)
+            with timer("attention.avg_pool"):
+                avg_v = v * (dst_attention_mask > -1)
+                average_context_layer = (avg_v.cumsum(-2) / torch.arange(1, T + 1, device=v.device).view(1, 1, -1, 1)).to(v.dtype)
+                average_scale = torch.sigmoid(estimated_scales[..., 1:2])
+                partial_context_layer = partial_context_layer * average_scale + (1 - average_scale) * average_context_layer
+                bench.register_temp_buffer('estimated_scales', estimated_scales)
+                bench.register_temp_buffer('average_scale', average_scale)
+                bench.register_temp_buffer('average_context_layer', average_context_layer)
+                bench.register_temp_buffer('partial_context_layer_2', partial_context_layer)
+        with timer("context_permute"):
+            partial_context_layer = partial_context_layer.permute(0, 2, 1, 3).contiguous().view(N, T, H * HID)
+        return partial_context_layer, partial_attention_probs, partial_attention_mask, attention_probs_dense, loss

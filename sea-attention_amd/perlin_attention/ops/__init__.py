@@ -1,0 +1,11 @@
+"""Operator package, same seven exports as the reference (src/models/perlin_attention/ops/__init__.py:1-7)."""
+from .resize_dense import resize_from_m_to_t
+from .flat_csr import resize_from_m_to_t_csr
+from .flat_csr import flat_csr_elmul
+from .flat_csr import flat_csr_masked_bmm
+from .flat_csr import flat_csr_sdbmm
+from .flat_csr import flat_csr_softmax
+from .flat_csr import flat_csr_to_dense
+# fused MI355X entry points (not in the reference)
+from .flat_csr import (FlatCSR, topk_to_csr, topk_mask, sparse_attention, sparse_attention_bytes,
+                       keep_table_causal, keep_table_kernel_test, z_capacity)

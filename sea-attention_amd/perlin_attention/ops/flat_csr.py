@@ -1,0 +1,367 @@
+"""Flat-CSR operators of SEA on MI355X -- host side of libsea_hip.so.
+
+Mirrors the reference's operator package one to one (same names, argument meaning, assertions):
+    src/models/perlin_attention/ops/__init__.py:1-7
+and adds the fused entry points the attention module uses (`topk_to_csr`, `sparse_attention`).
+
+Wire format (reference: ops/kernels/causal_resize_m_to_t.py:757-762): a batched
+`torch.sparse_csr_tensor` of logical shape (N, T_dst, H*T_src), int64 indices, column id =
+head*T_src + key.  Internally the kernels use the int32 `FlatCSR` below and only widen to int64
+when a torch CSR tensor is asked for.
+
+Every operator here launches HIP kernels through the C ABI; CPU tensors are rejected.
+"""
+import math
+from ctypes import c_void_p, c_int64
+from typing import Optional
+
+import torch
+
+from ... import _lib
+
+
+def _p(t: Optional[torch.Tensor]):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+# ------------------------------------------------------------------------------------------------
+# internal format
+# ------------------------------------------------------------------------------------------------
+class FlatCSR:
+    """int32 flat CSR + per-(row, head) offsets, as produced by the fused top-k/interpolate path.
+
+    crow     (N, T_dst+1) int32   row starts inside `col[n]`
+    col      (N, z_cap)   int32   head*T_src + key; entries >= crow[n,-1] are undefined
+    head_off (N, T_dst, H+1) int32
+    """
+
+    def __init__(self, crow, col, head_off, H, T_src, bits=None, row_nnz=None):
+        self.crow, self.col, self.head_off = crow, col, head_off
+        self.H, self.T_src = H, T_src
+        self.bits, self.row_nnz = bits, row_nnz
+        self.N, self.T_dst = crow.shape[0], crow.shape[1] - 1
+
+    @property
+    def shape(self):
+        return (self.N, self.T_dst, self.H * self.T_src)
+
+    @property
+    def is_sparse_csr(self):  # duck-typing for callers that only branch on the layout
+        return True
+
+    def nnz(self) -> torch.Tensor:
+        """device tensor (N,) of valid entries per batch item (no host sync)."""
+        return self.crow[:, -1]
+
+    def to_sparse_csr(self, values: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Materialise the reference's wire format: int64 indices, trimmed to Z = max nnz
+        (one host sync, like `Z = ....max().item()` at causal_resize_m_to_t.py:667)."""
+        Z = int(self.crow[:, -1].max().item())
+        crow = self.crow.to(torch.int64)
+        col = self.col[:, :Z].to(torch.int64)
+        valid = torch.arange(Z, device=col.device).view(1, -1) < crow[:, -1:]
+        col = col * valid                                   # the reference zero-fills the padding
+        if values is None:
+            values = torch.ones((self.N, Z), dtype=torch.float32, device=col.device)
+        else:
+            values = values[:, :Z]
+        return torch.sparse_csr_tensor(crow, col, values, size=self.shape)
+
+
+def keep_table_causal(H, T_dst, T_m, k, k_oversample=1.0, device=None) -> torch.Tensor:
+    """K_t of the module path as int32 (T_dst,), computed with the reference's own fp32 expression
+    (attention.py:800,849,856,866): clamp_min(round(H * (k*os*T_m / arange(1..T))), 1)."""
+    ctl = torch.arange(1, T_dst + 1, dtype=torch.long)
+    per = H * (k * k_oversample * T_m / ctl)
+    per = torch.clamp_min(torch.round(per), 1)
+    per = torch.clamp_max(per, H * T_m)
+    out = per.to(torch.int32)
+    return out.to(device) if device is not None else out
+
+
+def keep_table_kernel_test(H, T_dst, T_m, k, device=None) -> torch.Tensor:
+    """K_t of the reference's kernel self-tests (causal_topk_masking.py:31,37)."""
+    ctl = torch.arange(1, T_dst + 1, dtype=torch.long)
+    per = torch.clamp(H * torch.floor(k * T_m / ctl), 1, H * T_m)
+    out = torch.clamp_min(per, 1).to(torch.int32)
+    return out.to(device) if device is not None else out
+
+
+def z_capacity(keep_cpu: torch.Tensor, H, T_dst, T_src, T_m, max_k, is_causal=True) -> int:
+    """Analytic upper bound of entries per batch item (no device work): row t emits at most
+    min(K_t * min(ceil(w_t/T_m), max_k), H * min(w_t, T_m*max_k)) entries."""
+    w = torch.arange(1, T_src + 1)[-T_dst:] if is_causal else torch.full((T_dst,), T_src)
+    per_pixel = torch.clamp_max(torch.div(w + T_m - 1, T_m, rounding_mode="floor"), max_k)
+    kt = keep_cpu.view(-1, T_dst).max(0).values.to(torch.long)
+    bound = torch.minimum(kt * per_pixel, H * torch.minimum(w, torch.tensor(T_m * max_k)))
+    return max(int(bound.sum().item()), 1)
+
+
+# ------------------------------------------------------------------------------------------------
+# fused path: probs -> FlatCSR
+# ------------------------------------------------------------------------------------------------
+def topk_to_csr(probs: torch.Tensor, keep: torch.Tensor, k: int, target_width: Optional[int] = None,
+                is_causal: bool = True, z_cap: Optional[int] = None, want_mask: bool = False):
+    """Grouped top-k + nearest-neighbour interpolation to a FlatCSR in three launches, no host sync.
+
+    probs (N,H,T_dst,T_m) f32/f16/bf16 (pixel stride 1); keep int32 device tensor (T_dst,) or (N,T_dst).
+    Returns (FlatCSR, mask or None) where mask is the 0/1 fp32 (N,H,T_dst,T_m) compressed mask
+    (`partial_attention_mask_before_interp`).
+    Replaces attention.py:774-947 + ops/kernels/causal_resize_m_to_t.py:910-1007.
+    """
+    lib = _lib.load()
+    _lib.require_gpu(probs, keep)
+    assert probs.ndim == 4 and probs.stride(-1) == 1
+    N, H, T_dst, T_m = probs.shape
+    T_src = target_width if target_width is not None else T_dst
+    assert keep.dtype == torch.int32 and keep.is_contiguous()
+    assert keep.shape in ((T_dst,), (N, T_dst))
+    keep_stride_n = T_dst if keep.ndim == 2 else 0
+    dev = probs.device
+    W = (H * T_m + 31) // 32
+    bits = torch.empty((N, T_dst, W), dtype=torch.int32, device=dev)
+    row_nnz = torch.empty((N, T_dst), dtype=torch.int32, device=dev)
+    head_off = torch.empty((N, T_dst, H + 1), dtype=torch.int32, device=dev)
+    mask = torch.empty((N, H, T_dst, T_m), dtype=torch.float32, device=dev) if want_mask else None
+    st = _lib.stream_ptr()
+    _lib.check(lib.sea_topk_select(
+        _p(probs), _lib.dtype_code(probs.dtype), N, H, T_dst, T_m,
+        probs.stride(0), probs.stride(1), probs.stride(2),
+        _p(keep), keep_stride_n, T_src, int(is_causal), int(k),
+        _p(bits), _p(mask), _p(row_nnz), _p(head_off), st), "sea_topk_select")
+    crow = torch.empty((N, T_dst + 1), dtype=torch.int32, device=dev)
+    _lib.check(lib.sea_csr_row_scan(_p(row_nnz), N, T_dst, _p(crow), 4, st), "sea_csr_row_scan")
+    if z_cap is None:
+        z_cap = z_capacity(keep.cpu(), H, T_dst, T_src, T_m, int(k), is_causal)
+    col = torch.empty((N, z_cap), dtype=torch.int32, device=dev)
+    _lib.check(lib.sea_csr_emit(
+        _p(bits), _p(crow), _p(head_off), N, H, T_dst, T_m, T_src, int(is_causal), int(k),
+        _p(col), 4, col.stride(0), z_cap, None, st), "sea_csr_emit")
+    return FlatCSR(crow, col, head_off, H, T_src, bits=bits, row_nnz=row_nnz), mask
+
+
+def topk_mask(probs: torch.Tensor, keep: torch.Tensor, k: int, target_width=None, is_causal=True) -> torch.Tensor:
+    """a6 alone: 0/1 fp32 compressed mask (N,H,T_dst,T_m)."""
+    lib = _lib.load()
+    _lib.require_gpu(probs, keep)
+    N, H, T_dst, T_m = probs.shape
+    T_src = target_width if target_width is not None else T_dst
+    dev = probs.device
+    W = (H * T_m + 31) // 32
+    bits = torch.empty((N, T_dst, W), dtype=torch.int32, device=dev)
+    row_nnz = torch.empty((N, T_dst), dtype=torch.int32, device=dev)
+    head_off = torch.empty((N, T_dst, H + 1), dtype=torch.int32, device=dev)
+    mask = torch.empty((N, H, T_dst, T_m), dtype=torch.float32, device=dev)
+    keep_stride_n = T_dst if keep.ndim == 2 else 0
+    _lib.check(lib.sea_topk_select(
+        _p(probs), _lib.dtype_code(probs.dtype), N, H, T_dst, T_m,
+        probs.stride(0), probs.stride(1), probs.stride(2),
+        _p(keep), keep_stride_n, T_src, int(is_causal), int(k),
+        _p(bits), _p(mask), _p(row_nnz), _p(head_off), _lib.stream_ptr()), "sea_topk_select")
+    return mask
+
+
+def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = None,
+                     avg: Optional[torch.Tensor] = None, mix: Optional[torch.Tensor] = None,
+                     out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """Fused SDDMM + per-(row,head) softmax + row scale + SpMM (+ mix), one wave per (n,h,t).
+
+    q (N,H,T_dst,D), k/v (N,H,T_src,D), any [n,h,t] strides, feature stride 1.
+    row_scale, mix: fp32 (N,H,T_dst) contiguous (already passed through sigmoid); avg like v.
+    out: optional preallocated tensor viewed as (N,H,T_dst,D) with arbitrary strides -- pass a
+    permuted view of an (N,T_dst,H*D) buffer to get the layout of attention.py:1279-1282 directly.
+    Default output: fp32 (N,H,T_dst,D) (flat_csr_sdbmm.py:347 returns fp32).
+    """
+    lib = _lib.load()
+    _lib.require_gpu(q, k, v, csr.crow)
+    N, H, T_dst, D = q.shape
+    T_src = k.shape[2]
+    assert k.shape == (N, H, T_src, D) and v.shape == (N, H, T_src, D)
+    assert q.dtype == k.dtype == v.dtype
+    assert (csr.N, csr.T_dst, csr.H, csr.T_src) == (N, T_dst, H, T_src)
+    if out is None:
+        out = torch.empty((N, H, T_dst, D), dtype=out_dtype or torch.float32, device=q.device)
+    assert out.shape == (N, H, T_dst, D) and out.stride(-1) == 1
+    if row_scale is not None:
+        assert row_scale.dtype == torch.float32 and row_scale.shape == (N, H, T_dst) and row_scale.is_contiguous()
+    if mix is not None:
+        assert avg is not None and avg.shape == (N, H, T_dst, D) and avg.dtype == q.dtype
+        assert mix.dtype == torch.float32 and mix.shape == (N, H, T_dst) and mix.is_contiguous()
+    _lib.check(lib.sea_sparse_attention(
+        _p(q), _p(k), _p(v), _lib.dtype_code(q.dtype), N, H, T_dst, T_src, D,
+        _lib.strides3(q), _lib.strides3(k), _lib.strides3(v),
+        _p(csr.crow), _p(csr.col), csr.col.stride(0), _p(csr.head_off),
+        _p(row_scale), _p(avg), _lib.strides3(avg) if avg is not None else None, _p(mix),
+        _p(out), _lib.dtype_code(out.dtype), _lib.strides3(out), _lib.stream_ptr()), "sea_sparse_attention")
+    return out
+
+
+def sparse_attention_bytes(Z: int, N: int, H: int, T_dst: int, D: int, elem_bytes: int) -> int:
+    """Algorithmic bytes of one fused launch."""
+    return int(_lib.load().sea_sparse_attention_bytes(Z, N, H, T_dst, D, elem_bytes))
+
+
+# ------------------------------------------------------------------------------------------------
+# drop-in operators (ops/__init__.py:1-7)
+# ------------------------------------------------------------------------------------------------
+def _csr_parts(t: torch.Tensor):
+    assert t.is_sparse_csr
+    crow, col, val = t.crow_indices(), t.col_indices(), t.values()
+    assert crow.dtype == torch.int64 and col.dtype == torch.int64
+    return crow.contiguous(), col.contiguous(), val
+
+
+def resize_from_m_to_t_csr(x, masked_fill_value, k, target_width=None, training=False, need_assert=False,
+                           is_causal=True, max_col_z=None, benchmarking=False, oversampled=None):
+    """Drop-in for ops/kernels/causal_resize_m_to_t.py:910-1007 (METHOD 1, scan_col :631-762).
+
+    x: (N,H,T_dst,T_m) 0/1 mask.  Returns torch.sparse_csr_tensor (N, T_dst, H*T_src), int64 indices,
+    values = ones of x.dtype, Z = max over the batch (shorter items zero padded) -- one host sync
+    for Z exactly like the reference (`.max().item()`, :667)."""
+    assert not training
+    assert masked_fill_value == 0
+    lib = _lib.load()
+    _lib.require_gpu(x)
+    N, H, T_dst, T_m = x.shape
+    T_src = target_width if target_width is not None else T_dst
+    if x.stride(-1) != 1 or any(s % 4 for s in x.stride()[:3]):
+        x = x.contiguous()
+    dev = x.device
+    W = (H * T_m + 31) // 32
+    bits = torch.empty((N, T_dst, W), dtype=torch.int32, device=dev)
+    row_nnz = torch.empty((N, T_dst), dtype=torch.int32, device=dev)
+    head_off = torch.empty((N, T_dst, H + 1), dtype=torch.int32, device=dev)
+    st = _lib.stream_ptr()
+    _lib.check(lib.sea_mask_to_bits(
+        _p(x), _lib.dtype_code(x.dtype), N, H, T_dst, T_m, x.stride(0), x.stride(1), x.stride(2),
+        T_src, int(is_causal), int(k), _p(bits), _p(row_nnz), _p(head_off), st), "sea_mask_to_bits")
+    crow = torch.empty((N, T_dst + 1), dtype=torch.int64, device=dev)
+    _lib.check(lib.sea_csr_row_scan(_p(row_nnz), N, T_dst, _p(crow), 8, st), "sea_csr_row_scan")
+    Z = int(crow[:, -1].max().item())
+    col = torch.zeros((N, Z), dtype=torch.int64, device=dev)
+    values = torch.ones((N, Z), dtype=x.dtype, device=dev)
+    if Z > 0:
+        _lib.check(lib.sea_csr_emit(
+            _p(bits), _p(crow), _p(head_off), N, H, T_dst, T_m, T_src, int(is_causal), int(k),
+            _p(col), 8, col.stride(0), Z, None, st), "sea_csr_emit")
+    return torch.sparse_csr_tensor(crow, col, values, size=(N, T_dst, H * T_src))
+
+
+def flat_csr_masked_bmm(a: torch.Tensor, b: torch.Tensor, mask: torch.Tensor, max_z_per_row: int = None):
+    """Drop-in for flat_csr_masked_bmm.py:137-195 (SDDMM).  max_z_per_row is accepted and unused:
+    the HIP kernel walks each row's own length, so the reference's `.item()` sync (:162-164) is gone."""
+    assert mask.is_sparse_csr
+    assert a.ndim == b.ndim
+    assert a.ndim == 4
+    N, H, T_DST, HID = a.shape
+    assert b.shape[:2] == (N, H)
+    _, _, T_SRC, HID = b.shape
+    assert mask.shape == (N, T_DST, H * T_SRC)
+    lib = _lib.load()
+    _lib.require_gpu(a, b, mask)
+    crow, col, val = _csr_parts(mask)
+    out_values = val.to(torch.float32).clone()
+    assert crow.shape[0] == N
+    if a.stride(-1) != 1:
+        a = a.contiguous()
+    if b.stride(-1) != 1:
+        b = b.contiguous()
+    if a.dtype != b.dtype:
+        b = b.to(a.dtype)
+    if col.shape[1] > 0:
+        _lib.check(lib.sea_csr_sddmm(
+            _p(a), _p(b), _lib.dtype_code(a.dtype), N, H, T_DST, T_SRC, HID,
+            _lib.strides3(a), _lib.strides3(b), _p(crow), _p(col), 8, col.stride(0),
+            _p(out_values), _lib.stream_ptr()), "sea_csr_sddmm")
+    return torch.sparse_csr_tensor(crow, col, out_values, size=mask.shape)
+
+
+def flat_csr_softmax(scores: torch.Tensor, H: int, T_SRC: int, max_z_per_row: int = None):
+    """Drop-in for flat_csr_softmax.py:127-176."""
+    assert scores.is_sparse_csr
+    lib = _lib.load()
+    _lib.require_gpu(scores)
+    crow, col, val = _csr_parts(scores)
+    in_values = val.to(torch.float32).contiguous()
+    out_values = in_values.clone()
+    N, R_1 = crow.shape
+    if col.shape[1] > 0:
+        _lib.check(lib.sea_csr_softmax(
+            _p(in_values), _p(out_values), N, H, R_1 - 1, T_SRC, _p(crow), _p(col), 8, col.stride(0),
+            _lib.stream_ptr()), "sea_csr_softmax")
+    return torch.sparse_csr_tensor(crow, col, out_values, size=scores.shape)
+
+
+def flat_csr_elmul(probs: torch.Tensor, dense: torch.Tensor, max_z_per_row: int = None):
+    """Drop-in for flat_csr_elmul.py:110-162.  `dense` may be a stride-0 expanded view
+    (the module passes one, attention.py:1170-1171)."""
+    assert probs.is_sparse_csr
+    N, T_DST, H_T = probs.shape
+    _N, H, _T_DST, T = dense.shape
+    assert T_DST == _T_DST
+    assert N == _N
+    assert H_T == H * T
+    lib = _lib.load()
+    _lib.require_gpu(probs, dense)
+    crow, col, val = _csr_parts(probs)
+    in_values = val.to(torch.float32).contiguous()
+    out_values = in_values.clone()
+    if col.shape[1] > 0:
+        _lib.check(lib.sea_csr_elmul(
+            _p(in_values), _p(out_values), _p(dense), _lib.dtype_code(dense.dtype), _lib.strides4(dense),
+            N, H, T_DST, T, _p(crow), _p(col), 8, col.stride(0), _lib.stream_ptr()), "sea_csr_elmul")
+    return torch.sparse_csr_tensor(crow, col, out_values, size=probs.shape)
+
+
+def flat_csr_sdbmm(scores: torch.Tensor, value_layer: torch.Tensor, T_M: int, max_z_per_row: int = None,
+                   benchmarking: bool = False):
+    """Drop-in for flat_csr_sdbmm.py:323-439 (SpMM).  Output fp32 (N,H,T_dst,D) like the reference
+    (:347).  Rows must be grouped by ascending head (the reference relies on the same, :227-263);
+    unlike the reference no entry is dropped when a head holds more than MAX_ROW_T entries (:382-388)."""
+    assert scores.is_sparse_csr
+    lib = _lib.load()
+    _lib.require_gpu(scores, value_layer)
+    crow, col, val = _csr_parts(scores)
+    values = val.to(torch.float32).contiguous()
+    other = value_layer
+    N, R_1 = crow.shape
+    _N, H, T_SRC, HID = other.shape
+    assert N == _N
+    _N, T_DST, HT_SRC = scores.shape
+    assert N == _N
+    assert HT_SRC == (H * T_SRC)
+    if other.stride(-1) != 1:
+        other = other.contiguous()
+    output = torch.zeros((N, H, T_DST, HID), device=values.device)
+    if col.shape[1] == 0:
+        return output
+    st = _lib.stream_ptr()
+    head_off = torch.empty((N, T_DST, H + 1), dtype=torch.int32, device=values.device)
+    _lib.check(lib.sea_csr_head_offsets(
+        _p(crow), _p(col), 8, N, H, T_DST, T_SRC, col.stride(0), _p(head_off), st), "sea_csr_head_offsets")
+    _lib.check(lib.sea_csr_spmm(
+        _p(values), _p(other), _lib.dtype_code(other.dtype), N, H, T_DST, T_SRC, HID, _lib.strides3(other),
+        _p(crow), _p(col), 8, col.stride(0), _p(head_off), _p(output), st), "sea_csr_spmm")
+    return output
+
+
+def flat_csr_to_dense(csr, T_SRC, H):
+    """Drop-in for flat_csr_to_dense.py:3-36 (debug/parity probe): (N,H,T_dst,T_src) of the valid
+    entries.  Accepts a torch CSR tensor or a FlatCSR (then values are ones)."""
+    if isinstance(csr, FlatCSR):
+        csr = csr.to_sparse_csr()
+    assert csr.is_sparse_csr
+    N, T_DST, H_T = csr.shape
+    crow, col, values = csr.crow_indices(), csr.col_indices(), csr.values()
+    Z = col.shape[-1]
+    out = torch.zeros((N, H, T_DST, T_SRC), dtype=values.dtype, device=values.device)
+    if Z == 0:
+        return out
+    pos = torch.arange(Z, device=col.device).view(1, Z)
+    valid = pos < crow[:, -1:]
+    rows = (torch.searchsorted(crow.contiguous(), pos.expand(N, Z).contiguous(), right=True) - 1).clamp_(0, T_DST - 1)
+    n_idx = torch.arange(N, device=col.device).view(N, 1).expand(N, Z)
+    h_idx = torch.div(col, T_SRC, rounding_mode="floor")
+    k_idx = col - h_idx * T_SRC
+    out.index_put_((n_idx[valid], h_idx[valid], rows[valid], k_idx[valid]), values[valid], accumulate=True)
+    return out

@@ -1,0 +1,60 @@
+"""N>1 path on CPU: batch sharding + all-gather of context shards, world_size 2 over gloo.
+The compute inside each rank is the CPU oracle (tests may use it as a stand-in checker)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, n_items, ret):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from sea_attention_amd import distributed as D
+    from oracle import sea_oracle as O
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(7)                                  # same full batch on every rank
+    N, H, T, T_M, k, d = n_items, 2, 32, 8, 4, 8
+    probs = torch.softmax(torch.randn(N, H, T, T_M), -1)
+    q, kk, v = torch.randn(N, H, T, d), torch.randn(N, H, T, d), torch.randn(N, H, T, d)
+
+    def layer(p_, q_, k_, v_):
+        keep = O.keep_counts_module(H, T, T_M, k)
+        crow, col = O.resize_m_to_t_csr(O.grouped_topk_mask(p_, keep), k, T, True)
+        o = O.sparse_attention(q_, k_, v_, crow, col)
+        return o.permute(0, 2, 1, 3).reshape(o.shape[0], T, H * d)
+
+    full = layer(probs, q, kk, v)
+    local = layer(*[D.shard_batch(t) for t in (probs, q, kk, v)])
+    lo, hi = D.shard_bounds(N, world, rank)
+    assert local.shape[0] == hi - lo
+    gathered = D.all_gather_context(local, N)
+    ok = torch.allclose(gathered, full, atol=1e-6)
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(3)
+
+
+@pytest.mark.parametrize("n_items", [4, 5])               # equal shards and ragged shards
+def test_shard_and_all_gather_world2(n_items):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, n_items, None), nprocs=2, join=True)
+
+
+def test_shard_bounds_cover_everything():
+    from sea_attention_amd.distributed import shard_bounds
+    for n in (1, 7, 8, 9, 64):
+        for w in (1, 2, 4, 8):
+            spans = [shard_bounds(n, w, r) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
