@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- SEA sparse-attention layer on MI355X: tokens/s + achieved HBM GB/s of the sparse kernel.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched under
+torch.distributed.run with one rank per GPU (RCCL).  One JSON line on rank 0.
+
+A "step" = one forward of ONE SEA attention layer in sparse mode (`benchmarking=True`, steps A..L of
+SURVEY.md section 3B: value augmentation, Performer, predictor MLP+CNN, softmax, HIP grouped top-k +
+interpolation -> flat CSR, HIP fused sparse attention + mix) on a synthetic batch, followed -- when N>1 --
+by the RCCL all-gather of the context shards.  Workload = BASELINE.json configs[2]:
+OPT-1.3B SEA, H=32 d=64 T=4096, k=64, predictor length 256, nb-factor 8, bf16, random-init weights (seed 42).
+Per-GPU batch is fixed (weak scaling).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    "opt-1.3b": dict(H=32, d=64, T=4096, T_M=256, k=64, nbf=8),
+    "opt-125m": dict(H=12, d=64, T=2048, T_M=256, k=64, nbf=8),
+    "opt-2.7b": dict(H=32, d=80, T=8192, T_M=256, k=64, nbf=8),
+    "llama-13b": dict(H=40, d=128, T=4096, T_M=256, k=64, nbf=8),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+class _Cfg:
+    def __init__(self, hidden, heads, max_pos):
+        self.hidden_size, self.num_attention_heads, self.max_position_embeddings = hidden, heads, max_pos
+
+
+def _usable_cores():
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:                                             # cgroup v2 quota ("max" or "<quota> <period>")
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return n
+
+
+def cpu_baseline(w, seconds_hint=20):
+    """Oracle (CPU port of the reference's dense PyTorch branch) on a bounded sample: ONE sequence of the
+    workload shape through the kernel-level path (probs -> top-k -> interpolate -> dense masked attention),
+    fp32, all host cores."""
+    from oracle import sea_oracle as O
+    cores = _usable_cores()
+    torch.set_num_threads(cores)
+    H, d, T, T_M, k = w["H"], w["d"], w["T"], w["T_M"], w["k"]
+    g = torch.Generator().manual_seed(42)
+    probs = torch.softmax(torch.randn((1, H, T, T_M), generator=g), -1)
+    q = torch.randn((1, H, T, d), generator=g) * d ** -0.5
+    kk = torch.randn((1, H, T, d), generator=g)
+    v = torch.randn((1, H, T, d), generator=g)
+    rs = torch.sigmoid(torch.randn((1, H, T), generator=g))
+    hc = max(1, min(H, (1 << 29) // (T * T)))            # keep the T x T temporaries around 2 GB
+    t0 = time.perf_counter()
+    out, _ = O.dense_path(probs, q, kk, v, rs, k, head_chunk=hc)
+    out = O.mix(out, v, torch.zeros((1, H, T)))
+    dt = time.perf_counter() - t0
+    return {"value": T / dt, "unit": "tokens/s", "cores": cores, "kind": "port",
+            "sample": f"1 sequence x {T} tokens, kernel-level path H..K (probs given), fp32 dense branch, "
+                      f"head_chunk={hc}, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="opt-1.3b", choices=list(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=8, help="sequences per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-iters", type=int, default=20, help="extra kernel-only iterations (H..K) after the timed steps")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs the MI355X"
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    import sea_attention_amd as S
+    from sea_attention_amd import _lib, distributed as D
+    from sea_attention_amd.perlin_attention import PerlinAttentionConfig, PerlinSelfAttention, ops
+    _lib.load(build_if_missing=True)
+
+    w = WORKLOADS[args.workload]
+    H, d, T, T_M, k = w["H"], w["d"], w["T"], w["T_M"], w["k"]
+    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
+    NB = args.batch
+
+    S.seed(42)
+    pc = PerlinAttentionConfig(k=k, attention_predictor_length=T_M, performer_nb_factor=w["nbf"], causal=True,
+                               k_flatten=True, k_flatten_dim='causal_batch', context_output_method='mix')
+    layer = PerlinSelfAttention(_Cfg(H * d, H, T), pc).to(dev).to(dtype).eval()
+    for m in layer.modules():
+        if hasattr(m, 'benchmarking'):
+            m.benchmarking = True
+    layer.attention.context_layer_dtype = dtype          # the consumer (out_proj) runs in `dtype`
+    torch.manual_seed(42 + rank)
+    q = (torch.randn((NB, H, T, d), device=dev) * d ** -0.5).to(dtype)
+    kk = torch.randn((NB, H, T, d), device=dev).to(dtype)
+    v = torch.randn((NB, H, T, d), device=dev).to(dtype)
+    fp_min = torch.finfo(torch.float16 if dtype != torch.float32 else torch.float32).min / 2
+    mask = ((torch.arange(T, device=dev).view(1, T) > torch.arange(T, device=dev).view(T, 1)) * fp_min)
+    mask = mask.view(1, 1, T, T).to(dtype).expand(NB, 1, T, T).contiguous()
+
+    bench = S.get_bench()
+
+    def step():
+        with torch.no_grad():
+            out = layer(None, None, None, query_layer=q, key_layer=kk, value_layer=v, attention_mask=mask)
+            ctx = out.context_layer
+            if world > 1:
+                ctx = D.all_gather_context(ctx, NB * world)
+        return out, ctx
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    # per-kernel HIP events through the module's named regions (events only, no host sync inside the steps)
+    bench.disabled, bench.synchronize = False, True
+    bench.reset_measures()
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, ctx = step()
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    regions = bench.todict()                              # seconds per call, from HIP events on the launch stream
+    bench.disabled, bench.synchronize = True, False
+    bench.reset_measures()
+
+    t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    tokens_per_s = NB * world * T / (elapsed / args.steps)
+
+    # ---- roofline of the dominant HIP kernel (fused sparse attention) ---------------------------------
+    csr = out.partial_attention_mask
+    Z = int(csr.crow[:, -1].sum().item())
+    esz = torch.tensor([], dtype=dtype).element_size()
+    alg_bytes = ops.sparse_attention_bytes(Z, NB, H, T, d, esz)
+    t_attn = regions.get('attention.sparse.fused')
+    roof = None
+    if t_attn:
+        achieved = alg_bytes / t_attn / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("sea_sparse_attention_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roof = {"bound": "hbm", "kernel": "sparse_attn_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(t_attn * 1e3, 4), "nnz": Z}
+
+    # ---- kernel-level path only (H..K on HIP, probs given) -- what the CPU baseline below also runs -------
+    kernel_path = None
+    if args.kernel_iters > 0:
+        probs = torch.softmax(torch.randn((NB, H, T, T_M), device=dev), -1).to(dtype)
+        keep = ops.keep_table_causal(H, T, T_M, k, device=dev)
+        z_cap = ops.z_capacity(keep.cpu(), H, T, T, T_M, k, True)
+        rs = torch.sigmoid(torch.randn((NB, H, T), device=dev))
+        mx = torch.sigmoid(torch.randn((NB, H, T), device=dev))
+        avg = (v.float().cumsum(-2) / torch.arange(1, T + 1, device=dev).view(1, 1, -1, 1)).to(dtype)
+        ctx2 = torch.empty((NB, T, H * d), dtype=dtype, device=dev)
+
+        def kstep():
+            c, _ = ops.topk_to_csr(probs, keep, k, target_width=T, z_cap=z_cap)
+            ops.sparse_attention(q, kk, v, c, row_scale=rs, avg=avg, mix=mx, out=ctx2.view(NB, T, H, d).permute(0, 2, 1, 3))
+            return c
+        for _ in range(3):
+            kstep()
+        torch.cuda.synchronize()
+        e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
+        tk = ta = 0.0
+        for _ in range(args.kernel_iters):
+            e0.record(); c, _ = ops.topk_to_csr(probs, keep, k, target_width=T, z_cap=z_cap); e1.record()
+            ops.sparse_attention(q, kk, v, c, row_scale=rs, avg=avg, mix=mx, out=ctx2.view(NB, T, H, d).permute(0, 2, 1, 3))
+            e2.record(); torch.cuda.synchronize()
+            tk += e0.elapsed_time(e1); ta += e1.elapsed_time(e2)
+        tk /= args.kernel_iters; ta /= args.kernel_iters
+        Zk = int(c.crow[:, -1].sum().item())
+        kb = ops.sparse_attention_bytes(Zk, NB, H, T, d, esz)
+        kernel_path = {"value": round(NB * T / ((tk + ta) / 1e3), 1), "unit": "tokens/s",
+                       "topk_interp_csr_ms": round(tk, 4), "sparse_attention_ms": round(ta, 4),
+                       "sparse_attention_GBs": round(kb / (ta / 1e3) / 1e9, 1), "nnz": Zk,
+                       "note": "HIP kernels only (steps H..K), softmax(randn) probability map, per GPU"}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(w)
+
+    if rank == 0:
+        line = {
+            "metric": "tokens/sec + achieved HBM GB/s, OPT-1.3B SEA T=4096 k=64, 1/2/4/8 MI355X",
+            "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.workload} SEA attention layer forward (sparse mode, steps A-L), "
+                                   f"H={H} d={d} T={T} k={k} predictor_length={T_M} nbf={w['nbf']}, "
+                                   f"batch {NB} sequences/GPU, random-init weights seed 42"
+                                   + (", + RCCL all-gather of context shards" if world > 1 else ""),
+                       "global_batch": NB * world, "seq_len": T, "parallelism": f"dp{world} (batch shards)"},
+            "roofline": roof, "cpu_baseline": cpu, "kernel_path": kernel_path,
+            "regions_ms": {k_: round(v_ * 1e3, 4) for k_, v_ in sorted(regions.items())},
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

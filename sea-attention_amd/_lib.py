@@ -48,7 +48,7 @@ def load(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
-    path = _build.LIB_PATH
+    path = os.environ.get("SEA_HIP_LIB") or _build.LIB_PATH       # override: A/B builds of the same ABI
     if not os.path.exists(path):
         if not build_if_missing:
             raise RuntimeError(f"{path} not built; run `python -c 'import __graft_entry__ as g; g.build()'`")

@@ -117,6 +117,16 @@ class CausalConv2d(nn.Module):
         if w.dtype != x.dtype:
             w = w.to(x.dtype)
         b = self.bias if self.bias.dtype == x.dtype else self.bias.to(x.dtype)
+        if k == 1 and self.stride in (1, (1, 1)):
+            # a 1x1 convolution is a channel GEMM: (O x C) @ (C x T*W) per batch item.  Besides being the
+            # cheaper form on rocBLAS it keeps pixels independent bit for bit -- the MIOpen/CK 1x1 kernel was
+            # observed to couple vertically adjacent pixels at rounding level, which is enough to flip a
+            # top-k decision in the row before a perturbed token (causality canary).
+            if pw > 0:
+                x = F.pad(x, (pw, pw))
+            N, C, T, W = x.shape
+            y = torch.matmul(w.view(self.out_channels, C), x.reshape(N, C, T * W))
+            return (y + b.view(1, -1, 1)).view(N, self.out_channels, T, W)
         if ph > 0:
             x = F.pad(x, (0, 0, ph, 0))                   # past rows only
         return F.conv2d(x, w, b, self.stride, (0, pw), self.dilation)

@@ -1,0 +1,136 @@
+"""-m gpu: module-level parity, following the reference's own protocol
+(src/main/tests/test_perlin_opt_consist.py:103-232): run the attention layer once in dense mode
+(`benchmarking=False`, plain torch) and once in sparse mode (`benchmarking=True`, HIP kernels), capture
+every named temp buffer, compare.  The reference's bar is sum-squared-error <= 1e-5 per buffer with the
+mask buffers exactly equal; plus the causality canary of test_perlin_opt_causality.py:246-276."""
+import math
+
+import pytest
+import torch
+
+import sea_attention_amd as S
+from sea_attention_amd.perlin_attention import PerlinAttentionConfig, PerlinSelfAttention, ops
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class Cfg:
+    def __init__(self, hidden, heads, max_pos):
+        self.hidden_size, self.num_attention_heads, self.max_position_embeddings = hidden, heads, max_pos
+
+
+def causal_mask(N, T, dtype):
+    fp_min = torch.finfo(torch.float32 if dtype == torch.float32 else torch.float16).min / 2
+    m = ((torch.arange(T, device=DEV).view(1, T) > torch.arange(T, device=DEV).view(T, 1)) * fp_min).view(1, 1, T, T)
+    return m.expand(N, 1, T, T).contiguous().to(dtype)
+
+
+def make_layer(H, d, T_M, k, max_pos, dtype=torch.float32):
+    S.seed(42)
+    pc = PerlinAttentionConfig(k=k, attention_predictor_length=T_M, performer_nb_factor=8, causal=True,
+                               k_flatten=True, k_flatten_dim='causal_batch', context_output_method='mix')
+    return PerlinSelfAttention(Cfg(H * d, H, max_pos), pc).to(DEV).to(dtype).eval()
+
+
+def run(layer, q, k, v, mask, benchmarking, capture=True):
+    for m in layer.modules():
+        if hasattr(m, 'benchmarking'):
+            m.benchmarking = benchmarking
+    bench = S.get_bench()
+    bench.reset_temp_buffers()
+    bench.activate_temp_buffers = capture
+    try:
+        with torch.no_grad():
+            out = layer(None, None, None, query_layer=q, key_layer=k, value_layer=v, attention_mask=mask)
+        bufs = {n: b[-1] for n, b in bench.buffers.items()}
+    finally:
+        bench.activate_temp_buffers = False
+        bench.reset_temp_buffers()
+    return out, bufs
+
+
+@pytest.mark.parametrize("N,H,T,d,T_M,k", [(1, 12, 2048, 64, 256, 64), (2, 4, 512, 32, 64, 16)])
+def test_dense_vs_sparse_consistency(N, H, T, d, T_M, k):
+    layer = make_layer(H, d, T_M, k, T)
+    S.seed(42)
+    q = torch.randn((N, H, T, d), device=DEV)
+    qs = q * d ** -0.5
+    mask = causal_mask(N, T, torch.float32)
+    out_d, bd = run(layer, qs, q.clone(), q.clone(), mask, False)
+    out_s, bs = run(layer, qs, q.clone(), q.clone(), mask, True)
+
+    def sse(a, b):
+        return (a.float() - b.float()).square().sum().item()
+
+    same = ['q', 'k', 'v', 'v_for_atten', 'performer_context_layer', 'performer_value',
+            'estimated_attention_score_dec_row', 't_attention_predictor', 'estimated_attention_score',
+            'estimated_attention_probs', 'masked_estimated_attention_probs', 'estimated_scales', 'average_scale',
+            'average_context_layer', 'q_for_score', 'k_for_score']
+    for name in same:
+        assert sse(bd[name], bs[name]) <= 1e-5, name
+    # masks: exactly equal (dense mode stores 0 / FP_MIN, sparse mode 1 / 0)
+    alive_d = bd['partial_attention_mask_before_interp'] > -1
+    alive_s = bs['partial_attention_mask_before_interp'] > 0
+    assert torch.equal(alive_d, alive_s)
+    assert torch.equal(bd['partial_attention_mask'] > -1, bs['partial_attention_mask'] > 0)
+    # the dense branch leaves K_t unclamped (rank < K_t is all-true either way); the kernel table clamps to H*T_M
+    assert torch.equal(bd['per_item_top_k'].view(-1).float().clamp_max(H * T_M), bs['per_item_top_k'].view(-1).float())
+    for name in ['partial_context_layer_1', 'partial_context_layer_2', 'partial_context_layer_sparse', 'partial_context_layer']:
+        e = sse(bd[name], bs[name])
+        assert e <= 1e-5 * max(1.0, N * T / 2048), (name, e)
+    assert sse(out_d.context_layer, out_s.context_layer) <= 1e-5 * max(1.0, N * T / 2048)
+    assert out_s.context_layer.dtype == torch.float32 and tuple(out_s.context_layer.shape) == (N, T, H * d)
+    # fused production path (no probes) == probed path, bit for bit on the mask and within fp32 noise on the output
+    out_f, _ = run(layer, qs, q.clone(), q.clone(), mask, True, capture=False)
+    assert (out_f.context_layer - out_s.context_layer).abs().max().item() < 1e-5
+    assert isinstance(out_f.partial_attention_mask, ops.FlatCSR) and out_f.partial_attention_mask.is_sparse_csr
+    t = out_f.partial_attention_mask.to_sparse_csr()
+    assert t.is_sparse_csr and tuple(t.shape) == (N, T, H * T)
+    assert torch.equal(ops.flat_csr_to_dense(t, T, H) > 0, bd['partial_attention_mask'] > -1)
+
+
+def test_sparse_mode_bf16_close_to_fp32_dense():
+    """cfg-3 dtype: bf16 layer in sparse mode stays within bf16 noise of the same layer's dense mode."""
+    N, H, T, d, T_M, k = 1, 8, 1024, 64, 256, 64
+    layer = make_layer(H, d, T_M, k, T, torch.bfloat16)
+    S.seed(1)
+    q = torch.randn((N, H, T, d), device=DEV).to(torch.bfloat16)
+    mask = causal_mask(N, T, torch.bfloat16)
+    out_d, bd = run(layer, q * d ** -0.5, q.clone(), q.clone(), mask, False)
+    out_s, bs = run(layer, q * d ** -0.5, q.clone(), q.clone(), mask, True)
+    # identical estimator -> identical probability map -> identical mask
+    assert torch.equal(bd['estimated_attention_probs'], bs['estimated_attention_probs'])
+    assert torch.equal(bd['partial_attention_mask_before_interp'] > -1, bs['partial_attention_mask_before_interp'] > 0)
+    ref = out_d.context_layer.float()
+    rel = ((out_s.context_layer.float() - ref).norm() / ref.norm()).item()
+    assert rel < 2e-2, rel          # dense mode rounds scores/probs to bf16; the HIP path keeps them in fp32
+
+
+@pytest.mark.parametrize("H,d", [(1, 32), (7, 64), (12, 64), (16, 32)])
+def test_sparse_mode_is_causal(H, d):
+    N, T, T_M, k = 1, 512, 64, 16
+    layer = make_layer(H, d, T_M, k, T)
+    S.seed(3)
+    q = torch.randn((N, H, T, d), device=DEV)
+    q2 = q.clone()
+    q2[:, :, T // 2] = 3e5
+    mask = causal_mask(N, T, torch.float32)
+    a, _ = run(layer, q * d ** -0.5, q.clone(), q.clone(), mask, True, capture=False)
+    b, _ = run(layer, q2 * d ** -0.5, q2.clone(), q2.clone(), mask, True, capture=False)
+    diff = (a.context_layer[:, :T // 2] - b.context_layer[:, :T // 2]).abs().sum().item()
+    assert math.log10(diff + 1e-20) < -3, diff
+
+
+def test_padded_batch_sparse_mode():
+    """Left rows of a batch item masked out as padding (dst mask): dense and sparse mode agree."""
+    N, H, T, d, T_M, k = 2, 4, 256, 32, 64, 16
+    layer = make_layer(H, d, T_M, k, T)
+    S.seed(5)
+    q = torch.randn((N, H, T, d), device=DEV)
+    mask = causal_mask(N, T, torch.float32).clone()
+    fp_min = torch.finfo(torch.float32).min / 2
+    mask[1, :, :, :16] = fp_min            # item 1: 16 left-pad keys -> its dst mask marks every row dead
+    out_d, bd = run(layer, q * d ** -0.5, q.clone(), q.clone(), mask, False)
+    out_s, bs = run(layer, q * d ** -0.5, q.clone(), q.clone(), mask, True)
+    assert (out_d.context_layer - out_s.context_layer).abs().max().item() < 1e-4

@@ -1,0 +1,204 @@
+"""-m gpu: HIP path vs the CPU oracle on seeded inputs (sizes the oracle finishes in seconds), and
+size-independent properties at the full BASELINE configurations.
+
+Tolerances (north_star): top-k / CSR indices bit-exact; attention output within 1e-3 relative
+(fp32 inputs: 1e-4 abs; bf16/fp16 inputs are compared against the oracle run on the SAME rounded
+inputs, so only accumulation order differs: 2e-3 abs on O(1) outputs)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import sea_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sea_attention_amd.perlin_attention import ops
+    return ops
+
+
+def _inputs(N, H, T, T_M, d, seed=42, dtype=torch.float32):
+    g = torch.Generator().manual_seed(seed)
+    probs = torch.softmax(torch.randn((N, H, T, T_M), generator=g), -1)
+    q = (torch.randn((N, H, T, d), generator=g) * d ** -0.5).to(dtype)
+    k = torch.randn((N, H, T, d), generator=g).to(dtype)
+    v = torch.randn((N, H, T, d), generator=g).to(dtype)
+    rs = torch.sigmoid(torch.randn((N, H, T), generator=g))
+    return probs, q, k, v, rs
+
+
+@pytest.mark.parametrize("N,H,T,T_M,k,d", [(1, 12, 512, 64, 16, 64), (2, 12, 1024, 256, 64, 64), (1, 5, 300, 96, 8, 80),
+                                           (1, 32, 1024, 256, 64, 64), (1, 40, 768, 256, 64, 128)])
+def test_topk_csr_vs_oracle(ops, N, H, T, T_M, k, d):
+    probs, *_ = _inputs(N, H, T, T_M, 8)
+    keep = O.keep_counts_module(H, T, T_M, k)
+    mask_ref = O.grouped_topk_mask(probs, keep)
+    crow_ref, col_ref = O.resize_m_to_t_csr(mask_ref, k, T, True)
+    keep_dev = ops.keep_table_causal(H, T, T_M, k, device=DEV)
+    csr, mask = ops.topk_to_csr(probs.to(DEV), keep_dev, k, target_width=T, want_mask=True)
+    assert torch.equal(mask.cpu(), mask_ref)
+    assert torch.equal(csr.crow.cpu().long(), crow_ref)
+    z = crow_ref[:, -1]
+    for n in range(N):
+        assert torch.equal(csr.col[n, :z[n]].cpu().long(), col_ref[n, :z[n]])
+    assert csr.col.shape[1] >= int(z.max())                    # analytic capacity really is an upper bound
+    assert torch.equal(csr.head_off.cpu().long(), O.head_offsets(crow_ref, col_ref, H, T))
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+def test_topk_low_precision_probs_and_ties(ops, dtype):
+    """bf16/fp16 probability maps carry many exact ties: the tie rule (lower flat index first) must hold."""
+    N, H, T, T_M, k = 1, 8, 256, 64, 8
+    probs, *_ = _inputs(N, H, T, T_M, 8, seed=3)
+    probs = probs.to(dtype)
+    keep = O.keep_counts_module(H, T, T_M, k)
+    mask_ref = O.grouped_topk_mask(probs.float(), keep)
+    mask = ops.topk_mask(probs.to(DEV), ops.keep_table_causal(H, T, T_M, k, device=DEV), k)
+    assert torch.equal(mask.cpu(), mask_ref)
+    # degenerate rows: all equal, and a two-valued row
+    flat = torch.full((1, 2, 16, 32), 0.25)
+    flat[0, :, 8:, ::2] = 0.5
+    keep2 = torch.tensor([5] * 8 + [40] * 8, dtype=torch.int32)
+    ref2 = O.grouped_topk_mask(flat, keep2)
+    got2 = ops.topk_mask(flat.to(DEV), keep2.to(DEV), 4)
+    assert torch.equal(got2.cpu(), ref2)
+
+
+@pytest.mark.parametrize("T,T_M", [(4096, 256), (1000, 96), (130, 256), (8192, 256)])
+def test_interpolation_bounds_every_pixel(ops, T, T_M):
+    """An all-ones mask exercises every (t, b) boundary: the kernel's fp32 bound arithmetic must equal the
+    reference's round_half_away(b * fp32((t+1)/T_m)) table everywhere (T=8192: widths up to 32)."""
+    H, k = 1, 64
+    mask = torch.ones((1, H, T, T_M))
+    crow_ref, col_ref = O.resize_m_to_t_csr(mask, k, T, True)
+    csr = ops.resize_from_m_to_t_csr(mask.to(DEV), 0, k, target_width=T)
+    assert torch.equal(csr.crow_indices().cpu(), crow_ref)
+    assert torch.equal(csr.col_indices().cpu(), col_ref)
+
+
+@pytest.mark.parametrize("dtype,atol", [(torch.float32, 1e-4), (torch.bfloat16, 2e-3), (torch.float16, 2e-3)])
+@pytest.mark.parametrize("N,H,T,T_M,k,d", [(2, 12, 1024, 256, 64, 64), (1, 4, 512, 64, 16, 128), (1, 3, 256, 32, 8, 80),
+                                           (1, 2, 256, 32, 8, 32)])
+def test_sparse_attention_vs_oracle(ops, dtype, atol, N, H, T, T_M, k, d):
+    probs, q, kk, v, rs = _inputs(N, H, T, T_M, d, dtype=dtype)
+    keep = O.keep_counts_module(H, T, T_M, k)
+    crow, col = O.resize_m_to_t_csr(O.grouped_topk_mask(probs, keep), k, T, True)
+    ref = O.sparse_attention(q.float(), kk.float(), v.float(), crow, col, rs)
+    csr, _ = ops.topk_to_csr(probs.to(DEV), ops.keep_table_causal(H, T, T_M, k, device=DEV), k, target_width=T)
+    out = ops.sparse_attention(q.to(DEV), kk.to(DEV), v.to(DEV), csr, row_scale=rs.to(DEV))
+    assert out.dtype == torch.float32
+    err = (out.cpu() - ref).abs().max().item()
+    assert err < atol, err
+    rel = ((out.cpu() - ref).norm() / ref.norm()).item()
+    assert rel < 1e-3, rel
+    # strided q/k/v views (as cut from a fused qkv projection) give the same result
+    big = torch.randn((N, T, 3, H, d), dtype=dtype)
+    big[:, :, 0] = q.permute(0, 2, 1, 3); big[:, :, 1] = kk.permute(0, 2, 1, 3); big[:, :, 2] = v.permute(0, 2, 1, 3)
+    bd = big.to(DEV)
+    qv, kv, vv = (bd[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    out2 = ops.sparse_attention(qv, kv, vv, csr, row_scale=rs.to(DEV))
+    assert torch.equal(out2, out)
+
+
+def test_unfused_chain_equals_fused(ops):
+    N, H, T, T_M, k, d = 1, 12, 512, 64, 16, 64
+    probs, q, kk, v, rs = _inputs(N, H, T, T_M, d)
+    keep_dev = ops.keep_table_causal(H, T, T_M, k, device=DEV)
+    csr, mask = ops.topk_to_csr(probs.to(DEV), keep_dev, k, target_width=T, want_mask=True)
+    fused = ops.sparse_attention(q.to(DEV), kk.to(DEV), v.to(DEV), csr, row_scale=rs.to(DEV))
+    m = ops.resize_from_m_to_t_csr(mask, 0, k, target_width=T)
+    s = ops.flat_csr_masked_bmm(q.to(DEV), kk.to(DEV), m)
+    p = ops.flat_csr_softmax(s, H, T)
+    p = ops.flat_csr_elmul(p, rs.to(DEV).view(N, H, T, 1).expand(N, H, T, T))
+    o = ops.flat_csr_sdbmm(p, v.to(DEV), T_M)
+    assert (o - fused).abs().max().item() < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# full BASELINE sizes: size-independent properties
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("N,H,T,T_M,k,d,dtype", [
+    (1, 32, 4096, 256, 64, 64, torch.bfloat16),      # cfg 3  OPT-1.3B
+    (2, 12, 2048, 256, 64, 64, torch.float32),       # cfg 2  synthetic (2 of the 8 batch items)
+    (1, 32, 8192, 256, 64, 80, torch.bfloat16),      # cfg 4  OPT-2.7B shape, one item
+    (1, 40, 4096, 256, 64, 128, torch.bfloat16),     # cfg 5  LLaMA-13B shape
+])
+def test_full_size_properties(ops, N, H, T, T_M, k, d, dtype):
+    g = torch.Generator(device=DEV).manual_seed(42)
+    probs = torch.softmax(torch.randn((N, H, T, T_M), generator=g, device=DEV), -1)
+    keep = ops.keep_table_causal(H, T, T_M, k, device=DEV)
+    csr, mask = ops.topk_to_csr(probs, keep, k, target_width=T, want_mask=True)
+    # (1) exactly K_t pixels survive in every row, and they are the K_t largest: min kept >= max dropped
+    kept = mask.transpose(1, 2).reshape(N, T, H * T_M)
+    assert torch.equal(kept.sum(-1).to(torch.int32), keep.view(1, T).expand(N, T))
+    flat = probs.transpose(1, 2).reshape(N, T, H * T_M)
+    lo_kept = torch.where(kept > 0, flat, torch.full_like(flat, 2.0)).min(-1).values
+    hi_drop = torch.where(kept > 0, torch.full_like(flat, -1.0), flat).max(-1).values
+    assert torch.all(lo_kept >= hi_drop)
+    # (2) CSR structure: crow monotone, row nnz == head_off totals, heads ascending, columns causal & unique
+    crow = csr.crow.long()
+    assert torch.all(crow[:, 1:] >= crow[:, :-1]) and torch.all(crow[:, 0] == 0)
+    assert torch.equal(csr.head_off[:, :, -1].long(), crow[:, 1:] - crow[:, :-1])
+    assert torch.all(csr.head_off[:, :, 1:] >= csr.head_off[:, :, :-1])
+    Z = int(crow[0, -1])
+    col = csr.col[0, :Z].long()
+    rows = torch.repeat_interleave(torch.arange(T, device=DEV), crow[0, 1:] - crow[0, :-1])
+    head, key = col // T, col % T
+    assert torch.all(key <= rows)                                        # causal: key index <= query index
+    code = (rows * H + head) * T + key
+    assert torch.unique(code).numel() == Z                               # no duplicate (row, head, key)
+    seg = rows * H + head
+    assert torch.all(seg[1:] >= seg[:-1])                                # head-grouped, rows ascending
+    # densified CSR == dense twin of the compressed mask (max_k clamp idle at these shapes), per sampled rows
+    from sea_attention_amd.perlin_attention.ops import resize_from_m_to_t
+    rsel = torch.tensor([0, 1, 63, 64, 255, 256, 257, T // 2, T - 2, T - 1], device=DEV)
+    fp_min = torch.finfo(torch.float16).min / 2
+    cm = ((torch.arange(T, device=DEV).view(1, T) > rsel.view(-1, 1)) * fp_min).view(1, 1, len(rsel), T)
+    dense_rows = resize_from_m_to_t(mask[:1, :, rsel], 0, cm, target_width=T, is_causal=True, k=k, oversampled=1.0)
+    dense_rows = dense_rows.masked_fill(cm < -1, 0)
+    for i, t in enumerate(rsel.tolist()):
+        s, e = int(crow[0, t]), int(crow[0, t + 1])
+        got = torch.zeros((H, T), device=DEV)
+        got[csr.col[0, s:e].long() // T, csr.col[0, s:e].long() % T] = 1
+        assert torch.equal(got, dense_rows[0, :, i])
+    # (3) attention: rows are convex combinations -> with V = 1 every non-empty (row, head) returns exactly rs
+    q = (torch.randn((N, H, T, d), generator=g, device=DEV) * d ** -0.5).to(dtype)
+    kk = torch.randn((N, H, T, d), generator=g, device=DEV).to(dtype)
+    ones = torch.ones((N, H, T, d), device=DEV, dtype=dtype)
+    rs = torch.sigmoid(torch.randn((N, H, T), generator=g, device=DEV))
+    out1 = ops.sparse_attention(q, kk, ones, csr, row_scale=rs)
+    nonempty = (csr.head_off[:, :, 1:] > csr.head_off[:, :, :-1]).transpose(1, 2)       # (N,H,T)
+    expect = (rs * nonempty).unsqueeze(-1).expand_as(out1)
+    assert (out1 - expect).abs().max().item() < 2e-5
+    # (4) linearity in V: attn(a*V1 + V2) == a*attn(V1) + attn(V2)  (same probabilities)
+    v1 = torch.randn((N, H, T, d), generator=g, device=DEV).to(dtype)
+    v2 = torch.randn((N, H, T, d), generator=g, device=DEV).to(dtype)
+    o1, o2 = ops.sparse_attention(q, kk, v1, csr), ops.sparse_attention(q, kk, v2, csr)
+    o12 = ops.sparse_attention(q, kk, (v1.float() * 0.5 + v2.float()).to(dtype), csr)
+    tol = 1e-4 if dtype == torch.float32 else 3e-2
+    assert (o12 - (0.5 * o1 + o2)).abs().max().item() < tol
+    # (5) determinism: two launches are bit-identical
+    assert torch.equal(o1, ops.sparse_attention(q, kk, v1, csr))
+    # (6) rows 0..k-1 keep everything: full causal attention for the first k queries
+    sc = torch.matmul(q[:, :, :k].float(), kk[:, :, :k].float().transpose(-1, -2))
+    sc = sc.masked_fill(torch.arange(k, device=DEV).view(1, k) > torch.arange(k, device=DEV).view(k, 1), float("-inf"))
+    full = torch.matmul(torch.softmax(sc, -1), v1[:, :, :k].float())
+    assert (o1[:, :, :k] - full).abs().max().item() < (1e-4 if dtype == torch.float32 else 2e-3)
+
+
+def test_empty_rows_and_zero_keep(ops):
+    """K_t = 0 rows (padded queries) emit nothing and the attention output of an empty (row, head) is 0."""
+    N, H, T, T_M, k, d = 1, 4, 64, 16, 4, 16
+    probs, q, kk, v, rs = _inputs(N, H, T, T_M, d)
+    keep = ops.keep_table_causal(H, T, T_M, k)
+    keep[10:20] = 0
+    csr, mask = ops.topk_to_csr(probs.to(DEV), keep.to(DEV), k, target_width=T, want_mask=True)
+    assert mask[:, :, 10:20].sum() == 0
+    assert torch.all(csr.crow[0, 11:21] == csr.crow[0, 10])
+    out = ops.sparse_attention(q.to(DEV), kk.to(DEV), v.to(DEV), csr)
+    assert torch.all(out[:, :, 10:20] == 0) and torch.isfinite(out).all()
