@@ -156,6 +156,34 @@ int sea_sparse_attention(const void* q, const void* k, const void* v, int dtype,
                          void* out, int out_dtype, const int64_t* out_strides,
                          sea_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Bandwidth-bound estimator / epilogue pieces (the callers either side of the hot kernels).
+ */
+/* ChannelSplit + LayerNorm: out[n, c*S+i, t, :] = LN(x[n, c, t, i*W:(i+1)*W]) * gamma + beta.
+ * Replaces ChannelSplit (attention.py:123-131) + cnn.lnorm1 (attention.py:266).  x (N,C,T,S*W) and
+ * out (N,C*S,T,W) contiguous, dtype `dtype`; gamma/beta (W) of the same dtype. */
+int sea_split_layernorm(const void* x, int dtype, int64_t N, int64_t C, int64_t T, int64_t S, int64_t W,
+                        const void* gamma, const void* beta, float eps, void* out, sea_stream_t stream);
+
+/* Predictor tail in one pass: nearest upsample x`up` along the width + 1x1 conv (C -> H channels, zero pad 1
+ * on the width) + area resize (T_m+2 -> T_m) + LayerNorm(T_m) + softmax(T_m).
+ * Replaces cnn.keepres.upsam / conv4 / the KeepRes resize / cnn.lnorm2 (attention.py:271-281,
+ * modules.py:42-55,77-92) and the softmax of attention.py:670-673.
+ * y (N,C,T,W4) of `dtype` with element strides y_strides[n,c,t] (pixel stride 1);
+ * conv_wT (C, Hpad) FP32 = the conv weight transposed with the head axis zero-padded to Hpad = 8*ceil(H/8),
+ * conv_b (Hpad) FP32 (both are read through the scalar cache); gamma/beta (T_m) of `dtype`;
+ * probs and optional scores (pre-softmax) are (N,H,T,T_m) contiguous of `dtype`.
+ * Requires W4*up == T_m, T_m <= 512, W4 a multiple of the 16-byte vector width. */
+int sea_predictor_tail(const void* y, int dtype, int64_t N, int64_t C, int64_t H, int64_t T, int64_t W4,
+                       int64_t up, int64_t T_m, const int64_t* y_strides,
+                       const void* conv_wT, const void* conv_b, const void* gamma, const void* beta, float eps,
+                       void* probs, void* scores, sea_stream_t stream);
+
+/* Causal cumulative average out[n,h,t,:] = sum_{s<=t} v[n,h,s,:] / (t+1), fp32 accumulation.
+ * Replaces `avg_v.cumsum(-2) / arange(1..T)` (attention.py:1220-1222).  out (N,H,T,D) contiguous. */
+int sea_cumavg(const void* v, int dtype, int64_t N, int64_t H, int64_t T, int64_t D, const int64_t* v_strides,
+               void* out, sea_stream_t stream);
+
 /* Algorithmic bytes of one sea_sparse_attention launch:
  * Z*(2*D*s + 4) + N*H*T_dst*(2*D*s + 4).  Host-side helper, no device work. */
 int64_t sea_sparse_attention_bytes(int64_t Z, int64_t N, int64_t H, int64_t T_dst, int64_t D, int elem_bytes);

@@ -320,6 +320,29 @@ def mix(partial, v, scale1):
 
 
 # --------------------------------------------------------------------------
+# Estimator pieces that became HIP kernels: plain fp32 torch references of the same ops
+# (floating-point kernels: "plain PyTorch fp32 reference"), following the reference's module chain.
+# --------------------------------------------------------------------------
+def split_layernorm(x, splits, weight, bias, eps=1e-5):
+    """ChannelSplit (PA/attention.py:123-131) + nn.LayerNorm over the last dim (cnn.lnorm1, :266)."""
+    N, C, H, W = x.shape
+    y = x.float().view(N, C, H, splits, W // splits).permute(0, 1, 3, 2, 4).reshape(N, C * splits, H, W // splits)
+    return torch.nn.functional.layer_norm(y, (W // splits,), weight.float(), bias.float(), eps)
+
+
+def predictor_tail(y, conv_w_full, conv_b, ln_w, ln_b, up, T_m, eps=1e-5):
+    """UpsampleFP32((1,up)) -> CausalConv2d(C->H, k=1, padding=1) -> KeepRes resize ('area', since
+    T_m < T_m+2) -> LayerNorm(T_m) -> softmax  (PA/attention.py:271-281,670-673; PA/modules.py:12-55,77-92,96-192).
+    conv_w_full is the module's (H, C, 1, 1) weight.  Returns (probs, scores) in fp32."""
+    F = torch.nn.functional
+    x = F.interpolate(y.float(), scale_factor=(1, up), mode='nearest')
+    x = F.conv2d(x, conv_w_full.float(), conv_b.float(), 1, (0, 1), 1)
+    x = F.interpolate(x, (x.shape[-2], T_m), mode='area')
+    s = F.layer_norm(x, (T_m,), ln_w.float(), ln_b.float(), eps)
+    return torch.softmax(s, -1), s
+
+
+# --------------------------------------------------------------------------
 # Dense restatement of the whole kernel-level path: this is the CPU BASELINE
 # (BASELINE.md section 2): sort-based grouped top-k, gather-based interpolation,
 # dense matmul + additive mask + softmax + matmul (PA/attention.py:1066-1133).

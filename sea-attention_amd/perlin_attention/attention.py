@@ -119,6 +119,8 @@ class PerlinAttention(nn.Module):
         # sparse mode: return the mask as a torch.sparse_csr_tensor (int64, one host sync for Z) instead of
         # the internal int32 FlatCSR handle
         self.materialize_csr = False
+        # debugging / parity: run the estimator's LayerNorm / conv tail through the torch modules even on GPU
+        self.force_torch_estimator = False
 
         d, H = self.attention_head_size, self.num_attention_heads
         pc = self.pconfig
@@ -201,6 +203,20 @@ class PerlinAttention(nn.Module):
             self._keep_cache[key] = hit
         return hit
 
+    def _hip_estimator_ok(self, x):
+        """HIP kernels for ChannelSplit+LN1 / predictor tail apply when: device tensor, autograd off, the standard
+        causal predictor layout, and shapes inside the kernels' limits.  Otherwise the torch modules run."""
+        if self.force_torch_estimator or not x.is_cuda or torch.is_grad_enabled() or not self.pconfig.causal:
+            return False
+        T_M = self.pconfig.attention_predictor_length
+        body = list(self.attention_predictor_cnn[1].module.net.children())
+        up, conv4 = body[-2].module, body[-1].module
+        vec = 4 if x.dtype == torch.float32 else 8
+        return (isinstance(up, UpsampleFP32) and tuple(up.scale) == (1, 4) and isinstance(conv4, CausalConv2d)
+                and conv4.kernel_size == 1 and conv4.padding == (0, 1) and conv4.causal
+                and T_M % 4 == 0 and T_M <= 512 and (T_M // 4) % vec == 0
+                and ((T_M // 4 + 63) // 64) * ((self.num_attention_heads + 7) // 8) <= 16)
+
     def _estimate(self, q, k, v, q_for_atten, k_for_atten, v_for_atten, dst_attention_mask, not_padded, T_SRC):
         """Steps A..G: value augmentation, Performer, predictor MLP + CNN, softmax over T_M."""
         bench = get_bench()
@@ -234,18 +250,49 @@ class PerlinAttention(nn.Module):
                         assert (x.shape[-2] % query_skips) == 0
                         x = x[:, :, ::query_skips, :]
                     t_attention_predictor = self.attention_predictor_enc(x)
-            with timer("predictor.dec_row"):
-                estimated_attention_score = self.attention_predictor_dec_row(t_attention_predictor)
-                bench.register_temp_buffer('estimated_attention_score_dec_row', estimated_attention_score)
-            with timer("predictor.cnn"):
-                estimated_attention_score = self.attention_predictor_cnn(estimated_attention_score)
-                if query_skips > 1:
-                    estimated_attention_score = estimated_attention_score.repeat_interleave(query_skips, dim=-2)
-                    t_attention_predictor = t_attention_predictor.repeat_interleave(query_skips, dim=-2)
-            bench.register_temp_buffer('t_attention_predictor', t_attention_predictor)
-        with timer("mask_softmax"):
-            estimated_attention_probs = torch.softmax(estimated_attention_score.float(), dim=-1) \
-                .to(estimated_attention_score.dtype)
+            # HIP fast path for the bandwidth-bound estimator pieces: device tensors, no autograd, and the
+            # standard causal predictor layout (ChannelSplit+LN, ..., upsample x4, 1x1 conv pad 1, LN, softmax)
+            use_hip = self._hip_estimator_ok(t_attention_predictor)
+            want_scores = get_bench().activate_temp_buffers or (not self.benchmarking)
+            if use_hip:
+                cnn = self.attention_predictor_cnn
+                ln1, keepres, ln2 = cnn[0].module, cnn[1].module, cnn[2].module
+                with timer("predictor.dec_row"):
+                    dec = self.attention_predictor_dec_row[0](t_attention_predictor)          # Linear only
+                    bench.register_temp_buffer('estimated_attention_score_dec_row', None,
+                                               lazy=lambda: self.attention_predictor_dec_row[1](dec))
+                with timer("predictor.cnn"):
+                    with timer("cnn.lnorm1"):
+                        x = ops.split_layernorm(dec, self.attention_predictor_dec_row_splits, ln1.weight, ln1.bias, ln1.eps)
+                    body = list(keepres.net.children())
+                    with timer("cnn.keepres"):
+                        for layer in body[:-2]:                                               # causal convs + ReLUs
+                            x = layer(x)
+                        conv4 = body[-1].module
+                        with timer("cnn.tail"):
+                            estimated_attention_probs, estimated_attention_score = ops.predictor_tail(
+                                x, conv4.weight[:, :, 0, 0], conv4.bias, ln2.weight, ln2.bias, up=4,
+                                T_m=self.pconfig.attention_predictor_length, eps=ln2.eps, want_scores=want_scores)
+                    if query_skips > 1:
+                        estimated_attention_probs = estimated_attention_probs.repeat_interleave(query_skips, dim=-2)
+                        if estimated_attention_score is not None:
+                            estimated_attention_score = estimated_attention_score.repeat_interleave(query_skips, dim=-2)
+                        t_attention_predictor = t_attention_predictor.repeat_interleave(query_skips, dim=-2)
+                bench.register_temp_buffer('t_attention_predictor', t_attention_predictor)
+            else:
+                with timer("predictor.dec_row"):
+                    estimated_attention_score = self.attention_predictor_dec_row(t_attention_predictor)
+                    bench.register_temp_buffer('estimated_attention_score_dec_row', estimated_attention_score)
+                with timer("predictor.cnn"):
+                    estimated_attention_score = self.attention_predictor_cnn(estimated_attention_score)
+                    if query_skips > 1:
+                        estimated_attention_score = estimated_attention_score.repeat_interleave(query_skips, dim=-2)
+                        t_attention_predictor = t_attention_predictor.repeat_interleave(query_skips, dim=-2)
+                bench.register_temp_buffer('t_attention_predictor', t_attention_predictor)
+        if not use_hip:
+            with timer("mask_softmax"):
+                estimated_attention_probs = torch.softmax(estimated_attention_score.float(), dim=-1) \
+                    .to(estimated_attention_score.dtype)
         bench.register_temp_buffer('estimated_attention_score', estimated_attention_score)
         bench.register_temp_buffer('estimated_attention_probs', estimated_attention_probs)
         return v, t_attention_predictor, estimated_attention_score, estimated_attention_probs
@@ -397,8 +444,7 @@ class PerlinAttention(nn.Module):
                 average_scale = sig[..., 1].contiguous()
             with timer("attention.avg_pool"):
                 avg_v = v if not_padded else v * (dst_attention_mask > -1)
-                denom = torch.arange(1, T + 1, device=v.device).view(1, 1, -1, 1)
-                average_context_layer = (avg_v.cumsum(-2) / denom).to(v.dtype)
+                average_context_layer = ops.cumavg(avg_v)              # HIP scan, fp32 accumulation
             out_dtype = self.context_layer_dtype or torch.float32
             qs = q_for_score if q_for_score.stride(-1) == 1 else q_for_score.contiguous()
             ks = k_for_score if k_for_score.stride(-1) == 1 else k_for_score.contiguous()

@@ -1,0 +1,69 @@
+"""HIP kernels for the bandwidth-bound pieces of SEA's estimator and epilogue (csrc/sea_predictor.hip).
+Not part of the reference's operator package: there these steps are chains of framework kernels inside
+`PerlinAttention.forward` (attention.py:123-131,266-281,670-673,1220-1222)."""
+from ctypes import c_void_p
+from typing import Optional
+
+import torch
+
+from ... import _lib
+
+
+def _p(t):
+    return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
+
+
+def split_layernorm(x: torch.Tensor, splits: int, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5):
+    """ChannelSplit(splits) followed by LayerNorm over the new (narrower) last dim.
+    x (N,C,T,splits*W) -> (N,C*splits,T,W)."""
+    lib = _lib.load()
+    _lib.require_gpu(x, weight, bias)
+    N, C, T, SW = x.shape
+    assert SW % splits == 0
+    W = SW // splits
+    x = x.contiguous()
+    w = weight.to(x.dtype).contiguous()
+    b = bias.to(x.dtype).contiguous()
+    out = torch.empty((N, C * splits, T, W), dtype=x.dtype, device=x.device)
+    _lib.check(lib.sea_split_layernorm(_p(x), _lib.dtype_code(x.dtype), N, C, T, splits, W, _p(w), _p(b), float(eps),
+                                       _p(out), _lib.stream_ptr()), "sea_split_layernorm")
+    return out
+
+
+def predictor_tail(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor,
+                   up: int, T_m: int, eps: float = 1e-5, want_scores: bool = False):
+    """upsample(1,up) -> 1x1 conv (pad 1 on width) -> area resize to T_m -> LayerNorm(T_m) -> softmax.
+    y (N,C,T,W4) -> probs (N,H,T,T_m) [, scores].  conv_w (H,C) is the live row of the causal 1x1 kernel."""
+    lib = _lib.load()
+    _lib.require_gpu(y, conv_w, conv_b, ln_w, ln_b)
+    N, C, T, W4 = y.shape
+    H = conv_w.shape[0]
+    assert conv_w.shape == (H, C) and W4 * up == T_m
+    if y.stride(-1) != 1:
+        y = y.contiguous()
+    dt = y.dtype
+    Hpad = (H + 7) // 8 * 8
+    cw = torch.zeros((C, Hpad), dtype=torch.float32, device=y.device)     # transposed, head axis padded: scalar-cache reads
+    cw[:, :H] = conv_w.to(dt).float().t()
+    cb = torch.zeros((Hpad,), dtype=torch.float32, device=y.device)
+    cb[:H] = conv_b.to(dt).float()
+    g, b = ln_w.to(dt).contiguous(), ln_b.to(dt).contiguous()
+    probs = torch.empty((N, H, T, T_m), dtype=dt, device=y.device)
+    scores = torch.empty_like(probs) if want_scores else None
+    _lib.check(lib.sea_predictor_tail(_p(y), _lib.dtype_code(dt), N, C, H, T, W4, up, T_m, _lib.strides3(y),
+                                      _p(cw), _p(cb), _p(g), _p(b), float(eps), _p(probs), _p(scores),
+                                      _lib.stream_ptr()), "sea_predictor_tail")
+    return probs, scores
+
+
+def cumavg(v: torch.Tensor) -> torch.Tensor:
+    """Causal cumulative average over the time axis of (N,H,T,D), fp32 accumulation, dtype preserved."""
+    lib = _lib.load()
+    _lib.require_gpu(v)
+    N, H, T, D = v.shape
+    if v.stride(-1) != 1:
+        v = v.contiguous()
+    out = torch.empty((N, H, T, D), dtype=v.dtype, device=v.device)
+    _lib.check(lib.sea_cumavg(_p(v), _lib.dtype_code(v.dtype), N, H, T, D, _lib.strides3(v), _p(out),
+                              _lib.stream_ptr()), "sea_cumavg")
+    return out

@@ -1,0 +1,102 @@
+"""-m gpu: the estimator/epilogue HIP kernels (csrc/sea_predictor.hip) against plain fp32 torch references
+of the same ops (oracle.split_layernorm / predictor_tail / cumavg).  Floating point: fp32 inputs within 1e-5
+relative; 16-bit inputs are compared against the fp32 reference evaluated on the same rounded inputs, so
+the only differences are the final rounding of the outputs (bf16: 2^-8 relative)."""
+import pytest
+import torch
+
+from oracle import sea_oracle as O
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from sea_attention_amd.perlin_attention import ops
+    return ops
+
+
+def _tol(dtype):
+    return {torch.float32: (1e-5, 1e-5), torch.bfloat16: (1e-2, 1e-2), torch.float16: (2e-3, 2e-3)}[dtype]
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,C,T,S,W", [(2, 12, 128, 2, 16), (1, 32, 512, 2, 64), (1, 5, 70, 2, 32), (1, 4, 33, 4, 24),
+                                       (1, 8, 64, 2, 128)])
+def test_split_layernorm(ops, dtype, N, C, T, S, W):
+    if dtype != torch.float32 and W % 8:
+        pytest.skip("16-bit rows need W % 8 == 0")
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn((N, C, T, S * W), generator=g) * 2 + 0.3).to(dtype)
+    w = (torch.rand(W, generator=g) + 0.5).to(dtype)
+    b = torch.randn(W, generator=g).to(dtype)
+    ref = O.split_layernorm(x.float(), S, w.float(), b.float(), 1e-5)
+    out = ops.split_layernorm(x.to(DEV), S, w.to(DEV), b.to(DEV), 1e-5)
+    assert out.dtype == dtype and tuple(out.shape) == (N, C * S, T, W)
+    atol, rtol = _tol(dtype)
+    torch.testing.assert_close(out.float().cpu(), ref, atol=atol * 4, rtol=rtol)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,H,T,T_M", [(2, 12, 128, 64), (1, 32, 300, 256), (1, 40, 64, 256), (1, 4, 50, 128),
+                                       (1, 6, 40, 512), (1, 3, 20, 32)])
+def test_predictor_tail(ops, dtype, N, H, T, T_M):
+    C, W4 = 2 * H, T_M // 4
+    if dtype != torch.float32 and W4 % 8:
+        pytest.skip("16-bit rows need W4 % 8 == 0")
+    g = torch.Generator().manual_seed(1)
+    y = torch.relu(torch.randn((N, C, T, W4), generator=g)).to(dtype)
+    cw = (torch.randn((H, C, 1, 1), generator=g) * C ** -0.5).to(dtype)
+    cb = (torch.randn(H, generator=g) * 0.1).to(dtype)
+    lw = (torch.rand(T_M, generator=g) + 0.5).to(dtype)
+    lb = (torch.randn(T_M, generator=g) * 0.1).to(dtype)
+    p_ref, s_ref = O.predictor_tail(y.float(), cw.float(), cb.float(), lw.float(), lb.float(), 4, T_M)
+    probs, scores = ops.predictor_tail(y.to(DEV), cw[:, :, 0, 0].to(DEV), cb.to(DEV), lw.to(DEV), lb.to(DEV),
+                                       up=4, T_m=T_M, want_scores=True)
+    assert probs.dtype == dtype and tuple(probs.shape) == (N, H, T, T_M)
+    if dtype == torch.float32:
+        torch.testing.assert_close(scores.cpu(), s_ref, atol=2e-5, rtol=1e-5)
+        torch.testing.assert_close(probs.cpu(), p_ref, atol=1e-7, rtol=1e-4)
+    else:
+        torch.testing.assert_close(scores.float().cpu(), s_ref, atol=3e-2, rtol=1e-2)
+        torch.testing.assert_close(probs.float().cpu(), p_ref, atol=1e-5, rtol=4e-2)
+    assert torch.allclose(probs.float().sum(-1), torch.ones((), device=DEV), atol=2e-2 if dtype != torch.float32 else 1e-5)
+    p2, s2 = ops.predictor_tail(y.to(DEV), cw[:, :, 0, 0].to(DEV), cb.to(DEV), lw.to(DEV), lb.to(DEV), up=4, T_m=T_M)
+    assert s2 is None and torch.equal(p2, probs)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,T,D", [(2, 3, 100, 64), (1, 4, 4096, 64), (1, 2, 33, 80), (1, 2, 257, 128), (1, 1, 7, 16)])
+def test_cumavg(ops, dtype, N, H, T, D):
+    g = torch.Generator().manual_seed(2)
+    v = torch.randn((N, H, T, D), generator=g).to(dtype)
+    ref = v.float().cumsum(-2) / torch.arange(1, T + 1).view(1, 1, -1, 1)
+    out = ops.cumavg(v.to(DEV))
+    assert out.dtype == dtype
+    atol, rtol = _tol(dtype)
+    torch.testing.assert_close(out.float().cpu(), ref, atol=atol, rtol=rtol)
+    # strided input view (N,T,H,D) -> (N,H,T,D)
+    vt = v.permute(0, 2, 1, 3).contiguous().to(DEV).permute(0, 2, 1, 3)
+    assert torch.equal(ops.cumavg(vt), out)
+
+
+def test_module_hip_estimator_matches_torch_estimator():
+    """Same layer, same inputs: estimator through the HIP kernels vs through the torch modules."""
+    import sea_attention_amd as S
+    from test_gpu_module import make_layer, run, causal_mask
+    N, H, T, d, T_M, k = 1, 12, 512, 64, 256, 64
+    layer = make_layer(H, d, T_M, k, T)
+    S.seed(9)
+    q = torch.randn((N, H, T, d), device=DEV)
+    mask = causal_mask(N, T, torch.float32)
+    _, b_hip = run(layer, q * d ** -0.5, q.clone(), q.clone(), mask, True)
+    layer.attention.force_torch_estimator = True
+    try:
+        _, b_torch = run(layer, q * d ** -0.5, q.clone(), q.clone(), mask, True)
+    finally:
+        layer.attention.force_torch_estimator = False
+    for name, atol in [('estimated_attention_score_dec_row', 1e-6), ('estimated_attention_score', 2e-4),
+                       ('estimated_attention_probs', 1e-6), ('average_context_layer', 1e-5)]:
+        err = (b_hip[name].float() - b_torch[name].float()).abs().max().item()
+        assert err <= atol, (name, err)
