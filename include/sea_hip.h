@@ -159,11 +159,13 @@ int sea_sparse_attention(const void* q, const void* k, const void* v, int dtype,
 /* ---------------------------------------------------------------------------------------------
  * Bandwidth-bound estimator / epilogue pieces (the callers either side of the hot kernels).
  */
-/* ChannelSplit + LayerNorm: out[n, c*S+i, t, :] = LN(x[n, c, t, i*W:(i+1)*W]) * gamma + beta.
- * Replaces ChannelSplit (attention.py:123-131) + cnn.lnorm1 (attention.py:266).  x (N,C,T,S*W) and
- * out (N,C*S,T,W) contiguous, dtype `dtype`; gamma/beta (W) of the same dtype. */
+/* ChannelSplit + LayerNorm (+ optional GELU): out[n, c*S+i, t, :] = act(LN(x[n, c, t, i*W:(i+1)*W]) * gamma + beta).
+ * S=2, activation=0 replaces ChannelSplit (attention.py:123-131) + cnn.lnorm1 (attention.py:266);
+ * S=1, activation=1 (exact-erf GELU) replaces LayerNorm + GELU of attention_predictor_enc (attention.py:190-196).
+ * x (N,C,T,S*W) and out (N,C*S,T,W) contiguous, dtype `dtype`; gamma/beta (W) of the same dtype. */
 int sea_split_layernorm(const void* x, int dtype, int64_t N, int64_t C, int64_t T, int64_t S, int64_t W,
-                        const void* gamma, const void* beta, float eps, void* out, sea_stream_t stream);
+                        const void* gamma, const void* beta, float eps, int activation, void* out,
+                        sea_stream_t stream);
 
 /* Predictor tail in one pass: nearest upsample x`up` along the width + 1x1 conv (C -> H channels, zero pad 1
  * on the width) + area resize (T_m+2 -> T_m) + LayerNorm(T_m) + softmax(T_m).

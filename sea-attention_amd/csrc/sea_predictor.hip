@@ -27,7 +27,7 @@ template <int LPR> __device__ inline float lpr_sum(float x) {
 
 template <typename T, int LPR>
 __global__ __launch_bounds__(256) void split_layernorm_kernel(const T* x, T* out, const T* gamma, const T* beta, float eps,
-                                                             int64_t rows, int C, int Tn, int S, int W) {
+                                                             int64_t rows, int C, int Tn, int S, int W, int act_gelu) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr int RPW = 64 / LPR;  // rows per wave-instruction
   const int lane = threadIdx.x & 63;
@@ -71,6 +71,10 @@ __global__ __launch_bounds__(256) void split_layernorm_kernel(const T* x, T* out
       float o[VEC];
 #pragma unroll
       for (int j = 0; j < VEC; ++j) o[j] = (f[j] - mean) * rstd * g[j] + b[j];
+      if (act_gelu) {   // nn.GELU() default: exact erf form
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) o[j] = 0.5f * o[j] * (1.0f + erff(o[j] * 0.70710678118654752f));
+      }
       if (VEC == 4) {
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + o_off) = make_float4(o[0], o[1], o[2], o[3]);
       } else {
@@ -306,7 +310,7 @@ using namespace sea;
 
 template <typename T>
 static int launch_split_ln(const void* x, void* out, const void* g, const void* b, float eps, int64_t N, int64_t C,
-                           int64_t Tn, int64_t S, int64_t W, hipStream_t s) {
+                           int64_t Tn, int64_t S, int64_t W, int act, hipStream_t s) {
   constexpr int VEC = Elem<T>::VEC;
   int lpr = 1;
   while (lpr * VEC < W) lpr *= 2;
@@ -316,7 +320,7 @@ static int launch_split_ln(const void* x, void* out, const void* g, const void* 
   if (blocks > 16384) blocks = 16384;
   dim3 grid((unsigned)blocks), block(256);
 #define SEA_SLN(L) hipLaunchKernelGGL((split_layernorm_kernel<T, L>), grid, block, 0, s, (const T*)x, (T*)out, (const T*)g, \
-                                      (const T*)b, eps, rows, (int)C, (int)Tn, (int)S, (int)W)
+                                      (const T*)b, eps, rows, (int)C, (int)Tn, (int)S, (int)W, act)
   switch (lpr) {
     case 1: SEA_SLN(1); break; case 2: SEA_SLN(2); break; case 4: SEA_SLN(4); break; case 8: SEA_SLN(8); break;
     case 16: SEA_SLN(16); break; case 32: SEA_SLN(32); break; case 64: SEA_SLN(64); break;
@@ -327,11 +331,13 @@ static int launch_split_ln(const void* x, void* out, const void* g, const void* 
 }
 
 extern "C" int sea_split_layernorm(const void* x, int dtype, int64_t N, int64_t C, int64_t T, int64_t S, int64_t W,
-                                   const void* gamma, const void* beta, float eps, void* out, sea_stream_t stream) {
+                                   const void* gamma, const void* beta, float eps, int activation, void* out,
+                                   sea_stream_t stream) {
   const char* nm = "sea_split_layernorm";
   SEA_REQUIRE(x && gamma && beta && out, SEA_EINVAL, "%s: null pointer", nm);
   SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_F16 || dtype == SEA_BF16, SEA_EINVAL, "%s: bad dtype %d", nm, dtype);
   SEA_REQUIRE(N > 0 && C > 0 && T > 0 && S > 0 && W > 0, SEA_EINVAL, "%s: bad shape", nm);
+  SEA_REQUIRE(activation == 0 || activation == 1, SEA_EINVAL, "%s: activation must be 0 (none) or 1 (GELU)", nm);
   const int vec = dtype == SEA_F32 ? 4 : 8;
   SEA_REQUIRE(W % vec == 0 && W <= 64 * vec, SEA_EUNSUPPORTED, "%s: W=%lld must be a multiple of %d and <= %d", nm,
               (long long)W, vec, 64 * vec);
@@ -339,9 +345,9 @@ extern "C" int sea_split_layernorm(const void* x, int dtype, int64_t N, int64_t 
               "%s: tensors must be 16-byte aligned", nm);
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (dtype == SEA_F32) rc = launch_split_ln<float>(x, out, gamma, beta, eps, N, C, T, S, W, s);
-  else if (dtype == SEA_F16) rc = launch_split_ln<__half>(x, out, gamma, beta, eps, N, C, T, S, W, s);
-  else rc = launch_split_ln<__hip_bfloat16>(x, out, gamma, beta, eps, N, C, T, S, W, s);
+  if (dtype == SEA_F32) rc = launch_split_ln<float>(x, out, gamma, beta, eps, N, C, T, S, W, activation, s);
+  else if (dtype == SEA_F16) rc = launch_split_ln<__half>(x, out, gamma, beta, eps, N, C, T, S, W, activation, s);
+  else rc = launch_split_ln<__hip_bfloat16>(x, out, gamma, beta, eps, N, C, T, S, W, activation, s);
   SEA_REQUIRE(rc == SEA_OK, rc, "%s: unsupported width", nm);
   SEA_CHECK_LAUNCH(nm);
   return SEA_OK;

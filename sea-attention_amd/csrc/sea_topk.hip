@@ -16,6 +16,18 @@
 // Everything here is HBM-bound integer/compare work; LDS holds the score histogram only.
 #include "sea_common.hpp"
 
+#ifndef SEA_EXP
+#define SEA_EXP 0
+#endif
+
+#ifdef SEA_STAMP
+__device__ unsigned long long sea_dbg[16];
+#define STAMP(i) do { if (threadIdx.x == 0) { unsigned long long _t = __builtin_amdgcn_s_memtime(); \
+  atomicAdd(&sea_dbg[i], _t - _tprev); _tprev = _t; } } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
+
 namespace sea {
 
 constexpr int TK_THREADS = 256;
@@ -81,20 +93,118 @@ __device__ inline int block_excl_scan(int v, int* s_wave /*[TK_WAVES]*/, int* to
   return base + incl - v;
 }
 
-template <typename T, int EPT, bool FROM_MASK>
+constexpr int TK_CAND_CAP = 1024;  // threshold-bin keys resolved by direct ranking (more -> multi-pass fallback)
+
+// Slow path, rarely taken (massive ties / all-equal rows / overfull threshold bin): classic MSB radix passes
+// followed by an ordered tie scan.  It re-reads the row from memory in every pass instead of using the caller's
+// register-resident keys, so it adds nothing to the register budget of the hot path.
+template <typename T>
+__device__ __noinline__ unsigned long long select_multipass(const T* base, const TopkParams& p, int K, uint32_t umin,
+                                                            uint32_t umax, int rounds, int* s_hist, int* s_wave,
+                                                            int* s_bcast) {
+  const int tid = threadIdx.x;
+  auto load_keys = [&](int j, uint32_t* k4) -> bool {
+    const int c = j * TK_THREADS + tid;
+    if (c >= p.nchunks) { k4[0] = k4[1] = k4[2] = k4[3] = 0u; return false; }
+    const int f0 = c * 4;
+    const int h = f0 / p.T_m, b0 = f0 - h * p.T_m;
+    float f[4];
+    load4<T>(base + h * p.sh + b0, f);
+    for (int e = 0; e < 4; ++e) k4[e] = f2key(f[e]);
+    return true;
+  };
+  unsigned long long sel = 0;
+  uint32_t prefix = umax;
+  int bits_left = (umax == umin) ? 0 : (32 - __clz(umax ^ umin));
+  int kth = K, n_eq = p.M;
+  while (bits_left > 0) {
+    const int d = bits_left < 11 ? bits_left : 11;
+    const int shift = bits_left - d;
+    const int nb = 1 << d;
+    const int hi = shift + d;
+    for (int i = tid; i < nb; i += TK_THREADS) s_hist[i] = 0;
+    __syncthreads();
+    for (int j = 0; j < rounds; ++j) {
+      uint32_t k4[4];
+      if (!load_keys(j, k4)) continue;
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t u = k4[e];
+        const bool cand = (hi >= 32) ? true : ((u >> hi) == (prefix >> hi));
+        if (cand) atomicAdd(&s_hist[nb - 1 - (int)((u >> shift) & (uint32_t)(nb - 1))], 1);
+      }
+    }
+    __syncthreads();
+    const int per = (nb + TK_THREADS - 1) / TK_THREADS;
+    int mine = 0;
+    for (int i = 0; i < per; ++i) {
+      const int bi = tid * per + i;
+      if (bi < nb) mine += s_hist[bi];
+    }
+    int total;
+    const int excl = block_excl_scan(mine, s_wave, &total);
+    if (excl < kth && kth <= excl + mine) {
+      int run = excl;
+      for (int i = 0; i < per; ++i) {
+        const int bi = tid * per + i;
+        const int c = s_hist[bi];
+        if (kth <= run + c) { s_bcast[0] = bi; s_bcast[1] = run; s_bcast[2] = c; break; }
+        run += c;
+      }
+    }
+    __syncthreads();
+    const int rb = s_bcast[0];
+    kth -= s_bcast[1];
+    n_eq = s_bcast[2];
+    const uint32_t dmask = (uint32_t)(nb - 1) << shift;
+    prefix = (prefix & ~dmask) | ((uint32_t)(nb - 1 - rb) << shift);
+    bits_left = shift;
+    __syncthreads();
+  }
+  const uint32_t tau = prefix;
+  const int r = kth;   // how many of the keys == tau are kept: lowest flat index first
+  int seen = 0;        // ties in earlier rounds (flat order = round-major, then thread, then element)
+  for (int j = 0; j < rounds; ++j) {
+    uint32_t k4[4];
+    const bool valid = load_keys(j, k4);
+    int cnt = 0;
+    for (int e = 0; e < 4; ++e) cnt += (valid && k4[e] == tau) ? 1 : 0;
+    int total = 0, rank = 0;
+    if (n_eq != r) rank = seen + block_excl_scan(cnt, s_wave, &total);   // block-uniform condition
+    for (int e = 0; e < 4; ++e) {
+      if (!valid) continue;
+      if (k4[e] > tau) sel |= 1ull << (4 * j + e);
+      if (k4[e] == tau) {
+        if (n_eq == r || rank < r) sel |= 1ull << (4 * j + e);
+        ++rank;
+      }
+    }
+    seen += total;
+  }
+  return sel;
+}
+
+// FULL: H*T_m == 256*EPT, i.e. every register slot holds a real pixel (no validity tests on the hot path).
+template <typename T, int EPT, bool FROM_MASK, bool FULL>
 __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(TopkParams p) {
   constexpr int R = EPT / 4;  // chunk rounds
-  __shared__ int s_hist[TK_MAX_BINS];
+  __shared__ int s_hist[TK_MAX_BINS + 1];          // +1: dump bin for unused register slots
   __shared__ int s_head[1024];
   __shared__ int s_wave[TK_WAVES];
   __shared__ uint32_t s_red[2 * TK_WAVES];
   __shared__ int s_bcast[4];
+  __shared__ uint32_t s_ckey[TK_CAND_CAP];         // threshold-bin candidates: key ...
+  __shared__ uint32_t s_cidx[TK_CAND_CAP];         // ... and flat pixel index
+  __shared__ uint32_t s_selbits[512];              // resolved candidates, one bit per flat pixel (M <= 16384)
+  __shared__ int s_ncand;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const int row = blockIdx.x;
   const int n = row / p.T_dst, t = row - n * p.T_dst;
   const T* base = reinterpret_cast<const T*>(p.src) + n * p.sn + t * p.st;
+#ifdef SEA_STAMP
+  unsigned long long _tprev = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- load the row: chunk c = j*256 + tid covers flat pixels 4c..4c+3 (head-major) ------------
   uint32_t key[EPT];
@@ -103,7 +213,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(TopkParams p) {
   for (int j = 0; j < R; ++j) {
     const int c = j * TK_THREADS + tid;
     float f[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool valid = c < p.nchunks;
+    const bool valid = FULL || c < p.nchunks;
     if (valid) {
       const int f0 = c * 4;
       const int h = f0 / p.T_m, b0 = f0 - h * p.T_m;
@@ -119,58 +229,58 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(TopkParams p) {
       }
     }
   }
+  // LDS scratch is cleared while the loads are in flight
+  for (int i = tid; i <= TK_MAX_BINS; i += TK_THREADS) s_hist[i] = 0;
+  for (int i = tid; i < 512; i += TK_THREADS) s_selbits[i] = 0;
+  for (int i = tid; i < p.H; i += TK_THREADS) s_head[i] = 0;
+  if (tid == 0) s_ncand = 0;
+  STAMP(0);   // row loaded, keys built
 
   if (!FROM_MASK) {
+#if SEA_EXP == 1
+    const int K = p.M;   // ablation: skip the selection
+#else
     const int K = p.keep[n * p.keep_stride_n + t];
+#endif
     if (K >= p.M) {
 #pragma unroll
       for (int j = 0; j < R; ++j)
-        if (j * TK_THREADS + tid < p.nchunks) sel |= 0xFull << (4 * j);
-    } else if (K > 0) {
-      // ---- common leading bits of all keys: skip them (keeps the LDS histogram spread out) ------
+        if (FULL || j * TK_THREADS + tid < p.nchunks) sel |= 0xFull << (4 * j);
+      __syncthreads();
+    } else if (K <= 0) {
+      __syncthreads();
+    } else {
+      // ---- common leading bits of all keys: skipped, so the histogram digit starts where keys differ --------
       uint32_t umin = 0xFFFFFFFFu, umax = 0u;
 #pragma unroll
       for (int j = 0; j < R; ++j) {
-        if (j * TK_THREADS + tid < p.nchunks) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            umin = min(umin, key[4 * j + e]);
-            umax = max(umax, key[4 * j + e]);
-          }
+        if (FULL || j * TK_THREADS + tid < p.nchunks) {
+          umin = min(umin, min(min(key[4 * j], key[4 * j + 1]), min(key[4 * j + 2], key[4 * j + 3])));
+          umax = max(umax, max(max(key[4 * j], key[4 * j + 1]), max(key[4 * j + 2], key[4 * j + 3])));
         }
       }
       umin = wave_min(umin);
       umax = wave_max(umax);
       if (lane == 0) { s_red[wv] = umin; s_red[TK_WAVES + wv] = umax; }
-      __syncthreads();
+      __syncthreads();   // also publishes the cleared scratch
 #pragma unroll
       for (int i = 0; i < TK_WAVES; ++i) { umin = min(umin, s_red[i]); umax = max(umax, s_red[TK_WAVES + i]); }
-      __syncthreads();
-
-      uint32_t prefix = umax;          // the decided high bits (low bits are don't-care until decided)
-      int bits_left = (umax == umin) ? 0 : (32 - __clz(umax ^ umin));
-      int kth = K;                      // rank still to locate among the candidates
-      int n_eq = p.M;                   // keys equal to the final threshold (all, if every key is equal)
-      // ---- MSB radix passes, 11 bits at a time -------------------------------------------------
-      while (bits_left > 0) {
-        const int d = bits_left < 11 ? bits_left : 11;
-        const int shift = bits_left - d;
+      STAMP(1);   // min/max prologue
+      const int bits_left = (umax == umin) ? 0 : (32 - __clz(umax ^ umin));
+      bool fast = bits_left > 0;
+      int rb_sel = 0, kth = K, c_in = 0, shift = 0, d = 0;
+      if (fast) {
+        // ---- ONE histogram pass over the top `d` differing bits (descending bins) ------------------------------
+        d = bits_left < 11 ? bits_left : 11;
+        shift = bits_left - d;
         const int nb = 1 << d;
-        const int hi = shift + d;  // bits above the digit; candidates agree with `prefix` on them
-        for (int i = tid; i < nb; i += TK_THREADS) s_hist[i] = 0;
-        __syncthreads();
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
-          const uint32_t u = key[i];
-          const bool cand = (hi >= 32) ? true : ((u >> hi) == (prefix >> hi));
-          const bool valid = ((i >> 2) * TK_THREADS + tid) < p.nchunks;
-          if (cand && valid) {
-            const int rb = nb - 1 - (int)((u >> shift) & (uint32_t)(nb - 1));  // descending bins
-            atomicAdd(&s_hist[rb], 1);
-          }
+          int rb = (int)__builtin_amdgcn_ubfe(~key[i], shift, d);
+          if (!FULL) rb = (((i >> 2) * TK_THREADS + tid) < p.nchunks) ? rb : TK_MAX_BINS;
+          atomicAdd(&s_hist[rb], 1);
         }
         __syncthreads();
-        // locate the descending bin that holds rank `kth`: thread i owns bins [i*per, (i+1)*per)
         const int per = (nb + TK_THREADS - 1) / TK_THREADS;
         int mine = 0;
         for (int i = 0; i < per; ++i) {
@@ -179,68 +289,72 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(TopkParams p) {
         }
         int total;
         const int excl = block_excl_scan(mine, s_wave, &total);
-        if (excl < kth && kth <= excl + mine) {
+        if (excl < K && K <= excl + mine) {
           int run = excl;
           for (int i = 0; i < per; ++i) {
             const int bi = tid * per + i;
             const int c = s_hist[bi];
-            if (kth <= run + c) { s_bcast[0] = bi; s_bcast[1] = run; s_bcast[2] = c; break; }
+            if (K <= run + c) { s_bcast[0] = bi; s_bcast[1] = run; s_bcast[2] = c; break; }
             run += c;
           }
         }
         __syncthreads();
-        const int rb = s_bcast[0];
-        kth -= s_bcast[1];
-        n_eq = s_bcast[2];
-        const uint32_t digit = (uint32_t)(nb - 1 - rb);
-        const uint32_t dmask = (uint32_t)(nb - 1) << shift;
-        prefix = (prefix & ~dmask) | (digit << shift);
-        bits_left = shift;
-        __syncthreads();
+        rb_sel = s_bcast[0];
+        kth = K - s_bcast[1];       // rank still to find inside the threshold bin
+        c_in = s_bcast[2];          // keys in the threshold bin
+        // the bin is resolved by direct ranking unless it is overfull
+        fast = c_in <= TK_CAND_CAP;
       }
-      const uint32_t tau = prefix;
-      const int r = kth;  // how many of the keys == tau are kept (lowest flat index first)
-      if (n_eq == r) {
+      STAMP(2);   // histogram + bin search
+      if (fast) {
+        // ---- sweep: above the bin -> kept; inside the bin -> candidate list (key, flat index) -----------------
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
-          const bool valid = ((i >> 2) * TK_THREADS + tid) < p.nchunks;
-          if (valid && key[i] >= tau) sel |= 1ull << i;
+          const int rb = (int)__builtin_amdgcn_ubfe(~key[i], shift, d);
+          const bool valid = FULL || (((i >> 2) * TK_THREADS + tid) < p.nchunks);
+          if (valid && rb < rb_sel) sel |= 1ull << i;
+          if (valid && rb == rb_sel) {
+            const int slot = atomicAdd(&s_ncand, 1);
+            s_ckey[slot] = key[i];
+            s_cidx[slot] = (uint32_t)(((i >> 2) * TK_THREADS + tid) * 4 + (i & 3));
+          }
         }
-      } else {
-        int seen = 0;  // ties in earlier rounds (flat order = round-major, then thread, then element)
+        __syncthreads();
+        // ---- rank inside the bin: (key desc, flat index asc); the first `kth` are kept (ties resolved here) ---
+        for (int ci = tid; ci < c_in; ci += TK_THREADS) {
+          const uint32_t ku = s_ckey[ci], kf = s_cidx[ci];
+          int rank = 0;
+          for (int cj = 0; cj < c_in; ++cj) {
+            const uint32_t ou = s_ckey[cj], of = s_cidx[cj];
+            rank += (ou > ku || (ou == ku && of < kf)) ? 1 : 0;
+          }
+          if (rank < kth) atomicOr(&s_selbits[kf >> 5], 1u << (kf & 31));
+        }
+        __syncthreads();
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-          const bool valid = (j * TK_THREADS + tid) < p.nchunks;
-          int cnt = 0;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) cnt += (valid && key[4 * j + e] == tau) ? 1 : 0;
-          int total;
-          int rank = seen + block_excl_scan(cnt, s_wave, &total);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const uint32_t u = key[4 * j + e];
-            if (valid && u > tau) sel |= 1ull << (4 * j + e);
-            if (valid && u == tau) {
-              if (rank < r) sel |= 1ull << (4 * j + e);
-              ++rank;
-            }
-          }
-          seen += total;
+          const int c = j * TK_THREADS + tid;
+          const unsigned long long nibx = (s_selbits[(c >> 3) & 511] >> (4 * (c & 7))) & 0xFu;
+          sel |= nibx << (4 * j);
         }
+      } else {
+        sel = select_multipass<T>(base, p, K, umin, umax, R, s_hist, s_wave, s_bcast);
+        for (int i = tid; i < p.H; i += TK_THREADS) s_head[i] = 0;
+        __syncthreads();
       }
     }
+  } else {
+    __syncthreads();
   }
 
+  STAMP(3);   // selection flags
   // ---- outputs ----------------------------------------------------------------------------------
-  for (int i = tid; i < p.H; i += TK_THREADS) s_head[i] = 0;
-  __syncthreads();
-
   const int w_t = row_width(t, p.T_dst, p.T_src, p.is_causal);
   const float scale = interp_scale(w_t, p.T_m);
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     const int c = j * TK_THREADS + tid;
-    const bool valid = c < p.nchunks;
+    const bool valid = FULL || c < p.nchunks;
     const uint32_t nib = (uint32_t)(sel >> (4 * j)) & 0xFu;
     // bit mask: 8 consecutive lanes own one 32-bit word
     uint32_t word = nib << (4 * (lane & 7));
@@ -248,32 +362,33 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(TopkParams p) {
     word |= __shfl_xor(word, 2);
     word |= __shfl_xor(word, 4);
     if ((lane & 7) == 0 && (c >> 3) < p.W) p.bits[(int64_t)row * p.W + (c >> 3)] = word;
-
-    int h = 0, b0 = 0;
-    if (valid) { const int f0 = c * 4; h = f0 / p.T_m; b0 = f0 - h * p.T_m; }
     if (p.mask_out != nullptr && valid) {
+      const int f0 = c * 4;
+      const int h = f0 / p.T_m, b0 = f0 - h * p.T_m;
       float4 m;
       m.x = (nib & 1u) ? 1.f : 0.f; m.y = (nib & 2u) ? 1.f : 0.f;
       m.z = (nib & 4u) ? 1.f : 0.f; m.w = (nib & 8u) ? 1.f : 0.f;
       *reinterpret_cast<float4*>(p.mask_out + (((int64_t)n * p.H + h) * p.T_dst + t) * p.T_m + b0) = m;
     }
-    // entries this chunk will emit: sum over kept pixels of min(v_end - v_start, max_k)
-    int cnt = 0;
-    if (nib) {
-      float prev = interp_bound(b0, scale);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float nxt = interp_bound(b0 + e + 1, scale);
-        int w = (int)(nxt - prev);
-        w = w < p.max_k ? w : p.max_k;
-        if (nib & (1u << e)) cnt += w;
-        prev = nxt;
-      }
-    }
-    for (int o = 1; o < p.G; o <<= 1) cnt += __shfl_xor(cnt, o);
-    if (valid && (lane & (p.G - 1)) == 0 && cnt) atomicAdd(&s_head[h], cnt);
   }
+  // entries each kept pixel will emit: min(v_end - v_start, max_k), accumulated per head.  Only kept pixels
+  // are visited (a row keeps ~K_t << H*T_m of them once t is large).
+#if SEA_EXP != 2
+  {
+    unsigned long long m = sel;
+    while (m) {
+      const int i = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const int f = ((i >> 2) * TK_THREADS + tid) * 4 + (i & 3);
+      const int h = f / p.T_m, b = f - h * p.T_m;
+      int w = (int)(interp_bound(b + 1, scale) - interp_bound(b, scale));
+      w = w < p.max_k ? w : p.max_k;
+      if (w > 0) atomicAdd(&s_head[h], w);
+    }
+  }
+#endif
   __syncthreads();
+  STAMP(4);   // bit mask + widths + head counts
   // exclusive scan over heads (first wave, 64 heads per step)
   if (wv == 0) {
     int carry = 0;
@@ -440,12 +555,19 @@ template <typename T, bool FROM_MASK>
 static int launch_select(const TopkParams& p, int64_t rows, hipStream_t s) {
   const int ept = ((p.nchunks + TK_THREADS - 1) / TK_THREADS) * 4;
   dim3 grid((unsigned)rows), block(TK_THREADS);
-  if (ept <= 4) hipLaunchKernelGGL((topk_select_kernel<T, 4, FROM_MASK>), grid, block, 0, s, p);
-  else if (ept <= 8) hipLaunchKernelGGL((topk_select_kernel<T, 8, FROM_MASK>), grid, block, 0, s, p);
-  else if (ept <= 16) hipLaunchKernelGGL((topk_select_kernel<T, 16, FROM_MASK>), grid, block, 0, s, p);
-  else if (ept <= 32) hipLaunchKernelGGL((topk_select_kernel<T, 32, FROM_MASK>), grid, block, 0, s, p);
-  else if (ept <= 40) hipLaunchKernelGGL((topk_select_kernel<T, 40, FROM_MASK>), grid, block, 0, s, p);
-  else hipLaunchKernelGGL((topk_select_kernel<T, 64, FROM_MASK>), grid, block, 0, s, p);
+#define SEA_SEL(E)                                                                                      \
+  do {                                                                                                  \
+    const bool full = p.nchunks == ((E) / 4) * TK_THREADS; /* every register slot of THIS instantiation is live */ \
+    if (full) hipLaunchKernelGGL((topk_select_kernel<T, E, FROM_MASK, true>), grid, block, 0, s, p);   \
+    else hipLaunchKernelGGL((topk_select_kernel<T, E, FROM_MASK, false>), grid, block, 0, s, p);       \
+  } while (0)
+  if (ept <= 4) SEA_SEL(4);
+  else if (ept <= 8) SEA_SEL(8);
+  else if (ept <= 16) SEA_SEL(16);
+  else if (ept <= 32) SEA_SEL(32);
+  else if (ept <= 40) SEA_SEL(40);
+  else SEA_SEL(64);
+#undef SEA_SEL
   return 0;
 }
 
@@ -483,6 +605,15 @@ static int select_common(const char* name, const void* src, int dtype, int64_t N
 }  // namespace sea
 
 using namespace sea;
+
+#ifdef SEA_STAMP
+extern "C" int sea_debug_stamps(unsigned long long* host16) {
+  hipMemcpyFromSymbol(host16, HIP_SYMBOL(sea_dbg), sizeof(unsigned long long) * 16);
+  unsigned long long z[16] = {0};
+  hipMemcpyToSymbol(HIP_SYMBOL(sea_dbg), z, sizeof(z));
+  return 0;
+}
+#endif
 
 extern "C" int sea_topk_select(const void* probs, int dtype, int64_t N, int64_t H, int64_t T_dst, int64_t T_m,
                                int64_t stride_n, int64_t stride_h, int64_t stride_t, const int32_t* keep,

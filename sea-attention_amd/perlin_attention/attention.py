@@ -249,7 +249,12 @@ class PerlinAttention(nn.Module):
                     if query_skips > 1:
                         assert (x.shape[-2] % query_skips) == 0
                         x = x[:, :, ::query_skips, :]
-                    t_attention_predictor = self.attention_predictor_enc(x)
+                    if self._hip_estimator_ok(x) and x.shape[-1] * 2 // 3 <= (256 if x.dtype == torch.float32 else 512):
+                        enc = self.attention_predictor_enc                      # Linear -> [LayerNorm + GELU fused in HIP]
+                        t_attention_predictor = ops.split_layernorm(enc[0](x), 1, enc[1].weight, enc[1].bias,
+                                                                    enc[1].eps, gelu=True)
+                    else:
+                        t_attention_predictor = self.attention_predictor_enc(x)
             # HIP fast path for the bandwidth-bound estimator pieces: device tensors, no autograd, and the
             # standard causal predictor layout (ChannelSplit+LN, ..., upsample x4, 1x1 conv pad 1, LN, softmax)
             use_hip = self._hip_estimator_ok(t_attention_predictor)

@@ -13,9 +13,10 @@ def _p(t):
     return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
 
 
-def split_layernorm(x: torch.Tensor, splits: int, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5):
-    """ChannelSplit(splits) followed by LayerNorm over the new (narrower) last dim.
-    x (N,C,T,splits*W) -> (N,C*splits,T,W)."""
+def split_layernorm(x: torch.Tensor, splits: int, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5,
+                    gelu: bool = False):
+    """ChannelSplit(splits) followed by LayerNorm over the new (narrower) last dim, optionally followed by
+    the exact (erf) GELU.  x (N,C,T,splits*W) -> (N,C*splits,T,W).  splits=1 is a plain row LayerNorm."""
     lib = _lib.load()
     _lib.require_gpu(x, weight, bias)
     N, C, T, SW = x.shape
@@ -26,7 +27,7 @@ def split_layernorm(x: torch.Tensor, splits: int, weight: torch.Tensor, bias: to
     b = bias.to(x.dtype).contiguous()
     out = torch.empty((N, C * splits, T, W), dtype=x.dtype, device=x.device)
     _lib.check(lib.sea_split_layernorm(_p(x), _lib.dtype_code(x.dtype), N, C, T, splits, W, _p(w), _p(b), float(eps),
-                                       _p(out), _lib.stream_ptr()), "sea_split_layernorm")
+                                       int(gelu), _p(out), _lib.stream_ptr()), "sea_split_layernorm")
     return out
 
 

@@ -69,6 +69,27 @@ def test_topk_low_precision_probs_and_ties(ops, dtype):
     assert torch.equal(got2.cpu(), ref2)
 
 
+@pytest.mark.parametrize("levels", [1, 2, 4, 37])
+def test_topk_overfull_threshold_bin(ops, levels):
+    """Few distinct values over H*T_m = 8192 pixels: the threshold bin holds thousands of equal keys, which
+    forces the multi-pass fallback and the ordered tie scan of the select kernel."""
+    N, H, T, T_M, k = 1, 32, 96, 256, 64
+    g = torch.Generator().manual_seed(11)
+    vals = torch.rand(levels, generator=g) + 0.01
+    probs = vals[torch.randint(0, levels, (N, H, T, T_M), generator=g)]
+    keep = O.keep_counts_module(H, T, T_M, k)
+    keep[40:] = torch.tensor([1, 2, 100, 1023, 1024, 1025, 3000, 5000] * 7)      # also ranks around the list capacity
+    ref = O.grouped_topk_mask(probs, keep)
+    got = ops.topk_mask(probs.to(DEV), keep.to(torch.int32).to(DEV), k)
+    assert torch.equal(got.cpu(), ref)
+    # negative values and signed zeros order like floats
+    x = torch.randn((1, 4, 33, 64), generator=g)
+    x[0, 0, :, :8] = 0.0
+    x[0, 1, :, :8] = -0.0
+    keep2 = torch.full((33,), 100, dtype=torch.int32)
+    assert torch.equal(ops.topk_mask(x.to(DEV), keep2.to(DEV), 4).cpu(), O.grouped_topk_mask(x, keep2))
+
+
 @pytest.mark.parametrize("T,T_M", [(4096, 256), (1000, 96), (130, 256), (8192, 256)])
 def test_interpolation_bounds_every_pixel(ops, T, T_M):
     """An all-ones mask exercises every (t, b) boundary: the kernel's fp32 bound arithmetic must equal the
