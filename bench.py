@@ -154,6 +154,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out, ctx = step()
+    t_enqueued = time.perf_counter() - t0                 # host time to enqueue all K steps (no sync inside)
     sync_all()
     elapsed = time.perf_counter() - t0
     regions = bench.todict()                              # seconds per call, from HIP events on the launch stream
@@ -236,6 +237,7 @@ def main():
                                    + (", + RCCL all-gather of context shards" if world > 1 else ""),
                        "global_batch": NB * world, "seq_len": T, "parallelism": f"dp{world} (batch shards)"},
             "roofline": roof, "cpu_baseline": cpu, "kernel_path": kernel_path,
+            "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 3),
             "regions_ms": {k_: round(v_ * 1e3, 4) for k_, v_ in sorted(regions.items())},
         }
         print(json.dumps(line))

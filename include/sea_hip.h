@@ -186,6 +186,18 @@ int sea_predictor_tail(const void* y, int dtype, int64_t N, int64_t C, int64_t H
 int sea_cumavg(const void* v, int dtype, int64_t N, int64_t H, int64_t T, int64_t D, const int64_t* v_strides,
                void* out, sea_stream_t stream);
 
+/* Causal Performer of SEA's estimator in one launch, fp32 MFMA:
+ *   phi(x) = relu(D^-1/4 x W^T) + 1e-3;  ctx_t = sum_{s<=t} (phi(q_t).phi(k_s)) V_s / (phi(q_t).(sum_{s<=t} phi(k_s) + 1e-6))
+ * with V = [pos | v] (the learned causal value embedding concatenated in front of v, attention.py:506-510).
+ * Replaces performer_pytorch.FastAttention(causal, generalized) as called at attention.py:556-572 plus the
+ * concatenations at :506-510 and :577-590.  q,k,v (N,H,T,D) of `dtype` (element strides [n,h,t]), pos (>=T, D)
+ * with row stride pos_stride, proj (nb, D) FP32.  out (N,H,T,3D) contiguous of `dtype` = [ctx_pos | ctx_v | v].
+ * Supported: D in {64,80,128}, nb <= 80 (48 for D=80 with 64-row chunks). */
+int sea_performer_causal(const void* q, const void* k, const void* v, const void* pos, int dtype,
+                         const float* proj, int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb,
+                         const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                         int64_t pos_stride, void* out, sea_stream_t stream);
+
 /* Algorithmic bytes of one sea_sparse_attention launch:
  * Z*(2*D*s + 4) + N*H*T_dst*(2*D*s + 4).  Host-side helper, no device work. */
 int64_t sea_sparse_attention_bytes(int64_t Z, int64_t N, int64_t H, int64_t T_dst, int64_t D, int elem_bytes);

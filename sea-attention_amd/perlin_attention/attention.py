@@ -220,22 +220,37 @@ class PerlinAttention(nn.Module):
     def _estimate(self, q, k, v, q_for_atten, k_for_atten, v_for_atten, dst_attention_mask, not_padded, T_SRC):
         """Steps A..G: value augmentation, Performer, predictor MLP + CNN, softmax over T_M."""
         bench = get_bench()
-        with timer("vmask"):
-            with timer("vmask.cat_fill"):
-                pos = self.v_eye_learned_causal[:, :, :T_SRC, :]
-                v_for_atten = torch.cat([pos.expand(v_for_atten.shape).to(v_for_atten.dtype), v_for_atten], dim=-1)
-                bench.register_temp_buffer('v_for_atten', v_for_atten)
-                if not not_padded:
-                    v_for_atten = v_for_atten.masked_fill(dst_attention_mask < -1, 0)
-                    v = v.masked_fill(dst_attention_mask < -1, 0)
-        with timer("performer"):
-            # the estimator always runs in fp32 (attention.py:520-534)
-            performer_context_layer = self.performer(q_for_atten.float(), k_for_atten.float(), v_for_atten.float())
-            performer_context_layer = performer_context_layer.to(q_for_atten.dtype)
-            bench.register_temp_buffer('performer_context_layer', performer_context_layer)
-        with timer("performer_value"):
-            performer_value = torch.cat([performer_context_layer, v], dim=-1)
-            bench.register_temp_buffer('performer_value', performer_value)
+        hip_perf = (self._hip_estimator_ok(q) and not_padded and q_for_atten.shape == v_for_atten.shape
+                    and ops.performer_supported(q.shape[-1], self.performer_nb_features)
+                    and T_SRC == q.shape[-2] and q_for_atten.dtype == k_for_atten.dtype == v_for_atten.dtype)
+        if hip_perf:
+            # value augmentation + Performer + concat with v: one fp32-MFMA kernel (csrc/sea_performer.hip)
+            with timer("performer"):
+                pos = self.v_eye_learned_causal[0, 0, :T_SRC, :]
+                performer_value = ops.performer_value(q_for_atten, k_for_atten, v_for_atten, pos,
+                                                      self.performer.projection_matrix)
+                D_ = q.shape[-1]
+                bench.register_temp_buffer('v_for_atten', None, lazy=lambda: torch.cat(
+                    [pos.expand(v_for_atten.shape).to(v_for_atten.dtype), v_for_atten], dim=-1))
+                bench.register_temp_buffer('performer_context_layer', performer_value[..., :2 * D_])
+                bench.register_temp_buffer('performer_value', performer_value)
+        else:
+            with timer("vmask"):
+                with timer("vmask.cat_fill"):
+                    pos = self.v_eye_learned_causal[:, :, :T_SRC, :]
+                    v_for_atten = torch.cat([pos.expand(v_for_atten.shape).to(v_for_atten.dtype), v_for_atten], dim=-1)
+                    bench.register_temp_buffer('v_for_atten', v_for_atten)
+                    if not not_padded:
+                        v_for_atten = v_for_atten.masked_fill(dst_attention_mask < -1, 0)
+                        v = v.masked_fill(dst_attention_mask < -1, 0)
+            with timer("performer"):
+                # the estimator always runs in fp32 (attention.py:520-534)
+                performer_context_layer = self.performer(q_for_atten.float(), k_for_atten.float(), v_for_atten.float())
+                performer_context_layer = performer_context_layer.to(q_for_atten.dtype)
+                bench.register_temp_buffer('performer_context_layer', performer_context_layer)
+            with timer("performer_value"):
+                performer_value = torch.cat([performer_context_layer, v], dim=-1)
+                bench.register_temp_buffer('performer_value', performer_value)
         with timer("predictor"):
             query_skips = int(os.environ.get('QUERY_SKIPS', '1'))
             with timer("predictor.enc"):

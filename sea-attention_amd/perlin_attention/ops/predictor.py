@@ -68,3 +68,32 @@ def cumavg(v: torch.Tensor) -> torch.Tensor:
     _lib.check(lib.sea_cumavg(_p(v), _lib.dtype_code(v.dtype), N, H, T, D, _lib.strides3(v), _p(out),
                               _lib.stream_ptr()), "sea_cumavg")
     return out
+
+
+def performer_supported(D: int, nb: int) -> bool:
+    """Shapes the fused Performer kernel is instantiated for (csrc/sea_performer.hip: dispatch_perf)."""
+    nbt = (nb + 15) // 16
+    return D in (64, 80, 128) and nbt <= 5
+
+
+def performer_value(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torch.Tensor,
+                    projection: torch.Tensor) -> torch.Tensor:
+    """Causal Performer estimator + both concatenations in one launch.
+    q,k,v (N,H,T,D); pos (>=T, D) = v_eye_learned_causal[0,0]; projection (nb, D).
+    Returns performer_value (N,H,T,3D) = [ctx(pos) | ctx(v) | v] in q's dtype."""
+    lib = _lib.load()
+    _lib.require_gpu(q, k, v, pos, projection)
+    N, H, T, D = q.shape
+    assert k.shape == q.shape and v.shape == q.shape and pos.shape[-1] == D and pos.shape[0] >= T
+    nb = projection.shape[0]
+    q, k, v = (t if t.stride(-1) == 1 else t.contiguous() for t in (q, k, v))
+    k = k if k.dtype == q.dtype else k.to(q.dtype)
+    v = v if v.dtype == q.dtype else v.to(q.dtype)
+    pos = pos.to(q.dtype)
+    pos = pos if pos.stride(-1) == 1 else pos.contiguous()
+    proj = projection.to(q.dtype).float().contiguous()     # the reference casts the buffer to the data dtype first
+    out = torch.empty((N, H, T, 3 * D), dtype=q.dtype, device=q.device)
+    _lib.check(lib.sea_performer_causal(_p(q), _p(k), _p(v), _p(pos), _lib.dtype_code(q.dtype), _p(proj), N, H, T, D, nb,
+                                        _lib.strides3(q), _lib.strides3(k), _lib.strides3(v), pos.stride(0), _p(out),
+                                        _lib.stream_ptr()), "sea_performer_causal")
+    return out

@@ -103,3 +103,37 @@ def test_module_hip_estimator_matches_torch_estimator():
                        ('estimated_attention_probs', 1e-6), ('average_context_layer', 1e-5)]:
         err = (b_hip[name].float() - b_torch[name].float()).abs().max().item()
         assert err <= atol, (name, err)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("N,H,T,D,nbf", [(1, 2, 256, 64, 8), (2, 3, 200, 64, 8), (1, 2, 130, 80, 8), (1, 2, 96, 128, 8),
+                                         (1, 1, 64, 64, 4), (1, 4, 1024, 64, 8)])
+def test_performer_value(ops, dtype, N, H, T, D, nbf):
+    """Fused Performer kernel vs the torch restatement (perlin_attention/performer.py) evaluated in fp32, and vs
+    the naive prefix-sum formula of the published algorithm."""
+    import math
+    from sea_attention_amd.perlin_attention.performer import FastAttention
+    torch.manual_seed(5)
+    nb = int(D * math.log(D) / nbf)
+    fa = FastAttention(D, nb_features=nb, causal=True, generalized_attention=True)
+    q = (torch.randn(N, H, T, D) * D ** -0.5).to(dtype)
+    k = torch.randn(N, H, T, D).to(dtype)
+    v = torch.randn(N, H, T, D).to(dtype)
+    pos = torch.randn(T + 7, D).to(dtype)
+    W = fa.projection_matrix.to(dtype).float()
+    vaug = torch.cat([pos[:T].float().expand(N, H, T, D), v.float()], -1)
+    qp = torch.relu(D ** -0.25 * q.float() @ W.t()) + 1e-3
+    kp = torch.relu(D ** -0.25 * k.float() @ W.t()) + 1e-3
+    ksum = kp.double().cumsum(-2) + 1e-6
+    ctx_cum = torch.einsum('...nd,...ne->...nde', kp.double(), vaug.double()).cumsum(-3)
+    ref = torch.einsum('...nde,...nd,...n->...ne', ctx_cum, qp.double(), 1.0 / torch.einsum('...nd,...nd->...n', qp.double(), ksum)).float()
+    out = ops.performer_value(q.to(DEV), k.to(DEV), v.to(DEV), pos.to(DEV), fa.projection_matrix.to(DEV))
+    assert out.dtype == dtype and tuple(out.shape) == (N, H, T, 3 * D)
+    assert torch.equal(out[..., 2 * D:].cpu(), v)                      # the concatenated copy of v is exact
+    ctx = out[..., :2 * D].float().cpu()
+    if dtype == torch.float32:
+        torch.testing.assert_close(ctx, ref, atol=2e-4, rtol=2e-4)
+        mine = fa(q, k, vaug)                                           # the package's torch path (chunked GEMMs)
+        torch.testing.assert_close(ctx, mine, atol=2e-4, rtol=2e-4)
+    else:
+        torch.testing.assert_close(ctx, ref, atol=3e-2, rtol=2e-2)
