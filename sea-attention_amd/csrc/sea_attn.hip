@@ -18,6 +18,7 @@
 // gathers are served by L2 when the workgroups of a head run on one XCD: blockIdx is remapped so
 // that the (n, h) pair index is congruent to the XCD label blockIdx % 8 (speed only).
 #include "sea_common.hpp"
+#include <stdlib.h>
 
 namespace sea {
 
@@ -41,6 +42,30 @@ template <int LPR> __device__ inline float group_sum(float x) {
   if (LPR >= 32) x += __shfl_xor(x, 16);
   if (LPR >= 64) x += __shfl_xor(x, 32);
   return x;
+}
+
+// q . k over one 16-byte lane fragment.  16-bit inputs use the packed dot-product instructions
+// (v_dot2c_f32_bf16 / v_dot2_f32_f16: exact products, fp32 accumulation) on the raw registers -- no unpacking.
+typedef __attribute__((ext_vector_type(2))) __bf16 sea_bf2;
+typedef __attribute__((ext_vector_type(2))) _Float16 sea_h2;
+template <typename T> __device__ inline float frag_dot(const uint4& q, const uint4& k);
+template <> __device__ inline float frag_dot<float>(const uint4& q, const uint4& k) {
+  float d = __uint_as_float(q.x) * __uint_as_float(k.x);
+  d = fmaf(__uint_as_float(q.y), __uint_as_float(k.y), d);
+  d = fmaf(__uint_as_float(q.z), __uint_as_float(k.z), d);
+  return fmaf(__uint_as_float(q.w), __uint_as_float(k.w), d);
+}
+template <> __device__ inline float frag_dot<__hip_bfloat16>(const uint4& q, const uint4& k) {
+  float d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(sea_bf2, q.x), __builtin_bit_cast(sea_bf2, k.x), 0.f, false);
+  d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(sea_bf2, q.y), __builtin_bit_cast(sea_bf2, k.y), d, false);
+  d = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(sea_bf2, q.z), __builtin_bit_cast(sea_bf2, k.z), d, false);
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(sea_bf2, q.w), __builtin_bit_cast(sea_bf2, k.w), d, false);
+}
+template <> __device__ inline float frag_dot<__half>(const uint4& q, const uint4& k) {
+  float d = __builtin_amdgcn_fdot2(__builtin_bit_cast(sea_h2, q.x), __builtin_bit_cast(sea_h2, k.x), 0.f, false);
+  d = __builtin_amdgcn_fdot2(__builtin_bit_cast(sea_h2, q.y), __builtin_bit_cast(sea_h2, k.y), d, false);
+  d = __builtin_amdgcn_fdot2(__builtin_bit_cast(sea_h2, q.z), __builtin_bit_cast(sea_h2, k.z), d, false);
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(sea_h2, q.w), __builtin_bit_cast(sea_h2, k.w), d, false);
 }
 
 struct AttnParams {
@@ -121,12 +146,8 @@ __global__ __launch_bounds__(256) void sparse_attn_kernel(AttnParams p) {
   const T* kb = reinterpret_cast<const T*>(p.k) + n * p.ks[0] + h * p.ks[1] + sub * VEC;
   const T* vb = reinterpret_cast<const T*>(p.v) + n * p.vs[0] + h * p.vs[1] + sub * VEC;
 
-  float qf[VEC];
-  {
-    uint4 r = make_uint4(0, 0, 0, 0);
-    if (dact) r = *reinterpret_cast<const uint4*>(qp);
-    unpack16<T>(r, qf);
-  }
+  uint4 qraw = make_uint4(0, 0, 0, 0);
+  if (dact) qraw = *reinterpret_cast<const uint4*>(qp);
   const int row_beg = p.crow[(int64_t)n * (p.T_dst + 1) + t];
   const int32_t* ho = p.head_off + ((int64_t)n * p.T_dst + t) * (p.H + 1);
   const int beg = row_beg + ho[h], end = row_beg + ho[h + 1];
@@ -157,11 +178,7 @@ __global__ __launch_bounds__(256) void sparse_attn_kernel(AttnParams p) {
     float mnew = m;
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      float kf[VEC];
-      unpack16<T>(kr[u], kf);
-      float d = 0.f;
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) d = fmaf(qf[j], kf[j], d);
+      float d = frag_dot<T>(qraw, kr[u]);
       d = group_sum<LPR>(d);
       s[u] = ok[u] ? d : -INFINITY;
       mnew = fmaxf(mnew, s[u]);
@@ -216,6 +233,114 @@ __global__ __launch_bounds__(256) void sparse_attn_kernel(AttnParams p) {
       for (int j = 0; j < VEC; ++j) o[j] = o[j] * a + (1.0f - a) * af[j];
     }
     TO* op = reinterpret_cast<TO*>(p.out) + n * p.os[0] + h * p.os[1] + t * p.os[2] + sub * VEC;
+    store_frag<TO, VEC>(op, o);
+  }
+}
+
+// ---- variant B: one LPR-lane GROUP per query row (64/LPR rows per wave) -----------------------------------
+// Each group walks its own row's entries, one key per instruction step, U keys in flight, with its own online
+// softmax; nothing is merged across groups.  A wave therefore has 64/LPR independent
+// (offsets -> col -> K/V) load chains in flight instead of one, which is what the wave-per-row mapping lacks.
+// Workgroup = 4 waves = 256/LPR consecutive query rows of one (n, h).
+template <typename T, typename TO, int LPR, int U>
+__global__ __launch_bounds__(256) void sparse_attn_rows_kernel(AttnParams p) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int RPW = 64 / LPR;       // rows per wave
+  constexpr int RPB = 4 * RPW;        // rows per workgroup
+  int pair, tb;
+  if (!map_block(p.N * p.H, p.TB, &pair, &tb)) return;
+  const int n = pair / p.H, h = pair - n * p.H;
+  const int lane = threadIdx.x & 63;
+  const int grp = lane / LPR, sub = lane - grp * LPR;
+  const int t = tb * RPB + (threadIdx.x >> 6) * RPW + grp;
+  const bool rowok = t < p.T_dst;
+  const bool dact = sub * VEC < p.D;
+  const int tt = rowok ? t : p.T_dst - 1;
+  const int sube = dact ? sub : 0;    // lanes beyond D re-read fragment 0 (their q fragment is zero)
+
+  // wave-uniform 64-bit bases + per-lane 32-bit byte offsets (launcher guarantees T_src*stride*sizeof(T) < 2^31)
+  const char* kbase = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.k) + n * p.ks[0] + h * p.ks[1]);
+  const char* vbase = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.v) + n * p.vs[0] + h * p.vs[1]);
+  const uint32_t kst = (uint32_t)p.ks[2] * (uint32_t)sizeof(T), vst = (uint32_t)p.vs[2] * (uint32_t)sizeof(T);
+  const uint32_t lane_off = (uint32_t)(sube * VEC) * (uint32_t)sizeof(T);
+
+  uint4 qraw = make_uint4(0, 0, 0, 0);
+  if (dact) qraw = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.q) + n * p.qs[0] + h * p.qs[1] +
+                                                  (int64_t)tt * p.qs[2] + sub * VEC);
+  const int row_beg = p.crow[(int64_t)n * (p.T_dst + 1) + tt];
+  const int32_t* ho = p.head_off + ((int64_t)n * p.T_dst + tt) * (p.H + 1);
+  const int beg = row_beg + ho[h];
+  const int end = rowok ? row_beg + ho[h + 1] : beg;
+  const int32_t* col = p.col + n * p.col_stride_n;
+  const int hcol = h * p.T_src;
+
+  float m = -INFINITY, l = 0.f;
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+
+  // longest row of the wave bounds the loop (rows of a wave are neighbours: similar lengths)
+  int zmax = end - beg;
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) zmax = max(zmax, __shfl_xor(zmax, o));
+  const int last = end - 1;
+
+  for (int i0 = 0; i0 < zmax; i0 += U) {
+    bool ok[U];
+    uint4 kr[U], vr[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int e = beg + i0 + u;
+      ok[u] = e < end;
+      // entries past the row's end re-read a valid entry and are masked by -inf below: no exec branches
+      const int ec = ok[u] ? e : (last >= beg ? last : 0);
+      const uint32_t key = (uint32_t)(col[ec] - hcol);
+      const uint32_t key_c = (end > beg) ? key : 0u;
+      kr[u] = *reinterpret_cast<const uint4*>(kbase + (__umul24(key_c, kst) + lane_off));
+      vr[u] = *reinterpret_cast<const uint4*>(vbase + (__umul24(key_c, vst) + lane_off));
+    }
+    float s[U];
+    float mnew = m;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float d = frag_dot<T>(qraw, kr[u]);
+      d = group_sum<LPR>(d);
+      s[u] = ok[u] ? d : -INFINITY;
+      mnew = fmaxf(mnew, s[u]);
+    }
+    const float msafe = (mnew == -INFINITY) ? 0.f : mnew;     // rows that have seen nothing yet: exp(-inf - 0) = 0
+    const float alpha = __expf(m - msafe);
+    l *= alpha;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] *= alpha;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float pu = __expf(s[u] - msafe);
+      float vf[VEC];
+      unpack16<T>(vr[u], vf);
+      l += pu;
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] = fmaf(pu, vf[j], acc[j]);
+    }
+    m = mnew;
+  }
+
+  if (rowok && dact) {
+    const int64_t ridx = ((int64_t)n * p.H + h) * p.T_dst + t;
+    float scale = (l > 0.f) ? (1.0f / l) : 0.f;
+    if (p.row_scale) scale *= p.row_scale[ridx];
+    float o[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o[j] = acc[j] * scale;
+    if (p.mix) {
+      const float a = p.mix[ridx];
+      const T* ap = reinterpret_cast<const T*>(p.avg) + n * p.as[0] + h * p.as[1] + (int64_t)t * p.as[2] + sub * VEC;
+      float af[VEC];
+      unpack16<T>(*reinterpret_cast<const uint4*>(ap), af);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) o[j] = o[j] * a + (1.0f - a) * af[j];
+    }
+    TO* op = reinterpret_cast<TO*>(p.out) + n * p.os[0] + h * p.os[1] + (int64_t)t * p.os[2] + sub * VEC;
     store_frag<TO, VEC>(op, o);
   }
 }
@@ -339,11 +464,35 @@ static int lanes_per_row(int D, int vec) {
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 static bool strides_ok(const int64_t* s, int vec) { return s[0] % vec == 0 && s[1] % vec == 0 && s[2] % vec == 0; }
 
+static int attn_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("SEA_ATTN_VARIANT");      // 0 = wave per row, 1 = lane-group per row (default)
+    v = e ? atoi(e) : 1;
+  }
+  return v;
+}
+
 template <typename T, typename TO>
-static int launch_attn(const AttnParams& p, hipStream_t s) {
+static int launch_attn(AttnParams p, hipStream_t s) {
   constexpr int VEC = Elem<T>::VEC;
   const int lpr = lanes_per_row(p.D, VEC);
   const int NH = p.N * p.H;
+  const int esz = (int)sizeof(T);
+  const bool small = p.T_src < (1 << 24) && p.ks[2] * esz < (1 << 24) && p.vs[2] * esz < (1 << 24) &&
+                     (int64_t)p.T_src * p.ks[2] * esz < (1ll << 31) && (int64_t)p.T_src * p.vs[2] * esz < (1ll << 31);
+  if (attn_variant() == 1 && lpr <= 16 && small) {
+    const int rpb = 4 * (64 / lpr);
+    p.TB = (p.T_dst + rpb - 1) / rpb;
+    const int64_t blocks = (int64_t)8 * ((NH + 7) / 8) * p.TB;
+    dim3 grid((unsigned)blocks), block(256);
+    switch (lpr) {
+      case 4: hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 4, 4>), grid, block, 0, s, p); break;
+      case 8: hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 8, 4>), grid, block, 0, s, p); break;
+      default: hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 16, 4>), grid, block, 0, s, p); break;
+    }
+    return SEA_OK;
+  }
   const int64_t blocks = (int64_t)8 * ((NH + 7) / 8) * p.TB;
   dim3 grid((unsigned)blocks), block(256);
   switch (lpr) {

@@ -13,6 +13,21 @@ def _p(t):
     return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
 
 
+_prep_cache = {}
+
+
+def _cached(tag, tensors, dtype, build):
+    """Small per-call re-layouts of constant weights (inference): cached on (storage, version, dtype)."""
+    key = (tag, dtype) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+    hit = _prep_cache.get(key)
+    if hit is None:
+        if len(_prep_cache) > 256:
+            _prep_cache.clear()
+        hit = build()
+        _prep_cache[key] = hit
+    return hit
+
+
 def split_layernorm(x: torch.Tensor, splits: int, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5,
                     gelu: bool = False):
     """ChannelSplit(splits) followed by LayerNorm over the new (narrower) last dim, optionally followed by
@@ -23,8 +38,7 @@ def split_layernorm(x: torch.Tensor, splits: int, weight: torch.Tensor, bias: to
     assert SW % splits == 0
     W = SW // splits
     x = x.contiguous()
-    w = weight.to(x.dtype).contiguous()
-    b = bias.to(x.dtype).contiguous()
+    w, b = _cached("ln", (weight, bias), x.dtype, lambda: (weight.to(x.dtype).contiguous(), bias.to(x.dtype).contiguous()))
     out = torch.empty((N, C * splits, T, W), dtype=x.dtype, device=x.device)
     _lib.check(lib.sea_split_layernorm(_p(x), _lib.dtype_code(x.dtype), N, C, T, splits, W, _p(w), _p(b), float(eps),
                                        int(gelu), _p(out), _lib.stream_ptr()), "sea_split_layernorm")
@@ -44,11 +58,14 @@ def predictor_tail(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.Tensor, 
         y = y.contiguous()
     dt = y.dtype
     Hpad = (H + 7) // 8 * 8
-    cw = torch.zeros((C, Hpad), dtype=torch.float32, device=y.device)     # transposed, head axis padded: scalar-cache reads
-    cw[:, :H] = conv_w.to(dt).float().t()
-    cb = torch.zeros((Hpad,), dtype=torch.float32, device=y.device)
-    cb[:H] = conv_b.to(dt).float()
-    g, b = ln_w.to(dt).contiguous(), ln_b.to(dt).contiguous()
+
+    def build():
+        cw = torch.zeros((C, Hpad), dtype=torch.float32, device=y.device)  # transposed, head axis padded: scalar-cache reads
+        cw[:, :H] = conv_w.to(dt).float().t()
+        cb = torch.zeros((Hpad,), dtype=torch.float32, device=y.device)
+        cb[:H] = conv_b.to(dt).float()
+        return cw, cb, ln_w.to(dt).contiguous(), ln_b.to(dt).contiguous()
+    cw, cb, g, b = _cached("tail", (conv_w, conv_b, ln_w, ln_b), dt, build)
     probs = torch.empty((N, H, T, T_m), dtype=dt, device=y.device)
     scores = torch.empty_like(probs) if want_scores else None
     _lib.check(lib.sea_predictor_tail(_p(y), _lib.dtype_code(dt), N, C, H, T, W4, up, T_m, _lib.strides3(y),
@@ -89,9 +106,10 @@ def performer_value(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torc
     q, k, v = (t if t.stride(-1) == 1 else t.contiguous() for t in (q, k, v))
     k = k if k.dtype == q.dtype else k.to(q.dtype)
     v = v if v.dtype == q.dtype else v.to(q.dtype)
-    pos = pos.to(q.dtype)
+    pos = pos if pos.dtype == q.dtype else pos.to(q.dtype)
     pos = pos if pos.stride(-1) == 1 else pos.contiguous()
-    proj = projection.to(q.dtype).float().contiguous()     # the reference casts the buffer to the data dtype first
+    # the reference casts the projection buffer to the data dtype before using it
+    proj = _cached("proj", (projection,), q.dtype, lambda: projection.to(q.dtype).float().contiguous())
     out = torch.empty((N, H, T, 3 * D), dtype=q.dtype, device=q.device)
     _lib.check(lib.sea_performer_causal(_p(q), _p(k), _p(v), _p(pos), _lib.dtype_code(q.dtype), _p(proj), N, H, T, D, nb,
                                         _lib.strides3(q), _lib.strides3(k), _lib.strides3(v), pos.stride(0), _p(out),
