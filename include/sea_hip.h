@@ -171,7 +171,7 @@ int sea_split_layernorm(const void* x, int dtype, int64_t N, int64_t C, int64_t 
  * on the width) + area resize (T_m+2 -> T_m) + LayerNorm(T_m) + softmax(T_m).
  * Replaces cnn.keepres.upsam / conv4 / the KeepRes resize / cnn.lnorm2 (attention.py:271-281,
  * modules.py:42-55,77-92) and the softmax of attention.py:670-673.
- * y (N,C,T,W4) of `dtype` with element strides y_strides[n,c,t] (pixel stride 1);
+ * y (N,C,T,W4) of `dtype` with element strides y_strides[n,c,t,w]: unit stride along w (NCHW) or along c (NHWC);
  * conv_wT (C, Hpad) FP32 = the conv weight transposed with the head axis zero-padded to Hpad = 8*ceil(H/8),
  * conv_b (Hpad) FP32 (both are read through the scalar cache); gamma/beta (T_m) of `dtype`;
  * probs and optional scores (pre-softmax) are (N,H,T,T_m) contiguous of `dtype`.
@@ -185,6 +185,20 @@ int sea_predictor_tail(const void* y, int dtype, int64_t N, int64_t C, int64_t H
  * Replaces `avg_v.cumsum(-2) / arange(1..T)` (attention.py:1220-1222).  out (N,H,T,D) contiguous. */
 int sea_cumavg(const void* v, int dtype, int64_t N, int64_t H, int64_t T, int64_t D, const int64_t* v_strides,
                void* out, sea_stream_t stream);
+
+/* Channels-last predictor CNN for 16-bit data.
+ * sea_split_layernorm_nhwc: as sea_split_layernorm (no activation) but the result is written channels-last,
+ *   out (N, T, W, C*S) -- the layout the conv kernel below consumes.
+ * sea_causal_conv_nhwc: y = act(conv2d(x) + bias), square kernel `ksize`, dilation `dilation`, zero padding
+ *   (ksize-1)*dilation rows on TOP only (causal along T, = CausalConv2d of modules.py:96-192 whose lower kernel
+ *   rows are masked) and pad_w columns on both sides (width preserving).  x (N,T,W,Cin), y (N,T,W,Cout) NHWC;
+ *   w_packed (Cout, ksize*ksize*CinP) 16-bit = weight[co, ci, i, j] laid out [co][i*ksize+j][ci], ci zero-padded to
+ *   CinP (multiple of 32); bias (Cout) FP32; relu != 0 fuses the ReLU that follows conv1/conv2 (attention.py:271-276). */
+int sea_split_layernorm_nhwc(const void* x, int dtype, int64_t N, int64_t C, int64_t T, int64_t S, int64_t W,
+                             const void* gamma, const void* beta, float eps, void* out, sea_stream_t stream);
+int sea_causal_conv_nhwc(const void* x, int dtype, int64_t N, int64_t T, int64_t W, int64_t Cin, int64_t Cout,
+                         const void* w_packed, int64_t CinP, const float* bias, int ksize, int dilation, int pad_w,
+                         int relu, void* y, sea_stream_t stream);
 
 /* Causal Performer of SEA's estimator in one launch, fp32 MFMA:
  *   phi(x) = relu(D^-1/4 x W^T) + 1e-3;  ctx_t = sum_{s<=t} (phi(q_t).phi(k_s)) V_s / (phi(q_t).(sum_{s<=t} phi(k_s) + 1e-6))

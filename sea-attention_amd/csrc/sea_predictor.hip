@@ -106,7 +106,7 @@ struct TailParams {
   void* scores;      // optional (N, H, T, T_M)
   float eps;
   int N, C, H, T, W4, UP, T_M;
-  int64_t ys_n, ys_c, ys_t;  // element strides of y
+  int64_t ys_n, ys_c, ys_t, ys_w;  // element strides of y (NCHW: ys_w == 1; channels-last: ys_c == 1)
 };
 
 template <typename T, int E> __device__ inline void store_run(T* dst, const float* f, int j0, int T_M) {
@@ -136,8 +136,9 @@ __global__ __launch_bounds__(256) void predictor_tail_kernel(TailParams p) {
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int CW = p.C * p.W4;
-  float* s_y = reinterpret_cast<float*>(smem);                        // C x W4
-  float* s_z = s_y + CW + wv * (HB * p.W4);                           // per-wave HB x W4
+  const int LDY = p.W4 + 1;                                            // padded row stride of the y tile
+  float* s_y = reinterpret_cast<float*>(smem);                        // C x LDY
+  float* s_z = s_y + p.C * LDY + wv * (HB * p.W4);                    // per-wave HB x W4
   const float* __restrict__ wT = reinterpret_cast<const float*>(p.w4); // (C, Hpad) fp32, transposed
   const float* __restrict__ bF = reinterpret_cast<const float*>(p.b4); // (Hpad) fp32
   const int Hpad = ((p.H + HB - 1) / HB) * HB;
@@ -148,14 +149,25 @@ __global__ __launch_bounds__(256) void predictor_tail_kernel(TailParams p) {
   // ---- stage y[n, :, t, :] (C x W4) as fp32, 16-byte loads -----------------------------------------------
   {
     const T* yb = reinterpret_cast<const T*>(p.y) + n * p.ys_n + t * p.ys_t;
-    const int cpr = p.W4 / VEC;  // chunks per channel row
-    for (int ch = threadIdx.x; ch < CW / VEC; ch += 256) {
-      const int c = ch / cpr, w = (ch - c * cpr) * VEC;
-      float f[VEC];
-      unpack16<T>(*reinterpret_cast<const uint4*>(yb + c * p.ys_c + w), f);
-      float* dst = s_y + c * p.W4 + w;
+    if (p.ys_w == 1) {                            // NCHW: vectors run along the width
+      const int cpr = p.W4 / VEC;
+      for (int ch = threadIdx.x; ch < CW / VEC; ch += 256) {
+        const int c = ch / cpr, w = (ch - c * cpr) * VEC;
+        float f[VEC];
+        unpack16<T>(*reinterpret_cast<const uint4*>(yb + c * p.ys_c + w), f);
+        float* dst = s_y + c * LDY + w;
 #pragma unroll
-      for (int j = 0; j < VEC; j += 4) *reinterpret_cast<float4*>(dst + j) = make_float4(f[j], f[j + 1], f[j + 2], f[j + 3]);
+        for (int j = 0; j < VEC; ++j) dst[j] = f[j];
+      }
+    } else {                                      // channels-last: vectors run along the channels
+      const int cpp = p.C / VEC;
+      for (int ch = threadIdx.x; ch < CW / VEC; ch += 256) {
+        const int w = ch / cpp, c = (ch - w * cpp) * VEC;
+        float f[VEC];
+        unpack16<T>(*reinterpret_cast<const uint4*>(yb + (int64_t)w * p.ys_w + c), f);
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) s_y[(c + j) * LDY + w] = f[j];
+      }
     }
   }
 
@@ -200,7 +212,7 @@ __global__ __launch_bounds__(256) void predictor_tail_kernel(TailParams p) {
         const float* wp = wT + h0;
 #pragma unroll 4
         for (int c = 0; c < p.C; ++c) {
-          const float yv = s_y[c * p.W4 + w];
+          const float yv = s_y[c * LDY + w];
           const float4 wa = *reinterpret_cast<const float4*>(wp + (int64_t)c * Hpad);
           const float4 wb = *reinterpret_cast<const float4*>(wp + (int64_t)c * Hpad + 4);
           acc[0] = fmaf(wa.x, yv, acc[0]); acc[1] = fmaf(wa.y, yv, acc[1]);
@@ -384,15 +396,17 @@ extern "C" int sea_predictor_tail(const void* y, int dtype, int64_t N, int64_t C
   SEA_REQUIRE((((uintptr_t)probs | (uintptr_t)scores) & 15) == 0 && T_m % 4 == 0, SEA_EUNSUPPORTED,
               "%s: outputs must be 16-byte aligned", nm);
   const int vec = dtype == SEA_F32 ? 4 : 8;
-  SEA_REQUIRE(W4 % vec == 0 && y_strides[0] % vec == 0 && y_strides[1] % vec == 0 && y_strides[2] % vec == 0 &&
-                  ((uintptr_t)y & 15) == 0 && ((uintptr_t)conv_w & 15) == 0,
-              SEA_EUNSUPPORTED, "%s: y rows must be 16-byte aligned (W4 %% %d == 0)", nm, vec);
-  const size_t lds = (size_t)(C * W4 + 4 * 8 * W4) * sizeof(float);
+  const bool nchw = y_strides[3] == 1, nhwc = y_strides[1] == 1;
+  SEA_REQUIRE(nchw || nhwc, SEA_EUNSUPPORTED, "%s: y must have unit stride along the width (NCHW) or the channels (NHWC)", nm);
+  SEA_REQUIRE((nchw ? (W4 % vec == 0 && y_strides[1] % vec == 0) : (C % vec == 0 && y_strides[3] % vec == 0)) &&
+                  y_strides[0] % vec == 0 && y_strides[2] % vec == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)conv_w & 15) == 0,
+              SEA_EUNSUPPORTED, "%s: y vectors must be 16-byte aligned", nm);
+  const size_t lds = (size_t)(C * (W4 + 1) + 4 * 8 * W4) * sizeof(float);
   SEA_REQUIRE(lds <= 160 * 1024, SEA_EUNSUPPORTED, "%s: needs %zu B of LDS", nm, lds);
   TailParams p;
   p.y = y; p.w4 = conv_w; p.b4 = conv_b; p.gamma = gamma; p.beta = beta; p.probs = probs; p.scores = scores; p.eps = eps;
   p.N = (int)N; p.C = (int)C; p.H = (int)H; p.T = (int)T; p.W4 = (int)W4; p.UP = (int)up; p.T_M = (int)T_m;
-  p.ys_n = y_strides[0]; p.ys_c = y_strides[1]; p.ys_t = y_strides[2];
+  p.ys_n = y_strides[0]; p.ys_c = y_strides[1]; p.ys_t = y_strides[2]; p.ys_w = y_strides[3];
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)(N * T));
   int rc;

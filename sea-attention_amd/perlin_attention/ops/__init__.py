@@ -9,4 +9,5 @@ from .flat_csr import flat_csr_to_dense
 # fused MI355X entry points (not in the reference)
 from .flat_csr import (FlatCSR, topk_to_csr, topk_mask, sparse_attention, sparse_attention_bytes,
                        keep_table_causal, keep_table_kernel_test, z_capacity)
-from .predictor import split_layernorm, predictor_tail, cumavg, performer_value, performer_supported
+from .predictor import (split_layernorm, predictor_tail, cumavg, performer_value, performer_supported,
+                        split_layernorm_nhwc, causal_conv_nhwc, pack_conv_weight)

@@ -54,7 +54,7 @@ def predictor_tail(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.Tensor, 
     N, C, T, W4 = y.shape
     H = conv_w.shape[0]
     assert conv_w.shape == (H, C) and W4 * up == T_m
-    if y.stride(-1) != 1:
+    if y.stride(-1) != 1 and y.stride(1) != 1:
         y = y.contiguous()
     dt = y.dtype
     Hpad = (H + 7) // 8 * 8
@@ -68,7 +68,7 @@ def predictor_tail(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.Tensor, 
     cw, cb, g, b = _cached("tail", (conv_w, conv_b, ln_w, ln_b), dt, build)
     probs = torch.empty((N, H, T, T_m), dtype=dt, device=y.device)
     scores = torch.empty_like(probs) if want_scores else None
-    _lib.check(lib.sea_predictor_tail(_p(y), _lib.dtype_code(dt), N, C, H, T, W4, up, T_m, _lib.strides3(y),
+    _lib.check(lib.sea_predictor_tail(_p(y), _lib.dtype_code(dt), N, C, H, T, W4, up, T_m, _lib.strides4(y),
                                       _p(cw), _p(cb), _p(g), _p(b), float(eps), _p(probs), _p(scores),
                                       _lib.stream_ptr()), "sea_predictor_tail")
     return probs, scores
@@ -115,3 +115,47 @@ def performer_value(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torc
                                         _lib.strides3(q), _lib.strides3(k), _lib.strides3(v), pos.stride(0), _p(out),
                                         _lib.stream_ptr()), "sea_performer_causal")
     return out
+
+
+def split_layernorm_nhwc(x: torch.Tensor, splits: int, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5):
+    """ChannelSplit + LayerNorm writing channels-last: returns a tensor of logical shape (N, C*splits, T, W) whose
+    memory is (N, T, W, C*splits) (torch.channels_last strides).  16-bit dtypes only."""
+    lib = _lib.load()
+    _lib.require_gpu(x, weight, bias)
+    N, C, T, SW = x.shape
+    W = SW // splits
+    x = x.contiguous()
+    w, b = _cached("ln", (weight, bias), x.dtype, lambda: (weight.to(x.dtype).contiguous(), bias.to(x.dtype).contiguous()))
+    out = torch.empty((N, T, W, C * splits), dtype=x.dtype, device=x.device)
+    _lib.check(lib.sea_split_layernorm_nhwc(_p(x), _lib.dtype_code(x.dtype), N, C, T, splits, W, _p(w), _p(b), float(eps),
+                                            _p(out), _lib.stream_ptr()), "sea_split_layernorm_nhwc")
+    return out.permute(0, 3, 1, 2)
+
+
+def pack_conv_weight(weight: torch.Tensor, ksize: int, dtype: torch.dtype):
+    """(Cout, Cin, >=ksize, ksize) -> (Cout, ksize*ksize*CinP) laid out [co][tap][ci], ci zero-padded to a multiple
+    of 32.  Only the first `ksize` kernel rows are live for the causal conv (modules.py:113-121)."""
+    Cout, Cin = weight.shape[:2]
+    CinP = (Cin + 31) // 32 * 32
+    w = weight[:, :, :ksize, :].to(dtype).permute(0, 2, 3, 1)                  # (Cout, k, k, Cin)
+    packed = torch.zeros((Cout, ksize, ksize, CinP), dtype=dtype, device=weight.device)
+    packed[..., :Cin] = w
+    return packed.reshape(Cout, ksize * ksize * CinP).contiguous(), CinP
+
+
+def causal_conv_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, ksize: int, dilation: int, pad_w: int,
+                     relu: bool = True) -> torch.Tensor:
+    """Causal (along T) dilated conv + bias (+ReLU) on a channels-last tensor of logical shape (N, Cin, T, W).
+    `weight` is the module's (Cout, Cin, 2k-1, k) parameter.  Returns logical (N, Cout, T, W), channels-last memory."""
+    lib = _lib.load()
+    _lib.require_gpu(x, weight, bias)
+    N, Cin, T, W = x.shape
+    assert x.stride(1) == 1 and x.stride(3) == Cin and x.stride(2) == W * Cin, "input must be channels-last dense"
+    Cout = weight.shape[0]
+    (wp, CinP), bf = _cached("conv", (weight, bias), x.dtype,
+                             lambda: (pack_conv_weight(weight, ksize, x.dtype), bias.to(x.dtype).float().contiguous()))
+    y = torch.empty((N, T, W, Cout), dtype=x.dtype, device=x.device)
+    _lib.check(lib.sea_causal_conv_nhwc(_p(x), _lib.dtype_code(x.dtype), N, T, W, Cin, Cout, _p(wp), CinP, _p(bf),
+                                        int(ksize), int(dilation), int(pad_w), int(relu), _p(y), _lib.stream_ptr()),
+               "sea_causal_conv_nhwc")
+    return y.permute(0, 3, 1, 2)

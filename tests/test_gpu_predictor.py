@@ -137,3 +137,80 @@ def test_performer_value(ops, dtype, N, H, T, D, nbf):
         torch.testing.assert_close(ctx, mine, atol=2e-4, rtol=2e-4)
     else:
         torch.testing.assert_close(ctx, ref, atol=3e-2, rtol=2e-2)
+
+
+def _causal_conv_ref(x, weight, bias, k, dil, pad_w, relu):
+    """fp32 reference: CausalConv2d semantics (modules.py:96-192): live rows :k of the (2k-1) x k kernel, top padding."""
+    F = torch.nn.functional
+    y = F.conv2d(F.pad(x.float(), (0, 0, (k - 1) * dil, 0)), weight[:, :, :k, :].float(), bias.float(), 1, (0, pad_w), dil)
+    return torch.relu(y) if relu else y
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,Cin,Cout,T,W", [(2, 64, 64, 40, 64), (1, 24, 24, 33, 16), (1, 80, 80, 20, 64), (1, 64, 64, 9, 32),
+                                            (1, 32, 48, 17, 128)])
+def test_causal_conv_nhwc(ops, dtype, N, Cin, Cout, T, W):
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((N, Cin, T, W), generator=g).to(dtype)
+    wt = (torch.randn((Cout, Cin, 5, 3), generator=g) * (Cin * 9) ** -0.5).to(dtype)
+    b = (torch.randn(Cout, generator=g) * 0.1).to(dtype)
+    for relu in (True, False):
+        ref = _causal_conv_ref(x, wt, b, 3, 2, 2, relu)
+        xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
+        y = ops.causal_conv_nhwc(xd, wt.to(DEV), b.to(DEV), 3, 2, 2, relu=relu)
+        assert tuple(y.shape) == (N, Cout, T, W) and y.stride(1) == 1
+        torch.testing.assert_close(y.float().cpu(), ref, atol=2e-2, rtol=2e-2)
+    # causality along T: future rows do not leak
+    x2 = x.clone(); x2[:, :, T // 2:] += 50
+    y1 = ops.causal_conv_nhwc(x.to(DEV).contiguous(memory_format=torch.channels_last), wt.to(DEV), b.to(DEV), 3, 2, 2)
+    y2 = ops.causal_conv_nhwc(x2.to(DEV).contiguous(memory_format=torch.channels_last), wt.to(DEV), b.to(DEV), 3, 2, 2)
+    assert torch.equal(y1[:, :, :T // 2], y2[:, :, :T // 2])
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,C,T,S,W", [(2, 12, 40, 2, 16), (1, 32, 70, 2, 64), (1, 40, 9, 2, 64), (1, 4, 5, 2, 128)])
+def test_split_layernorm_nhwc(ops, dtype, N, C, T, S, W):
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn((N, C, T, S * W), generator=g) * 2 + 0.3).to(dtype)
+    w = (torch.rand(W, generator=g) + 0.5).to(dtype)
+    b = torch.randn(W, generator=g).to(dtype)
+    a = ops.split_layernorm(x.to(DEV), S, w.to(DEV), b.to(DEV), 1e-5)
+    c = ops.split_layernorm_nhwc(x.to(DEV), S, w.to(DEV), b.to(DEV), 1e-5)
+    assert tuple(c.shape) == tuple(a.shape) and c.stride(1) == 1
+    # same arithmetic, different layout; the two kernels may contract one FMA differently: <= 1 ulp of the 16-bit type
+    torch.testing.assert_close(a.float(), c.contiguous().float(), atol=1e-3, rtol=8e-3)
+    assert (a != c.contiguous()).float().mean().item() < 1e-3
+
+
+def test_predictor_tail_accepts_channels_last(ops):
+    g = torch.Generator().manual_seed(1)
+    N, H, T, T_M = 1, 32, 50, 256
+    C, W4 = 2 * H, T_M // 4
+    y = torch.relu(torch.randn((N, C, T, W4), generator=g)).bfloat16().to(DEV)
+    cw = (torch.randn((H, C), generator=g) * C ** -0.5).bfloat16().to(DEV)
+    cb = (torch.randn(H, generator=g) * 0.1).bfloat16().to(DEV)
+    lw = (torch.rand(T_M, generator=g) + 0.5).bfloat16().to(DEV); lb = torch.zeros(T_M).bfloat16().to(DEV)
+    p1, s1 = ops.predictor_tail(y, cw, cb, lw, lb, up=4, T_m=T_M, want_scores=True)
+    p2, s2 = ops.predictor_tail(y.contiguous(memory_format=torch.channels_last), cw, cb, lw, lb, up=4, T_m=T_M, want_scores=True)
+    assert torch.equal(p1, p2) and torch.equal(s1, s2)
+
+
+def test_module_bf16_hip_estimator_close_to_torch_estimator():
+    """bf16 layer: channels-last MFMA CNN + fused kernels vs the torch modules (which round every intermediate to bf16)."""
+    import sea_attention_amd as S
+    from test_gpu_module import make_layer, run, causal_mask
+    N, H, T, d, T_M, k = 1, 12, 512, 64, 256, 64
+    layer = make_layer(H, d, T_M, k, T, torch.bfloat16)
+    S.seed(9)
+    q = torch.randn((N, H, T, d), device=DEV).bfloat16()
+    mask = causal_mask(N, T, torch.bfloat16)
+    _, b_hip = run(layer, q * d ** -0.5, q.clone(), q.clone(), mask, True)
+    layer.attention.force_torch_estimator = True
+    try:
+        _, b_torch = run(layer, q * d ** -0.5, q.clone(), q.clone(), mask, True)
+    finally:
+        layer.attention.force_torch_estimator = False
+    for name, tol in [('performer_context_layer', 3e-2), ('t_attention_predictor', 6e-2), ('estimated_attention_score', 0.25)]:
+        a, b = b_hip[name].float(), b_torch[name].float()
+        rel = ((a - b).norm() / b.norm()).item()
+        assert rel < tol, (name, rel)
