@@ -98,25 +98,27 @@ constexpr int TK_CAND_CAP = 1024;  // threshold-bin keys resolved by direct rank
 // Slow path, rarely taken (massive ties / all-equal rows / overfull threshold bin): classic MSB radix passes
 // followed by an ordered tie scan.  It re-reads the row from memory in every pass instead of using the caller's
 // register-resident keys, so it adds nothing to the register budget of the hot path.
+// (scalars are passed by value: a reference to the kernel's parameter struct would make the compiler spill the
+// whole struct to per-lane scratch at kernel entry)
 template <typename T>
-__device__ __noinline__ unsigned long long select_multipass(const T* base, const TopkParams& p, int K, uint32_t umin,
-                                                            uint32_t umax, int rounds, int* s_hist, int* s_wave,
-                                                            int* s_bcast) {
+__device__ __noinline__ unsigned long long select_multipass(const T* base, int64_t sh, int T_m, int nchunks, int M, int K,
+                                                            uint32_t umin, uint32_t umax, int rounds, int* s_hist,
+                                                            int* s_wave, int* s_bcast) {
   const int tid = threadIdx.x;
   auto load_keys = [&](int j, uint32_t* k4) -> bool {
     const int c = j * TK_THREADS + tid;
-    if (c >= p.nchunks) { k4[0] = k4[1] = k4[2] = k4[3] = 0u; return false; }
+    if (c >= nchunks) { k4[0] = k4[1] = k4[2] = k4[3] = 0u; return false; }
     const int f0 = c * 4;
-    const int h = f0 / p.T_m, b0 = f0 - h * p.T_m;
+    const int h = f0 / T_m, b0 = f0 - h * T_m;
     float f[4];
-    load4<T>(base + h * p.sh + b0, f);
+    load4<T>(base + h * sh + b0, f);
     for (int e = 0; e < 4; ++e) k4[e] = f2key(f[e]);
     return true;
   };
   unsigned long long sel = 0;
   uint32_t prefix = umax;
   int bits_left = (umax == umin) ? 0 : (32 - __clz(umax ^ umin));
-  int kth = K, n_eq = p.M;
+  int kth = K, n_eq = M;
   while (bits_left > 0) {
     const int d = bits_left < 11 ? bits_left : 11;
     const int shift = bits_left - d;
@@ -184,6 +186,24 @@ __device__ __noinline__ unsigned long long select_multipass(const T* base, const
 }
 
 // FULL: H*T_m == 256*EPT, i.e. every register slot holds a real pixel (no validity tests on the hot path).
+// 64-bit variant (two packed counters)
+__device__ inline long long block_excl_scan64(long long v, long long* s_wave /*[TK_WAVES]*/, long long* total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  long long incl = wave_incl_scan(v);
+  if (lane == 63) s_wave[w] = incl;
+  __syncthreads();
+  long long base = 0, tot = 0;
+#pragma unroll
+  for (int i = 0; i < TK_WAVES; ++i) {
+    const long long x = s_wave[i];
+    if (i < w) base += x;
+    tot += x;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + incl - v;
+}
+
 template <typename T, int EPT, bool FROM_MASK, bool FULL>
 __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(TopkParams p) {
   constexpr int R = EPT / 4;  // chunk rounds
@@ -338,7 +358,7 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(TopkParams p) {
           sel |= nibx << (4 * j);
         }
       } else {
-        sel = select_multipass<T>(base, p, K, umin, umax, R, s_hist, s_wave, s_bcast);
+        sel = select_multipass<T>(base, p.sh, p.T_m, p.nchunks, p.M, K, umin, umax, R, s_hist, s_wave, s_bcast);
         for (int i = tid; i < p.H; i += TK_THREADS) s_head[i] = 0;
         __syncthreads();
       }
@@ -439,9 +459,18 @@ struct EmitParams {
   float* values_out;
 };
 
+// One workgroup per row.  The kept pixels of the row are first compacted, in order, into an LDS list
+// (pixel id, output offset); then groups of G lanes (G = next pow2 of the widest pixel of this row) expand one
+// pixel each, so a store instruction writes 256/G complete, adjacent runs: contiguous 4-byte stores instead of a
+// per-lane serial walk.  Rows are processed in chunks of 4096 pixels (128 bit-mask words).
+constexpr int EM_CHUNK_WORDS = 128;
+constexpr int EM_CHUNK_PIX = EM_CHUNK_WORDS * 32;
+
 template <typename I>
 __global__ __launch_bounds__(TK_THREADS) void csr_emit_kernel(EmitParams p) {
-  __shared__ int s_wave[TK_WAVES];
+  __shared__ long long s_wave[TK_WAVES];
+  __shared__ unsigned short s_pix[EM_CHUNK_PIX];      // pixel id relative to the chunk
+  __shared__ int s_off[EM_CHUNK_PIX + 1];             // output offset of the pixel inside the row
   const int tid = threadIdx.x;
   const int row = blockIdx.x;
   const int n = row / p.T_dst, t = row - n * p.T_dst;
@@ -454,51 +483,73 @@ __global__ __launch_bounds__(TK_THREADS) void csr_emit_kernel(EmitParams p) {
   const uint32_t* bits = p.bits + (int64_t)row * p.W;
   const int w_t = row_width(t, p.T_dst, p.T_src, p.is_causal);
   const float scale = interp_scale(w_t, p.T_m);
+  int wmax = (w_t + p.T_m - 1) / p.T_m;               // widest pixel of this row, after the max_k clamp
+  wmax = wmax < p.max_k ? wmax : p.max_k;
+  int G = 1;
+  while (G < wmax) G <<= 1;                           // lanes per pixel (<= 256: max_k is far below)
+  if (G > TK_THREADS) G = TK_THREADS;
 
-  int carry = 0;
-  for (int w0 = 0; w0 < p.W; w0 += TK_THREADS) {
-    const int wi = w0 + tid;
-    uint32_t word = wi < p.W ? bits[wi] : 0u;
-    // pass 1: entries produced by this thread's 32 pixels
-    int mine = 0;
+  int carry = 0;                                      // entries emitted by earlier chunks of this row
+  for (int w0 = 0; w0 < p.W; w0 += EM_CHUNK_WORDS) {
+    // ---- compaction: thread owns one 16-pixel half word --------------------------------------------------
+    const int wi = w0 + (tid >> 1);
+    uint32_t half = 0;
+    if (wi < p.W) half = (bits[wi] >> (16 * (tid & 1))) & 0xFFFFu;
+    const int fbase = (tid >> 1) * 32 + (tid & 1) * 16;    // first pixel of this half word, relative to the chunk
+    int npix = __popc(half), nent = 0;
     {
-      uint32_t m = word;
+      uint32_t m = half;
       while (m) {
         const int bit = __ffs(m) - 1;
         m &= m - 1;
-        const int f = wi * 32 + bit;
-        const int b = f % p.T_m;
-        int w = (int)(interp_bound(b + 1, scale) - interp_bound(b, scale));
-        mine += w < p.max_k ? w : p.max_k;
+        const int b = (w0 * 32 + fbase + bit) % p.T_m;
+        const int w = (int)(interp_bound(b + 1, scale) - interp_bound(b, scale));
+        nent += w < p.max_k ? w : p.max_k;
       }
     }
-    int total;
-    int off = carry + block_excl_scan(mine, s_wave, &total);
-    carry += total;
-    // pass 2: write them (keys descending inside a pixel, causal_resize_m_to_t.py:569)
-    uint32_t m = word;
-    while (m) {
-      const int bit = __ffs(m) - 1;
-      m &= m - 1;
-      const int f = wi * 32 + bit;
-      const int h = f / p.T_m, b = f - h * p.T_m;
-      const float vs = interp_bound(b, scale), ve = interp_bound(b + 1, scale);
-      const int width = (int)(ve - vs);
-      const int cnt = width < p.max_k ? width : p.max_k;
-      if (cnt <= 0) continue;
-      const float hbase = (float)(h * p.T_src);
-      const float rs = vs + hbase, re = ve + hbase;
-      const float step = __fdiv_rn(re - rs, (float)cnt);
-      const int64_t o = row_beg + off;
-      for (int i = 0; i < cnt; ++i) {
-        const float c = (re - (float)(int)__fmul_rn((float)i, step)) - 1.0f;
-        if (o + i < p.z_cap) {
-          col[o + i] = (I)c;
-          if (vals) vals[o + i] = 1.0f;
+    long long total;
+    const long long excl = block_excl_scan64(((long long)npix << 32) | (long long)nent, s_wave, &total);   // pixels | entries
+    {
+      int pos = (int)(excl >> 32), off = carry + (int)(excl & 0xFFFFFFFFll);
+      uint32_t m = half;
+      while (m) {
+        const int bit = __ffs(m) - 1;
+        m &= m - 1;
+        const int b = (w0 * 32 + fbase + bit) % p.T_m;
+        int w = (int)(interp_bound(b + 1, scale) - interp_bound(b, scale));
+        w = w < p.max_k ? w : p.max_k;
+        s_pix[pos] = (unsigned short)(fbase + bit);
+        s_off[pos] = off;
+        ++pos;
+        off += w;
+      }
+    }
+    const int S = (int)(total >> 32);
+    const int chunk_entries = (int)(total & 0xFFFFFFFFll);
+    if (tid == 0) s_off[S] = carry + chunk_entries;
+    __syncthreads();
+    // ---- expansion: G lanes per pixel, keys descending inside a pixel (causal_resize_m_to_t.py:569) -----------
+    const int j = tid & (G - 1);
+    for (int i = tid / G; i < S; i += TK_THREADS / G) {
+      const int f = w0 * 32 + (int)s_pix[i];
+      const int o = s_off[i];
+      const int cnt = s_off[i + 1] - o;
+      if (j < cnt) {
+        const int h = f / p.T_m, b = f - h * p.T_m;
+        const float vs = interp_bound(b, scale), ve = interp_bound(b + 1, scale);
+        const float hbase = (float)(h * p.T_src);
+        const float rs = vs + hbase, re = ve + hbase;
+        const float step = __fdiv_rn(re - rs, (float)cnt);
+        const float c = (re - (float)(int)__fmul_rn((float)j, step)) - 1.0f;
+        const int64_t dst = row_beg + o + j;
+        if (dst < p.z_cap) {
+          col[dst] = (I)c;
+          if (vals) vals[dst] = 1.0f;
         }
       }
-      off += cnt;
     }
+    carry += chunk_entries;
+    __syncthreads();
   }
 }
 
