@@ -174,11 +174,14 @@ int sea_split_layernorm(const void* x, int dtype, int64_t N, int64_t C, int64_t 
  * y (N,C,T,W4) of `dtype` with element strides y_strides[n,c,t,w]: unit stride along w (NCHW) or along c (NHWC);
  * conv_wT (C, Hpad) FP32 = the conv weight transposed with the head axis zero-padded to Hpad = 8*ceil(H/8),
  * conv_b (Hpad) FP32 (both are read through the scalar cache); gamma/beta (T_m) of `dtype`;
+ * conv_w16 (optional, may be NULL): (16*ceil(H/16), Cp) row-major copy of the weight in `dtype`, channels zero-padded
+ * to Cp (multiple of 32) -- with it, 16-bit channels-last input takes the MFMA variant of the kernel;
  * probs and optional scores (pre-softmax) are (N,H,T,T_m) contiguous of `dtype`.
  * Requires W4*up == T_m, T_m <= 512, W4 a multiple of the 16-byte vector width. */
 int sea_predictor_tail(const void* y, int dtype, int64_t N, int64_t C, int64_t H, int64_t T, int64_t W4,
                        int64_t up, int64_t T_m, const int64_t* y_strides,
-                       const void* conv_wT, const void* conv_b, const void* gamma, const void* beta, float eps,
+                       const void* conv_wT, const void* conv_b, const void* conv_w16, int64_t Cp,
+                       const void* gamma, const void* beta, float eps,
                        void* probs, void* scores, sea_stream_t stream);
 
 /* Causal cumulative average out[n,h,t,:] = sum_{s<=t} v[n,h,s,:] / (t+1), fp32 accumulation.

@@ -35,8 +35,8 @@ _SIGNATURES = {
                               ptr, ptr, i64, ptr, ptr, ptr, _i64p, ptr, ptr, c_int, _i64p, ptr], c_int),
     "sea_sparse_attention_bytes": ([i64, i64, i64, i64, i64, c_int], i64),
     "sea_split_layernorm": ([ptr, c_int, i64, i64, i64, i64, i64, ptr, ptr, ctypes.c_float, c_int, ptr, ptr], c_int),
-    "sea_predictor_tail": ([ptr, c_int, i64, i64, i64, i64, i64, i64, i64, _i64p, ptr, ptr, ptr, ptr, ctypes.c_float,
-                            ptr, ptr, ptr], c_int),
+    "sea_predictor_tail": ([ptr, c_int, i64, i64, i64, i64, i64, i64, i64, _i64p, ptr, ptr, ptr, i64, ptr, ptr,
+                            ctypes.c_float, ptr, ptr, ptr], c_int),
     "sea_cumavg": ([ptr, c_int, i64, i64, i64, i64, _i64p, ptr, ptr], c_int),
     "sea_split_layernorm_nhwc": ([ptr, c_int, i64, i64, i64, i64, i64, ptr, ptr, ctypes.c_float, ptr, ptr], c_int),
     "sea_causal_conv_nhwc": ([ptr, c_int, i64, i64, i64, i64, i64, ptr, i64, ptr, c_int, c_int, c_int, c_int, ptr, ptr], c_int),

@@ -13,6 +13,13 @@
 // upsampling, so the channel GEMM runs on the T_M/4-wide tensor, and everything after it happens on-chip.
 #include "sea_common.hpp"
 
+#ifdef SEA_STAMP
+__device__ unsigned long long sea_dbg_tail[8];
+#define TSTAMP(i) do { if (threadIdx.x == 0) { unsigned long long _t = __builtin_amdgcn_s_memtime(); atomicAdd(&sea_dbg_tail[i], _t - _tprev); _tprev = _t; } } while (0)
+#else
+#define TSTAMP(i) do {} while (0)
+#endif
+
 namespace sea {
 
 // ------------------------------------------------------------------------------------------------------
@@ -107,6 +114,8 @@ struct TailParams {
   float eps;
   int N, C, H, T, W4, UP, T_M;
   int64_t ys_n, ys_c, ys_t, ys_w;  // element strides of y (NCHW: ys_w == 1; channels-last: ys_c == 1)
+  const void* w16;   // MFMA variant: (HP16, Cp) 16-bit row-major copy of the conv weight, zero padded
+  int Cp;            // channels padded to a multiple of 32
 };
 
 template <typename T, int E> __device__ inline void store_run(T* dst, const float* f, int j0, int T_M) {
@@ -145,6 +154,9 @@ __global__ __launch_bounds__(256) void predictor_tail_kernel(TailParams p) {
 
   const int row = blockIdx.x;
   const int n = row / p.T, t = row - n * p.T;
+#ifdef SEA_STAMP
+  unsigned long long _tprev = __builtin_amdgcn_s_memtime();
+#endif
 
   // ---- stage y[n, :, t, :] (C x W4) as fp32, 16-byte loads -----------------------------------------------
   {
@@ -197,6 +209,7 @@ __global__ __launch_bounds__(256) void predictor_tail_kernel(TailParams p) {
   }
   const float invT = 1.0f / (float)p.T_M;
   __syncthreads();
+  TSTAMP(0);   // staging + per-lane constants
 
   const int hblocks = Hpad / HB;
   for (int it = 0; it * 4 < hblocks; ++it) {
@@ -225,6 +238,7 @@ __global__ __launch_bounds__(256) void predictor_tail_kernel(TailParams p) {
       }
     }
     __syncthreads();
+    TSTAMP(1);   // channel GEMM
     // ---- per head: area resize -> LayerNorm -> (scores) -> softmax -> probs -----------------------------------
     if (active) {
       for (int jh = 0; jh < HB && h0 + jh < p.H; ++jh) {
@@ -272,6 +286,124 @@ __global__ __launch_bounds__(256) void predictor_tail_kernel(TailParams p) {
       }
     }
     __syncthreads();
+    TSTAMP(2);   // resize + LN + softmax + stores
+  }
+}
+
+// MFMA variant of the predictor tail for channels-last 16-bit input: the 1x1 conv z = y W^T is
+// (W4 pixels x C) @ (C x H) on v_mfma_f32_16x16x32; A fragments (8 channels of a pixel = 16 B) come straight from
+// global memory, so there is no staging pass at all.  z lands in LDS as [head][pixel] (+ a bias slot and a zero
+// slot per row, which turn the padded / unused taps of the area resize into plain reads).
+typedef __attribute__((ext_vector_type(4))) float tf4;
+typedef __attribute__((ext_vector_type(8))) __bf16 tbf8;
+typedef __attribute__((ext_vector_type(8))) _Float16 th8;
+template <typename T> __device__ inline tf4 tail_mfma(const uint4& a, const uint4& b, tf4 c);
+template <> __device__ inline tf4 tail_mfma<__hip_bfloat16>(const uint4& a, const uint4& b, tf4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tbf8, a), __builtin_bit_cast(tbf8, b), c, 0, 0, 0);
+}
+template <> __device__ inline tf4 tail_mfma<__half>(const uint4& a, const uint4& b, tf4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(th8, a), __builtin_bit_cast(th8, b), c, 0, 0, 0);
+}
+
+template <typename T, int E>
+__global__ __launch_bounds__(256) void predictor_tail_mfma_kernel(TailParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int HP = ((p.H + 15) / 16) * 16;
+  const int LDZ = p.W4 + 3;                     // z row: W4 pixels, [W4] = bias, [W4+1] = 0 (odd stride: no bank aliasing)
+  float* s_z = reinterpret_cast<float*>(smem);  // HP x LDZ
+  const float* __restrict__ bF = reinterpret_cast<const float*>(p.b4);
+  const T* __restrict__ w16 = reinterpret_cast<const T*>(p.w16);
+  const int row = blockIdx.x;
+  const int n = row / p.T, t = row - n * p.T;
+  const T* yb = reinterpret_cast<const T*>(p.y) + n * p.ys_n + t * p.ys_t;
+
+  // ---- z = y W^T + b --------------------------------------------------------------------------------------
+  const int MT = (p.W4 + 15) / 16, NT = HP / 16, KC = p.Cp / 32;
+  for (int mt = wv; mt < MT; mt += 4) {
+    const int wpix = mt * 16 + li;
+    for (int nt = 0; nt < NT; ++nt) {
+      tf4 acc = tf4{0.f, 0.f, 0.f, 0.f};
+      for (int kc = 0; kc < KC; ++kc) {
+        const int ci = kc * 32 + 8 * lg;
+        uint4 a = make_uint4(0, 0, 0, 0);
+        if (ci < p.C && wpix < p.W4) a = *reinterpret_cast<const uint4*>(yb + (int64_t)wpix * p.ys_w + ci);
+        const uint4 b = *reinterpret_cast<const uint4*>(w16 + (nt * 16 + li) * p.Cp + ci);
+        acc = tail_mfma<T>(a, b, acc);
+      }
+      const int h = nt * 16 + li;                // C layout: col = li -> head, row = lg*4 + r -> pixel
+      const float bias = h < p.H ? bF[h] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int px = mt * 16 + lg * 4 + r;
+        if (px < p.W4) s_z[h * LDZ + px] = acc[r] + bias;
+      }
+    }
+  }
+  for (int h = threadIdx.x; h < HP; h += 256) { s_z[h * LDZ + p.W4] = h < p.H ? bF[h] : 0.f; s_z[h * LDZ + p.W4 + 1] = 0.f; }
+
+  // ---- per-lane constants of the area-resize / LayerNorm stage (as in the VALU variant) ---------------------
+  const int Wp = p.W4 * p.UP + 2;
+  const T* gam = reinterpret_cast<const T*>(p.gamma);
+  const T* bet = reinterpret_cast<const T*>(p.beta);
+  float g[E], be[E], rcnt[E];
+  int src[E][3];   // index into the z row: pixel, W4 (bias: zero-padded border) or W4+1 (unused tap)
+#pragma unroll
+  for (int e = 0; e < E; ++e) {
+    const int j = lane * E + e;
+    g[e] = 0.f; be[e] = 0.f; rcnt[e] = 0.f;
+    src[e][0] = src[e][1] = src[e][2] = p.W4 + 1;
+    if (j < p.T_M) {
+      g[e] = Elem<T>::to_f(gam[j]); be[e] = Elem<T>::to_f(bet[j]);
+      const int xs = (int)floorf((float)(j * Wp) / (float)p.T_M);
+      const int xe = (int)ceilf((float)((j + 1) * Wp) / (float)p.T_M);
+      rcnt[e] = 1.0f / (float)(xe - xs);
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int x = xs + k;
+        if (x < xe) src[e][k] = (x == 0 || x == Wp - 1) ? p.W4 : (x - 1) / p.UP;
+      }
+    }
+  }
+  const float invT = 1.0f / (float)p.T_M;
+  __syncthreads();
+
+  for (int h = wv; h < p.H; h += 4) {
+    const float* zr = s_z + h * LDZ;
+    float a[E];
+    float s1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      a[e] = (zr[src[e][0]] + zr[src[e][1]] + zr[src[e][2]]) * rcnt[e];
+      s1 += a[e];
+    }
+    const float mean = wave_sum(s1) * invT;
+    float s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (lane * E + e < p.T_M) { const float d = a[e] - mean; s2 += d * d; }
+    const float rstd = rsqrtf(wave_sum(s2) * invT + p.eps);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      a[e] = (a[e] - mean) * rstd * g[e] + be[e];
+      if (lane * E + e < p.T_M) mx = fmaxf(mx, a[e]);
+    }
+    mx = wave_max(mx);
+    const int64_t obase = (((int64_t)n * p.H + h) * p.T + t) * p.T_M;
+    if (p.scores) store_run<T, E>(reinterpret_cast<T*>(p.scores) + obase, a, lane * E, p.T_M);
+    float se = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      a[e] = (lane * E + e < p.T_M) ? __expf(a[e] - mx) : 0.f;
+      se += a[e];
+    }
+    const float inv = 1.0f / wave_sum(se);
+#pragma unroll
+    for (int e = 0; e < E; ++e) a[e] *= inv;
+    store_run<T, E>(reinterpret_cast<T*>(p.probs) + obase, a, lane * E, p.T_M);
   }
 }
 
@@ -366,6 +498,22 @@ extern "C" int sea_split_layernorm(const void* x, int dtype, int64_t N, int64_t 
 }
 
 template <typename T>
+static int launch_tail_mfma(const TailParams& p, dim3 grid, hipStream_t s) {
+  const int E = (p.T_M + 63) / 64;
+  const int HP = ((p.H + 15) / 16) * 16;
+  const size_t lds = (size_t)HP * (p.W4 + 3) * sizeof(float);
+  if (lds > 64 * 1024) return SEA_EUNSUPPORTED;
+#define SEA_TAILM(EE) hipLaunchKernelGGL((predictor_tail_mfma_kernel<T, EE>), grid, dim3(256), lds, s, p)
+  switch (E) {
+    case 1: SEA_TAILM(1); break; case 2: SEA_TAILM(2); break; case 3: SEA_TAILM(3); break; case 4: SEA_TAILM(4); break;
+    case 5: case 6: SEA_TAILM(6); break; case 7: case 8: SEA_TAILM(8); break;
+    default: return SEA_EUNSUPPORTED;
+  }
+#undef SEA_TAILM
+  return SEA_OK;
+}
+
+template <typename T>
 static int launch_tail(const TailParams& p, size_t lds, dim3 grid, hipStream_t s) {
   const int E = (p.T_M + 63) / 64;
 #define SEA_TAIL(EE)                                                                                         \
@@ -383,10 +531,19 @@ static int launch_tail(const TailParams& p, size_t lds, dim3 grid, hipStream_t s
   return SEA_OK;
 }
 
+#ifdef SEA_STAMP
+extern "C" int sea_debug_tail_stamps(unsigned long long* host8) {
+  (void)hipMemcpyFromSymbol(host8, HIP_SYMBOL(sea_dbg_tail), sizeof(unsigned long long) * 8);
+  unsigned long long z[8] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(sea_dbg_tail), z, sizeof(z));
+  return 0;
+}
+#endif
+
 extern "C" int sea_predictor_tail(const void* y, int dtype, int64_t N, int64_t C, int64_t H, int64_t T, int64_t W4,
                                   int64_t up, int64_t T_m, const int64_t* y_strides, const void* conv_w,
-                                  const void* conv_b, const void* gamma, const void* beta, float eps, void* probs,
-                                  void* scores, sea_stream_t stream) {
+                                  const void* conv_b, const void* conv_w16, int64_t Cp, const void* gamma,
+                                  const void* beta, float eps, void* probs, void* scores, sea_stream_t stream) {
   const char* nm = "sea_predictor_tail";
   SEA_REQUIRE(y && y_strides && conv_w && conv_b && gamma && beta && probs, SEA_EINVAL, "%s: null pointer", nm);
   SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_F16 || dtype == SEA_BF16, SEA_EINVAL, "%s: bad dtype %d", nm, dtype);
@@ -407,10 +564,14 @@ extern "C" int sea_predictor_tail(const void* y, int dtype, int64_t N, int64_t C
   p.y = y; p.w4 = conv_w; p.b4 = conv_b; p.gamma = gamma; p.beta = beta; p.probs = probs; p.scores = scores; p.eps = eps;
   p.N = (int)N; p.C = (int)C; p.H = (int)H; p.T = (int)T; p.W4 = (int)W4; p.UP = (int)up; p.T_M = (int)T_m;
   p.ys_n = y_strides[0]; p.ys_c = y_strides[1]; p.ys_t = y_strides[2]; p.ys_w = y_strides[3];
+  p.w16 = conv_w16; p.Cp = (int)Cp;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)(N * T));
   int rc;
-  if (dtype == SEA_F32) rc = launch_tail<float>(p, lds, grid, s);
+  const bool mfma = conv_w16 != nullptr && dtype != SEA_F32 && nhwc && !nchw && Cp % 32 == 0 && Cp >= C &&
+                    (((uintptr_t)conv_w16) & 15) == 0;
+  if (mfma) rc = dtype == SEA_F16 ? launch_tail_mfma<__half>(p, grid, s) : launch_tail_mfma<__hip_bfloat16>(p, grid, s);
+  else if (dtype == SEA_F32) rc = launch_tail<float>(p, lds, grid, s);
   else if (dtype == SEA_F16) rc = launch_tail<__half>(p, lds, grid, s);
   else rc = launch_tail<__hip_bfloat16>(p, lds, grid, s);
   SEA_REQUIRE(rc == SEA_OK, rc, "%s: unsupported T_m", nm);

@@ -64,12 +64,17 @@ def predictor_tail(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.Tensor, 
         cw[:, :H] = conv_w.to(dt).float().t()
         cb = torch.zeros((Hpad,), dtype=torch.float32, device=y.device)
         cb[:H] = conv_b.to(dt).float()
-        return cw, cb, ln_w.to(dt).contiguous(), ln_b.to(dt).contiguous()
-    cw, cb, g, b = _cached("tail", (conv_w, conv_b, ln_w, ln_b), dt, build)
+        w16, Cp = None, 0
+        if dt != torch.float32:                                           # row-major 16-bit copy for the MFMA variant
+            Cp, HP = (C + 31) // 32 * 32, (H + 15) // 16 * 16
+            w16 = torch.zeros((HP, Cp), dtype=dt, device=y.device)
+            w16[:H, :C] = conv_w.to(dt)
+        return cw, cb, ln_w.to(dt).contiguous(), ln_b.to(dt).contiguous(), w16, Cp
+    cw, cb, g, b, w16, Cp = _cached("tail", (conv_w, conv_b, ln_w, ln_b), dt, build)
     probs = torch.empty((N, H, T, T_m), dtype=dt, device=y.device)
     scores = torch.empty_like(probs) if want_scores else None
     _lib.check(lib.sea_predictor_tail(_p(y), _lib.dtype_code(dt), N, C, H, T, W4, up, T_m, _lib.strides4(y),
-                                      _p(cw), _p(cb), _p(g), _p(b), float(eps), _p(probs), _p(scores),
+                                      _p(cw), _p(cb), _p(w16), Cp, _p(g), _p(b), float(eps), _p(probs), _p(scores),
                                       _lib.stream_ptr()), "sea_predictor_tail")
     return probs, scores
 

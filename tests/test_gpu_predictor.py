@@ -41,10 +41,11 @@ def test_split_layernorm(ops, dtype, N, C, T, S, W):
         torch.testing.assert_close(out_g.float().cpu(), torch.nn.functional.gelu(ref), atol=atol * 4, rtol=rtol)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,H,T,T_M", [(2, 12, 128, 64), (1, 32, 300, 256), (1, 40, 64, 256), (1, 4, 50, 128),
                                        (1, 6, 40, 512), (1, 3, 20, 32)])
-def test_predictor_tail(ops, dtype, N, H, T, T_M):
+def test_predictor_tail(ops, dtype, N, H, T, T_M, layout):
     C, W4 = 2 * H, T_M // 4
     if dtype != torch.float32 and W4 % 8:
         pytest.skip("16-bit rows need W4 % 8 == 0")
@@ -55,17 +56,25 @@ def test_predictor_tail(ops, dtype, N, H, T, T_M):
     lw = (torch.rand(T_M, generator=g) + 0.5).to(dtype)
     lb = (torch.randn(T_M, generator=g) * 0.1).to(dtype)
     p_ref, s_ref = O.predictor_tail(y.float(), cw.float(), cb.float(), lw.float(), lb.float(), 4, T_M)
-    probs, scores = ops.predictor_tail(y.to(DEV), cw[:, :, 0, 0].to(DEV), cb.to(DEV), lw.to(DEV), lb.to(DEV),
+    yd = y.to(DEV)
+    if layout == "nhwc":                     # 16-bit channels-last input takes the MFMA variant of the kernel
+        if C % (4 if dtype == torch.float32 else 8):
+            pytest.skip("channels-last rows need C % vec == 0")
+        yd = yd.contiguous(memory_format=torch.channels_last)
+    probs, scores = ops.predictor_tail(yd, cw[:, :, 0, 0].to(DEV), cb.to(DEV), lw.to(DEV), lb.to(DEV),
                                        up=4, T_m=T_M, want_scores=True)
     assert probs.dtype == dtype and tuple(probs.shape) == (N, H, T, T_M)
     if dtype == torch.float32:
         torch.testing.assert_close(scores.cpu(), s_ref, atol=2e-5, rtol=1e-5)
         torch.testing.assert_close(probs.cpu(), p_ref, atol=1e-7, rtol=1e-4)
-    else:
+    elif dtype == torch.bfloat16:
         torch.testing.assert_close(scores.float().cpu(), s_ref, atol=3e-2, rtol=1e-2)
         torch.testing.assert_close(probs.float().cpu(), p_ref, atol=1e-5, rtol=4e-2)
+    else:
+        torch.testing.assert_close(scores.float().cpu(), s_ref, atol=4e-3, rtol=2e-3)
+        torch.testing.assert_close(probs.float().cpu(), p_ref, atol=1e-6, rtol=6e-3)
     assert torch.allclose(probs.float().sum(-1), torch.ones((), device=DEV), atol=2e-2 if dtype != torch.float32 else 1e-5)
-    p2, s2 = ops.predictor_tail(y.to(DEV), cw[:, :, 0, 0].to(DEV), cb.to(DEV), lw.to(DEV), lb.to(DEV), up=4, T_m=T_M)
+    p2, s2 = ops.predictor_tail(yd, cw[:, :, 0, 0].to(DEV), cb.to(DEV), lw.to(DEV), lb.to(DEV), up=4, T_m=T_M)
     assert s2 is None and torch.equal(p2, probs)
 
 
@@ -190,9 +199,15 @@ def test_predictor_tail_accepts_channels_last(ops):
     cw = (torch.randn((H, C), generator=g) * C ** -0.5).bfloat16().to(DEV)
     cb = (torch.randn(H, generator=g) * 0.1).bfloat16().to(DEV)
     lw = (torch.rand(T_M, generator=g) + 0.5).bfloat16().to(DEV); lb = torch.zeros(T_M).bfloat16().to(DEV)
-    p1, s1 = ops.predictor_tail(y, cw, cb, lw, lb, up=4, T_m=T_M, want_scores=True)
-    p2, s2 = ops.predictor_tail(y.contiguous(memory_format=torch.channels_last), cw, cb, lw, lb, up=4, T_m=T_M, want_scores=True)
-    assert torch.equal(p1, p2) and torch.equal(s1, s2)
+    p1, s1 = ops.predictor_tail(y, cw, cb, lw, lb, up=4, T_m=T_M, want_scores=True)              # NCHW: VALU variant
+    p2, s2 = ops.predictor_tail(y.contiguous(memory_format=torch.channels_last), cw, cb, lw, lb, up=4, T_m=T_M,
+                                want_scores=True)                                                # NHWC: MFMA variant
+    p_ref, s_ref = O.predictor_tail(y.float().cpu(), cw.float().cpu().view(H, C, 1, 1), cb.float().cpu(), lw.float().cpu(),
+                                    lb.float().cpu(), 4, T_M)
+    for pp, ss in ((p1, s1), (p2, s2)):
+        torch.testing.assert_close(ss.float().cpu(), s_ref, atol=3e-2, rtol=1e-2)
+        torch.testing.assert_close(pp.float().cpu(), p_ref, atol=1e-5, rtol=4e-2)
+    assert (p1.float() - p2.float()).abs().max().item() < 2e-4
 
 
 def test_module_bf16_hip_estimator_close_to_torch_estimator():
