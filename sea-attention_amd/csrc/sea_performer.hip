@@ -60,6 +60,8 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
   float* sKp = sQp + C * LDP;     // C x LDP     phi(K)
   float* sKsum = sKp + C * LDP;   // NBP         running sum of phi(k)
   float* sDen = sKsum + NBP;      // C           denominators of the current chunk
+  constexpr int DSL = RB + NW * 64 / C;       // partial-denominator slots per row: RB key blocks + carry parts
+  float* sDenP = sDen + C;        // C x DSL     partials, summed in a fixed order (bitwise reproducible)
   float* sA = sQ;
 
   const int tid = threadIdx.x;
@@ -132,7 +134,7 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
       }
     }
     if (t0 + C < p.T) issue_loads(t0 + C);                 // next chunk: in flight during phases (b)..(e)
-    for (int i = tid; i < C; i += NTH) sDen[i] = 0.f;
+    for (int i = tid; i < C * DSL; i += NTH) sDenP[i] = 0.f;
     __syncthreads();
     PSTAMP(0);   // (a) staging
 
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
         sA[row * LDA + col] = val;                       // NOTE: overlays sQ, which step (b) no longer needs
         float s = val;                                   // sum over the 16 columns held by lanes li = 0..15
         s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
-        if (li == 0) atomicAdd(&sDen[row], s);
+        if (li == 0) sDenP[row * DSL + jb] = s;            // one writer per (row, key block)
       }
     }
     // denominators' carry part: phi(q_i) . (ksum + eps)   (ksum = state BEFORE this chunk)
@@ -199,7 +201,14 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
       const int per = (NBP + PARTS - 1) / PARTS;
       float s = 0.f;
       for (int r = part * per; r < min(p.nb, (part + 1) * per); ++r) s = fmaf(sQp[row * LDP + r], sKsum[r] + 1e-6f, s);
-      atomicAdd(&sDen[row], s);
+      sDenP[row * DSL + RB + part] = s;
+    }
+    __syncthreads();
+    if (tid < C) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < DSL; ++i) s += sDenP[tid * DSL + i];
+      sDen[tid] = s;
     }
     __syncthreads();
     PSTAMP(2);   // (c) A + denominators
@@ -283,7 +292,8 @@ using namespace sea;
 template <typename T, int D, int NBT, int C, int NW = 8>
 static int launch_perf(const PerfParams& p, hipStream_t s) {
   constexpr int E = 2 * D, NBP = NBT * 16;
-  constexpr size_t lds = sizeof(float) * (NBP * (D + 2) + 2 * C * (D + 2) + C * (E + 16) + 2 * C * (NBP + 2) + NBP + C);
+  constexpr size_t lds = sizeof(float) * (NBP * (D + 2) + 2 * C * (D + 2) + C * (E + 16) + 2 * C * (NBP + 2) + NBP + C +
+                                          C * (C / 16 + NW * 64 / C));
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool configured = false;   // one per template instantiation; the attribute call is a slow driver round trip
   if (lds > 64 * 1024 && !configured) {

@@ -229,3 +229,27 @@ def test_module_bf16_hip_estimator_close_to_torch_estimator():
         a, b = b_hip[name].float(), b_torch[name].float()
         rel = ((a - b).norm() / b.norm()).item()
         assert rel < tol, (name, rel)
+
+
+def test_estimator_kernels_are_bitwise_reproducible(ops):
+    """Two launches on the same inputs give identical bits (no float atomics on the estimator path): the module-level
+    dense-vs-sparse consistency test relies on it."""
+    import math
+    from sea_attention_amd.perlin_attention.performer import FastAttention
+    torch.manual_seed(0)
+    N, H, T, D, T_M = 2, 8, 700, 64, 256
+    fa = FastAttention(D, nb_features=int(D * math.log(D) / 8), causal=True, generalized_attention=True).to(DEV)
+    q = (torch.randn(N, H, T, D, device=DEV) * D ** -0.5).bfloat16(); k = torch.randn(N, H, T, D, device=DEV).bfloat16()
+    v = torch.randn(N, H, T, D, device=DEV).bfloat16(); pos = torch.randn(T, D, device=DEV).bfloat16()
+    a = ops.performer_value(q, k, v, pos, fa.projection_matrix)
+    for _ in range(3):
+        assert torch.equal(a, ops.performer_value(q, k, v, pos, fa.projection_matrix))
+    y = torch.relu(torch.randn(N, 2 * H, T, T_M // 4, device=DEV)).bfloat16().contiguous(memory_format=torch.channels_last)
+    cw = torch.randn(H, 2 * H, device=DEV).bfloat16(); cb = torch.zeros(H, device=DEV).bfloat16()
+    lw = torch.ones(T_M, device=DEV).bfloat16(); lb = torch.zeros(T_M, device=DEV).bfloat16()
+    p0, _ = ops.predictor_tail(y, cw, cb, lw, lb, up=4, T_m=T_M)
+    wt = torch.randn(2 * H, 2 * H, 5, 3, device=DEV).bfloat16() * 0.05; b = torch.zeros(2 * H, device=DEV).bfloat16()
+    c0 = ops.causal_conv_nhwc(y, wt, b, 3, 2, 2)
+    for _ in range(3):
+        assert torch.equal(p0, ops.predictor_tail(y, cw, cb, lw, lb, up=4, T_m=T_M)[0])
+        assert torch.equal(c0, ops.causal_conv_nhwc(y, wt, b, 3, 2, 2))
