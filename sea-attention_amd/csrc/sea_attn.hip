@@ -285,44 +285,54 @@ __global__ __launch_bounds__(256) void sparse_attn_rows_kernel(AttnParams p) {
   for (int o = LPR; o < 64; o <<= 1) zmax = max(zmax, __shfl_xor(zmax, o));
   const int last = end - 1;
 
-  for (int i0 = 0; i0 < zmax; i0 += U) {
-    bool ok[U];
-    uint4 kr[U], vr[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const int e = beg + i0 + u;
-      ok[u] = e < end;
-      // entries past the row's end re-read a valid entry and are masked by -inf below: no exec branches
-      const int ec = ok[u] ? e : (last >= beg ? last : 0);
-      const uint32_t key = (uint32_t)(col[ec] - hcol);
-      const uint32_t key_c = (end > beg) ? key : 0u;
-      kr[u] = *reinterpret_cast<const uint4*>(kbase + (__umul24(key_c, kst) + lane_off));
-      vr[u] = *reinterpret_cast<const uint4*>(vbase + (__umul24(key_c, vst) + lane_off));
+  // Column indices: lane `sub` of a group fetches entry (i0 + sub) -- one coalesced load per LPR entries -- and the
+  // group reads them back one by one through the LDS crossbar (ds_bpermute), which this kernel otherwise leaves idle.
+  const int grp_lane0 = (lane - sub) << 2;                 // byte address of the group's first lane for bpermute
+  for (int i0 = 0; i0 < zmax; i0 += LPR) {
+    int cidx;
+    {
+      const int e = beg + i0 + sub;
+      const int ec = e < end ? e : (last >= beg ? last : 0);
+      cidx = (end > beg) ? (col[ec] - hcol) : 0;           // rows without entries read key 0 (masked below)
     }
-    float s[U];
-    float mnew = m;
 #pragma unroll
-    for (int u = 0; u < U; ++u) {
-      float d = frag_dot<T>(qraw, kr[u]);
-      d = group_sum<LPR>(d);
-      s[u] = ok[u] ? d : -INFINITY;
-      mnew = fmaxf(mnew, s[u]);
+    for (int u0 = 0; u0 < LPR; u0 += U) {
+      if (i0 + u0 < zmax) {                                // wave-uniform
+        bool ok[U];
+        uint4 kr[U], vr[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          ok[u] = beg + i0 + u0 + u < end;
+          const uint32_t key_c = (uint32_t)__builtin_amdgcn_ds_bpermute(grp_lane0 + ((u0 + u) << 2), cidx);
+          kr[u] = *reinterpret_cast<const uint4*>(kbase + (__umul24(key_c, kst) + lane_off));
+          vr[u] = *reinterpret_cast<const uint4*>(vbase + (__umul24(key_c, vst) + lane_off));
+        }
+        float s[U];
+        float mnew = m;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          float d = frag_dot<T>(qraw, kr[u]);
+          d = group_sum<LPR>(d);
+          s[u] = ok[u] ? d : -INFINITY;
+          mnew = fmaxf(mnew, s[u]);
+        }
+        const float msafe = (mnew == -INFINITY) ? 0.f : mnew;     // rows that have seen nothing yet: exp(-inf - 0) = 0
+        const float alpha = __expf(m - msafe);
+        l *= alpha;
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) acc[j] *= alpha;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const float pu = __expf(s[u] - msafe);
+          float vf[VEC];
+          unpack16<T>(vr[u], vf);
+          l += pu;
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) acc[j] = fmaf(pu, vf[j], acc[j]);
+        }
+        m = mnew;
+      }
     }
-    const float msafe = (mnew == -INFINITY) ? 0.f : mnew;     // rows that have seen nothing yet: exp(-inf - 0) = 0
-    const float alpha = __expf(m - msafe);
-    l *= alpha;
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) acc[j] *= alpha;
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const float pu = __expf(s[u] - msafe);
-      float vf[VEC];
-      unpack16<T>(vr[u], vf);
-      l += pu;
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) acc[j] = fmaf(pu, vf[j], acc[j]);
-    }
-    m = mnew;
   }
 
   if (rowok && dact) {
