@@ -171,11 +171,13 @@ int sea_split_layernorm(const void* x, int dtype, int64_t N, int64_t C, int64_t 
  * on the width) + area resize (T_m+2 -> T_m) + LayerNorm(T_m) + softmax(T_m).
  * Replaces cnn.keepres.upsam / conv4 / the KeepRes resize / cnn.lnorm2 (attention.py:271-281,
  * modules.py:42-55,77-92) and the softmax of attention.py:670-673.
- * y (N,C,T,W4) of `dtype` with element strides y_strides[n,c,t,w]: unit stride along w (NCHW) or along c (NHWC);
+ * y (N,C,T,W4) of `dtype` with FIVE element strides y_strides = {n, c, t, w, c8}: element (n,c,t,w) lives at
+ * n*s[0] + (c/8)*s[4] + (c%8)*s[1] + t*s[2] + w*s[3].  Plain 4-D layouts have s[4] = 8*s[1] (NCHW: s[3] == 1;
+ * NHWC: s[1] == 1); the C8 layout of sea_causal_conv_c8 has s[1] = 1, s[3] = 8, s[4] = 8*W4, s[2] = C*W4;
  * conv_wT (C, Hpad) FP32 = the conv weight transposed with the head axis zero-padded to Hpad = 8*ceil(H/8),
  * conv_b (Hpad) FP32 (both are read through the scalar cache); gamma/beta (T_m) of `dtype`;
  * conv_w16 (optional, may be NULL): (16*ceil(H/16), Cp) row-major copy of the weight in `dtype`, channels zero-padded
- * to Cp (multiple of 32) -- with it, 16-bit channels-last input takes the MFMA variant of the kernel;
+ * to Cp (multiple of 32) -- with it, 16-bit NHWC / C8 input takes the MFMA variant of the kernel;
  * probs and optional scores (pre-softmax) are (N,H,T,T_m) contiguous of `dtype`.
  * Requires W4*up == T_m, T_m <= 512, W4 a multiple of the 16-byte vector width. */
 int sea_predictor_tail(const void* y, int dtype, int64_t N, int64_t C, int64_t H, int64_t T, int64_t W4,
@@ -189,19 +191,22 @@ int sea_predictor_tail(const void* y, int dtype, int64_t N, int64_t C, int64_t H
 int sea_cumavg(const void* v, int dtype, int64_t N, int64_t H, int64_t T, int64_t D, const int64_t* v_strides,
                void* out, sea_stream_t stream);
 
-/* Channels-last predictor CNN for 16-bit data.
- * sea_split_layernorm_nhwc: as sea_split_layernorm (no activation) but the result is written channels-last,
- *   out (N, T, W, C*S) -- the layout the conv kernel below consumes.
- * sea_causal_conv_nhwc: y = act(conv2d(x) + bias), square kernel `ksize`, dilation `dilation`, zero padding
+/* Channel-blocked ("C8") predictor CNN for 16-bit data.
+ * C8 layout of a logical (N, C, T, W) activation, C % 8 == 0:  memory (N, T, C/8, W, 8) -- 16-byte blocks of 8
+ * channels, consecutive pixels of a block adjacent (what an MFMA operand fragment reads contiguously).
+ * sea_split_layernorm_c8: as sea_split_layernorm (no activation) but the result is written C8,
+ *   out (N, T, C*S/8, W, 8) -- the layout the conv kernel below consumes.
+ * sea_causal_conv_c8: y = act(conv2d(x) + bias), square kernel `ksize` (1 or 3), dilation `dilation`, zero padding
  *   (ksize-1)*dilation rows on TOP only (causal along T, = CausalConv2d of modules.py:96-192 whose lower kernel
- *   rows are masked) and pad_w columns on both sides (width preserving).  x (N,T,W,Cin), y (N,T,W,Cout) NHWC;
+ *   rows are masked) and pad_w columns on both sides (width preserving).  x (N,T,Cin/8,W,8), y (N,T,Cout/8,W,8);
  *   w_packed (Cout, ksize*ksize*CinP) 16-bit = weight[co, ci, i, j] laid out [co][i*ksize+j][ci], ci zero-padded to
- *   CinP (multiple of 32); bias (Cout) FP32; relu != 0 fuses the ReLU that follows conv1/conv2 (attention.py:271-276). */
-int sea_split_layernorm_nhwc(const void* x, int dtype, int64_t N, int64_t C, int64_t T, int64_t S, int64_t W,
-                             const void* gamma, const void* beta, float eps, void* out, sea_stream_t stream);
-int sea_causal_conv_nhwc(const void* x, int dtype, int64_t N, int64_t T, int64_t W, int64_t Cin, int64_t Cout,
-                         const void* w_packed, int64_t CinP, const float* bias, int ksize, int dilation, int pad_w,
-                         int relu, void* y, sea_stream_t stream);
+ *   CinP (Cin rounded up to 32); bias (Cout) FP32; relu != 0 fuses the ReLU that follows conv1/conv2
+ *   (attention.py:271-276). */
+int sea_split_layernorm_c8(const void* x, int dtype, int64_t N, int64_t C, int64_t T, int64_t S, int64_t W,
+                           const void* gamma, const void* beta, float eps, void* out, sea_stream_t stream);
+int sea_causal_conv_c8(const void* x, int dtype, int64_t N, int64_t T, int64_t W, int64_t Cin, int64_t Cout,
+                       const void* w_packed, int64_t CinP, const float* bias, int ksize, int dilation, int pad_w,
+                       int relu, void* y, sea_stream_t stream);
 
 /* Causal Performer of SEA's estimator in one launch, fp32 MFMA:
  *   phi(x) = relu(D^-1/4 x W^T) + 1e-3;  ctx_t = sum_{s<=t} (phi(q_t).phi(k_s)) V_s / (phi(q_t).(sum_{s<=t} phi(k_s) + 1e-6))

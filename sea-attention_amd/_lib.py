@@ -38,8 +38,8 @@ _SIGNATURES = {
     "sea_predictor_tail": ([ptr, c_int, i64, i64, i64, i64, i64, i64, i64, _i64p, ptr, ptr, ptr, i64, ptr, ptr,
                             ctypes.c_float, ptr, ptr, ptr], c_int),
     "sea_cumavg": ([ptr, c_int, i64, i64, i64, i64, _i64p, ptr, ptr], c_int),
-    "sea_split_layernorm_nhwc": ([ptr, c_int, i64, i64, i64, i64, i64, ptr, ptr, ctypes.c_float, ptr, ptr], c_int),
-    "sea_causal_conv_nhwc": ([ptr, c_int, i64, i64, i64, i64, i64, ptr, i64, ptr, c_int, c_int, c_int, c_int, ptr, ptr], c_int),
+    "sea_split_layernorm_c8": ([ptr, c_int, i64, i64, i64, i64, i64, ptr, ptr, ctypes.c_float, ptr, ptr], c_int),
+    "sea_causal_conv_c8": ([ptr, c_int, i64, i64, i64, i64, i64, ptr, i64, ptr, c_int, c_int, c_int, c_int, ptr, ptr], c_int),
     "sea_performer_causal": ([ptr, ptr, ptr, ptr, c_int, ptr, i64, i64, i64, i64, i64, _i64p, _i64p, _i64p, i64, ptr, ptr], c_int),
 }
 
@@ -84,6 +84,16 @@ def strides3(t):
 
 def strides4(t):
     return (c_int64 * 4)(*t.stride())
+
+
+def strides5_blocked(t):
+    """{n, c, t, w, block-of-8} element strides of an activation for sea_predictor_tail: `t` is either a 4-D
+    (N,C,T,W) tensor of any strides or a 5-D C8 tensor (N, T, C/8, W, 8)."""
+    if t.dim() == 5:
+        sn, st, sb, sw, sc = t.stride()
+        return (c_int64 * 5)(sn, sc, st, sw, sb)
+    sn, sc, st, sw = t.stride()
+    return (c_int64 * 5)(sn, sc, st, sw, 8 * sc)
 
 
 def stream_ptr():

@@ -73,6 +73,12 @@ template <> __device__ inline float from_f<float>(float x) { return x; }
 template <> __device__ inline __half from_f<__half>(float x) { return __float2half(x); }
 template <> __device__ inline __hip_bfloat16 from_f<__hip_bfloat16>(float x) { return __float2bfloat16(x); }
 
+// Two floats -> one dword of packed 16-bit values (low half = a), same rounding as from_f<T>.
+template <typename T> __device__ inline uint32_t pack2(float a, float b) {
+  const T x = from_f<T>(a), y = from_f<T>(b);
+  return (uint32_t)__builtin_bit_cast(unsigned short, x) | ((uint32_t)__builtin_bit_cast(unsigned short, y) << 16);
+}
+
 // ---- wave-level primitives -----------------------------------------------------------------
 __device__ inline int lane_id() { return threadIdx.x & 63; }
 

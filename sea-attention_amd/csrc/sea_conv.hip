@@ -1,17 +1,22 @@
-// SEA predictor CNN in channels-last (NHWC) form, hand-written for gfx950 (16-bit data, bf16/f16 MFMA).
+// SEA predictor CNN in channel-blocked ("C8") form, hand-written for gfx950 (16-bit data, bf16/f16 MFMA).
 //
 // Replaces, for 16-bit tensors (reference: src/models/perlin_attention/attention.py:266-281,
 // modules.py:96-192):
-//   ChannelSplit + cnn.lnorm1                         -> split_layernorm_nhwc_kernel   (writes NHWC)
-//   cnn.keepres.conv1 / conv2 (+ the ReLU after each) -> causal_conv_nhwc_kernel       (NHWC -> NHWC)
-// MIOpen's implicit-GEMM needs NHWC too and therefore brackets every NCHW conv with two layout transposes,
-// a padded copy of the input and separate bias / ReLU passes; here the tensors simply stay NHWC between the
-// LayerNorm and the predictor tail, padding is done by predication and bias + ReLU live in the epilogue.
+//   ChannelSplit + cnn.lnorm1                         -> split_layernorm_c8_kernel   (writes C8)
+//   cnn.keepres.conv1 / conv2 (+ the ReLU after each) -> causal_conv_c8_kernel       (C8 -> C8)
 //
-// causal_conv_nhwc_kernel: implicit GEMM, M = pixels, N = C_out, K = taps x C_in, v_mfma_f32_16x16x32.
-//   one wave = 64 consecutive pixels of one (n, t) row  x  all C_out   (4 M-tiles x NT N-tiles)
-//   A fragments (8 channels of one tap of one pixel = 16 B) come straight from global memory (L1/L2 absorb the
-//   9x tap reuse); B fragments (weights, [co][tap][ci] with padded rows) are staged once per workgroup in LDS.
+// C8 layout of an activation with logical shape (N, C, T, W):  memory (N, T, C/8, W, 8) -- blocks of 8 channels
+// (16 B) are the unit, consecutive pixels of one block are adjacent.  It is what the MFMA operand wants: a lane
+// holds 8 consecutive K (channels) of one pixel, the 16 lanes of a fragment column-group hold 16 consecutive
+// pixels, so every wave-wide load or store touches four contiguous 256-byte runs (plain NHWC puts the 16 pixels
+// 2*C bytes apart: 16 half-used cache lines per pass, which kept the texture addresser ~80 % busy and the MFMA
+// pipe at 17 %).  A tap shift is an offset of whole 16-byte units.  MIOpen's implicit GEMM needs NHWC and brackets
+// every NCHW conv with two transposes, a padded copy and separate bias / ReLU passes; here the tensors stay C8
+// between the LayerNorm and the predictor tail, padding is hardware range-checking and bias + ReLU live in the
+// epilogue.
+//
+// causal_conv_c8_kernel: implicit GEMM, M = C_out, N = pixels, K = taps x C_in, v_mfma_f32_16x16x32.
+//   one wave = 64 consecutive pixels of one (n, t) row  x  all C_out   (NT M-tiles x 4 N-tiles)
 #include "sea_common.hpp"
 
 namespace sea {
@@ -19,119 +24,194 @@ namespace sea {
 typedef __attribute__((ext_vector_type(4))) float cf4;
 typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
 typedef __attribute__((ext_vector_type(8))) _Float16 h8;
+typedef __attribute__((ext_vector_type(4))) unsigned int cu4;
 
 template <typename T> struct Mfma16;
 template <> struct Mfma16<__hip_bfloat16> {
-  __device__ static inline cf4 run(const uint4& a, const uint4& b, cf4 c) {
+  __device__ static inline cf4 run(const uint4& a, const cu4& b, cf4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
   }
 };
 template <> struct Mfma16<__half> {
-  __device__ static inline cf4 run(const uint4& a, const uint4& b, cf4 c) {
+  __device__ static inline cf4 run(const uint4& a, const cu4& b, cf4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
   }
 };
 
 struct ConvParams {
-  const void* x;    // (N, T, W, Cin)   NHWC
+  const void* x;    // (N, T, Cin/8, W, 8)   C8
   const void* w;    // (Cout, taps*CinP) packed [co][tap][ci], ci padded to CinP (multiple of 32), 16-bit
   const float* b;   // (Cout) fp32
-  void* y;          // (N, T, W, Cout)  NHWC
+  void* y;          // (N, T, Cout/8, W, 8)  C8
   int N, T, W, Cin, Cout, CinP;
   int KS, dil, pad_w, relu;
 };
 
-// NT = number of 16-wide output-channel tiles (Cout <= 16*NT)
-template <typename T, int NT>
-__global__ __launch_bounds__(256) void causal_conv_nhwc_kernel(ConvParams p) {
+// NT = number of 16-wide output-channel tiles (Cout <= 16*NT); KS = square kernel size (compile time: the
+// per-lane tap offsets live in registers); 8 waves per workgroup share one weight image in LDS.
+//
+// A operand = weights, B operand = pixels: in the accumulator (col = lane%16, row = 4*(lane/16) + r) a lane then
+// owns ONE pixel and 4 consecutive channels per M-tile.  Weight row (nt, 4*g + r) of the LDS image is channel
+// g*4*NT + nt*4 + r, so the 4*NT values of a lane are one contiguous run of channels -> 16-byte C8 stores.
+// LDS weight image: [k-step][lg][row][8 elements]; a lane's 16 bytes sit at bank 4*li for every lg, which is
+// conflict-free for ds_read_b128's lane groups without any padding.
+// k-steps run (tap row, 32-channel chunk, tap column); the three column shifts of one chunk re-read the same
+// lines back to back.  Pixel fragments come through buffer loads: a lane whose tap falls outside the row (or whose
+// channel block is K padding) carries an offset beyond num_records and the hardware returns zeros, so the k-loop
+// is branch-free and the next step's loads are in flight under the current step's MFMAs.
+constexpr int CONV_WAVES = 6;
+constexpr unsigned CONV_OOB = 0x7FFFFF00u;       // > any valid byte offset (launcher checks the image is < 1 GiB)
+
+template <typename T, int NT, int KS>
+__global__ __launch_bounds__(CONV_WAVES * 64, (NT <= 4 ? 3 : 2)) void causal_conv_c8_kernel(ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int NTH = CONV_WAVES * 64;
+  constexpr int ROWS = 16 * NT;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, lg = lane >> 4;
-  const int taps = p.KS * p.KS;
-  const int KP = taps * p.CinP;                 // packed K extent (elements)
-  const int ldw = KP + 8;                       // LDS row stride in elements (+16 B: conflict-free b128 reads)
-  T* sW = reinterpret_cast<T*>(smem);           // (16*NT) x ldw
+  const int kchunks = p.CinP / 32;
+  const int nsteps = KS * KS * kchunks;          // k-steps, ordered (ti, chunk, tj)
+  const int KP = KS * KS * p.CinP;               // packed K extent of the global weight rows (elements)
+  T* sW = reinterpret_cast<T*>(smem);            // nsteps x 4 x ROWS x 8
+  float* sBias = reinterpret_cast<float*>(smem + (size_t)nsteps * 4 * ROWS * 8 * sizeof(T));   // ROWS, by channel
   // ---- stage the weights once per workgroup ----------------------------------------------------------
   {
     const T* wg = reinterpret_cast<const T*>(p.w);
-    const int chunks_per_row = KP / 8;
-    for (int ch = threadIdx.x; ch < 16 * NT * chunks_per_row; ch += 256) {
-      const int co = ch / chunks_per_row, kc = (ch - co * chunks_per_row) * 8;
+    for (int ch = threadIdx.x; ch < nsteps * 4 * ROWS; ch += NTH) {
+      const int row = ch % ROWS, sl = ch / ROWS;           // sl = st*4 + lg
+      const int g = sl & 3, st = sl >> 2;
+      const int tj = st % KS, tc = st / KS;
+      const int cci = tc % kchunks, ti = tc / kchunks;
+      const int nt = row >> 4, rr = row & 15;
+      const int co = (rr >> 2) * (4 * NT) + nt * 4 + (rr & 3);
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (co < p.Cout) v = *reinterpret_cast<const uint4*>(wg + (int64_t)co * KP + kc);
-      *reinterpret_cast<uint4*>(sW + co * ldw + kc) = v;
+      if (co < p.Cout) v = *reinterpret_cast<const uint4*>(wg + (int64_t)co * KP + (ti * KS + tj) * p.CinP + cci * 32 + g * 8);
+      *reinterpret_cast<uint4*>(sW + (int64_t)ch * 8) = v;
     }
+    for (int c = threadIdx.x; c < ROWS; c += NTH) sBias[c] = c < p.Cout ? p.b[c] : 0.f;
   }
   __syncthreads();
 
   const int segs = (p.W + 63) / 64;                          // 64-pixel segments per row
+  const int C8i = p.Cin >> 3, C8o = p.Cout >> 3;
+  const unsigned img_bytes = (unsigned)p.T * (unsigned)p.W * (unsigned)p.Cin * (unsigned)sizeof(T);
+  const T* wlane = sW + (lg * ROWS + li) * 8;                // + st*4*ROWS*8 + nt*16*8
   const int64_t nwork = (int64_t)p.N * p.T * segs;
-  for (int64_t work = (int64_t)blockIdx.x * 4 + wv; work < nwork; work += (int64_t)gridDim.x * 4) {
+  for (int64_t work = (int64_t)blockIdx.x * CONV_WAVES + wv; work < nwork; work += (int64_t)gridDim.x * CONV_WAVES) {
     const int seg = (int)(work % segs);
     const int64_t nt_ = work / segs;
     const int t = (int)(nt_ % p.T), n = (int)(nt_ / p.T);
     const int w0 = seg * 64;
     const T* xn = reinterpret_cast<const T*>(p.x) + (int64_t)n * p.T * p.W * p.Cin;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xn), 0, (int)img_bytes, 0x00020000);
 
-    cf4 acc[4][NT];
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = cf4{0.f, 0.f, 0.f, 0.f};
+    const int px = w0 + li;                                  // this lane's pixel of M-tile 0
+    const unsigned lbase = (unsigned)((lg * p.W + px) * 16);  // its byte offset inside one (row, 4-block chunk) slab
 
-    for (int ti = 0; ti < p.KS; ++ti) {
-      const int tr = t + p.dil * (ti - (p.KS - 1));          // causal: rows t-(KS-1)*dil .. t
-      if (tr < 0) continue;                                  // wave-uniform: zero padding on top
-      for (int tj = 0; tj < p.KS; ++tj) {
-        const int tap = ti * p.KS + tj;
-        for (int cc = 0; cc < p.CinP; cc += 32) {
-          const int ci = cc + 8 * lg;                        // this lane's 8 input channels
-          uint4 a[4];
+    cf4 acc[NT][4];
 #pragma unroll
-          for (int mt = 0; mt < 4; ++mt) {
-            const int wpix = w0 + mt * 16 + li;
-            const int wc = wpix + p.dil * tj - p.pad_w;
-            a[mt] = make_uint4(0, 0, 0, 0);
-            if (ci < p.Cin && wc >= 0 && wc < p.W && wpix < p.W)
-              a[mt] = *reinterpret_cast<const uint4*>(xn + ((int64_t)tr * p.W + wc) * p.Cin + ci);
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = cf4{0.f, 0.f, 0.f, 0.f};
+
+    // tap rows that lie entirely in the causal padding are a prefix of the step order (wave-uniform skip)
+    int ti0 = 0;
+    while (ti0 < KS && t + p.dil * (ti0 - (KS - 1)) < 0) ++ti0;
+
+    // step cursor: (ti, cci) group + compile-time tj
+    auto issue = [&](int grp, int tj, cu4 (&a)[4]) {        // grp = ti*kchunks + cci
+      const int ngrp = KS * kchunks;
+      const bool live = grp < ngrp;
+      const int gc = live ? grp : ngrp - 1;
+      const int ti = gc / kchunks, cci = gc - ti * kchunks;
+      const int tr = t + p.dil * (ti - (KS - 1));
+      const int soff = ((tr * C8i + cci * 4) * p.W) * 16;   // bytes; tr >= 0 for every live group
+      const bool lane_live = live && (cci * 4 + lg < C8i);
+      const int dw = p.dil * tj - p.pad_w;                   // column shift of this tap (pixels outside the row: zeros;
+#pragma unroll                                               //  pixels >= W of a ragged last segment are never stored)
+      for (int mt = 0; mt < 4; ++mt) {
+        const bool ok = lane_live && (unsigned)(px + mt * 16 + dw) < (unsigned)p.W;
+        a[mt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok ? lbase + (unsigned)((mt * 16 + dw) * 16) : CONV_OOB),
+                                                      live ? soff : 0, 0);
+      }
+    };
+    auto compute = [&](int grp, int tj, const cu4 (&a)[4]) {   // a dead group multiplies zeros: clamp its weight index
+      const int gc = grp < KS * kchunks ? grp : KS * kchunks - 1;
+      const T* wst = wlane + (gc * KS + tj) * (4 * ROWS * 8);
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const uint4 wf = *reinterpret_cast<const uint4*>(wst + nt * 128);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = Mfma16<T>::run(wf, a[mt], acc[nt][mt]);
+      }
+    };
+
+    const int ngrp = KS * kchunks;
+    if constexpr (KS == 3) {
+      // 3 steps per group, prefetch distance 1, two register buffers whose roles swap every group: the body is two
+      // groups = 6 straight-line steps (an odd group count runs one dead group on zeros)
+      cu4 a0[4], a1[4];
+      int grp = ti0 * kchunks;
+      issue(grp, 0, a0);
+#pragma unroll 1
+      for (; grp < ngrp; grp += 2) {
+        issue(grp, 1, a1);     compute(grp, 0, a0);
+        issue(grp, 2, a0);     compute(grp, 1, a1);
+        issue(grp + 1, 0, a1); compute(grp, 2, a0);
+        issue(grp + 1, 1, a0); compute(grp + 1, 0, a1);
+        issue(grp + 1, 2, a1); compute(grp + 1, 1, a0);
+        issue(grp + 2, 0, a0); compute(grp + 1, 2, a1);
+      }
+    } else {
+      cu4 a0[4];
+      for (int grp = ti0 * kchunks; grp < ngrp; ++grp)
+#pragma unroll
+        for (int tj = 0; tj < KS; ++tj) { issue(grp, tj, a0); compute(grp, tj, a0); }
+    }
+
+    // ---- epilogue: bias (+ ReLU), C8 store: lane = pixel (mt, li), channels lg*4*NT + nt*4 + r ------------
+    T* yn = reinterpret_cast<T*>(p.y) + ((int64_t)n * p.T + t) * p.W * p.Cout;
+    const int cbase = lg * 4 * NT;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      const int wpix = w0 + mt * 16 + li;
+      unsigned pk[2 * NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const float4 b4 = *reinterpret_cast<const float4*>(sBias + cbase + nt * 4);
+        float v0 = acc[nt][mt][0] + b4.x, v1 = acc[nt][mt][1] + b4.y, v2 = acc[nt][mt][2] + b4.z, v3 = acc[nt][mt][3] + b4.w;
+        if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+        pk[2 * nt] = pack2<T>(v0, v1);
+        pk[2 * nt + 1] = pack2<T>(v2, v3);
+      }
+      if (wpix < p.W) {
+        if constexpr ((NT & 1) == 0) {           // whole 8-channel blocks per lane: 16-byte stores
+#pragma unroll
+          for (int q = 0; q < NT / 2; ++q) {
+            const int blk = (cbase >> 3) + q;
+            if (blk < C8o)
+              *reinterpret_cast<uint4*>(yn + ((int64_t)blk * p.W + wpix) * 8) = make_uint4(pk[4 * q], pk[4 * q + 1], pk[4 * q + 2], pk[4 * q + 3]);
           }
-          const T* wrow = sW + tap * p.CinP + ci;
+        } else {                                 // odd NT: lanes own half blocks -> 8-byte stores
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) {
-            const uint4 b = *reinterpret_cast<const uint4*>(wrow + (nt * 16 + li) * ldw);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[mt][nt] = Mfma16<T>::run(a[mt], b, acc[mt][nt]);
+            const int c0 = cbase + nt * 4;
+            if (c0 < p.Cout)
+              *reinterpret_cast<uint2*>(yn + ((int64_t)(c0 >> 3) * p.W + wpix) * 8 + (c0 & 7)) = make_uint2(pk[2 * nt], pk[2 * nt + 1]);
           }
-        }
-      }
-    }
-    // ---- epilogue: bias (+ ReLU), NHWC store.  C layout: col = li (channel), row = lg*4 + r (pixel) -------
-    T* yn = reinterpret_cast<T*>(p.y) + ((int64_t)n * p.T + t) * p.W * p.Cout;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int co = nt * 16 + li;
-      const float bias = co < p.Cout ? p.b[co] : 0.f;
-#pragma unroll
-      for (int mt = 0; mt < 4; ++mt) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int wpix = w0 + mt * 16 + lg * 4 + r;
-          float v = acc[mt][nt][r] + bias;
-          if (p.relu) v = fmaxf(v, 0.f);
-          if (co < p.Cout && wpix < p.W) yn[(int64_t)wpix * p.Cout + co] = from_f<T>(v);
         }
       }
     }
   }
 }
 
-// ChannelSplit + LayerNorm with a channels-last result:
-//   x (N, C, T, S*W) -> out[n, t, w, c*S+i] = LN(x[n, c, t, i*W:(i+1)*W])[w] * gamma[w] + beta[w]
+// ChannelSplit + LayerNorm with a C8 result:
+//   x (N, C, T, S*W) -> out[n, t, (c*S+i)/8, w, (c*S+i)%8] = LN(x[n, c, t, i*W:(i+1)*W])[w] * gamma[w] + beta[w]
 // One workgroup per (n, t): the C*S rows are normalised by 8-lane groups, transposed through LDS and written
-// as one contiguous W x (C*S) block.
+// as one contiguous (C*S/8) x W x 8 block.
 template <typename T>
-__global__ __launch_bounds__(256) void split_layernorm_nhwc_kernel(const T* x, T* out, const T* gamma, const T* beta, float eps,
+__global__ __launch_bounds__(256) void split_layernorm_c8_kernel(const T* x, T* out, const T* gamma, const T* beta, float eps,
                                                                   int C, int Tn, int S, int W) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int VEC = 8;
@@ -176,10 +256,9 @@ __global__ __launch_bounds__(256) void split_layernorm_nhwc_kernel(const T* x, T
   }
   __syncthreads();
   T* on = out + (int64_t)nt * W * CS;
-  const int cpr = CS / VEC;                     // 16-byte chunks per pixel
-  for (int ch = threadIdx.x; ch < W * cpr; ch += 256) {
-    const int w = ch / cpr, c0 = (ch - w * cpr) * VEC;
-    *reinterpret_cast<uint4*>(on + (int64_t)w * CS + c0) = *reinterpret_cast<const uint4*>(tile + w * ldt + c0);
+  for (int ch = threadIdx.x; ch < W * (CS / VEC); ch += 256) {     // ch = block*W + w: the C8 order, coalesced
+    const int blk = ch / W, w = ch - blk * W;
+    *reinterpret_cast<uint4*>(on + (int64_t)ch * VEC) = *reinterpret_cast<const uint4*>(tile + w * ldt + blk * VEC);
   }
 }
 
@@ -190,40 +269,47 @@ using namespace sea;
 template <typename T>
 static int launch_conv(const ConvParams& p, hipStream_t s) {
   const int nt = (p.Cout + 15) / 16;
-  const size_t lds = (size_t)(16 * nt) * (size_t)(p.KS * p.KS * p.CinP + 8) * sizeof(T);
+  const size_t lds = (size_t)(p.KS * p.KS * (p.CinP / 32)) * 4 * (16 * nt) * 8 * sizeof(T) + (size_t)(16 * nt) * sizeof(float);
   if (lds > 160 * 1024) return SEA_EUNSUPPORTED;
+  if ((int64_t)p.T * p.W * p.Cin * (int64_t)sizeof(T) >= (int64_t)(1u << 30)) return SEA_EUNSUPPORTED;   // 32-bit buffer offsets
   const int64_t nwork = (int64_t)p.N * p.T * ((p.W + 63) / 64);
-  int64_t blocks = (nwork + 3) / 4;
-  if (blocks > 256 * 8) blocks = 256 * 8;      // persistent-ish: weights are staged once per workgroup
-  dim3 grid((unsigned)blocks), block(256);
-#define SEA_CONV(NTV)                                                                                               \
+  int64_t blocks = (nwork + CONV_WAVES - 1) / CONV_WAVES;
+  if (blocks > 256 * 4) blocks = 256 * 4;      // persistent-ish: weights are staged once per workgroup
+  dim3 grid((unsigned)blocks), block(CONV_WAVES * 64);
+#define SEA_CONV(NTV, KSV)                                                                                          \
   do {                                                                                                              \
     static bool configured = false;                                                                                 \
     if (lds > 64 * 1024 && !configured) {                                                                           \
-      (void)hipFuncSetAttribute((const void*)causal_conv_nhwc_kernel<T, NTV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      (void)hipFuncSetAttribute((const void*)causal_conv_c8_kernel<T, NTV, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       configured = true;                                                                                            \
     }                                                                                                               \
-    hipLaunchKernelGGL((causal_conv_nhwc_kernel<T, NTV>), grid, block, lds, s, p);                                  \
+    hipLaunchKernelGGL((causal_conv_c8_kernel<T, NTV, KSV>), grid, block, lds, s, p);                               \
   } while (0)
-  switch (nt) {
-    case 1: SEA_CONV(1); break; case 2: SEA_CONV(2); break; case 3: SEA_CONV(3); break; case 4: SEA_CONV(4); break;
-    case 5: SEA_CONV(5); break; case 6: SEA_CONV(6); break; case 8: SEA_CONV(8); break;
-    default: return SEA_EUNSUPPORTED;
+#define SEA_CONV_NT(KSV)                                                                                            \
+  switch (nt) {                                                                                                     \
+    case 1: SEA_CONV(1, KSV); break; case 2: SEA_CONV(2, KSV); break; case 3: SEA_CONV(3, KSV); break;              \
+    case 4: SEA_CONV(4, KSV); break; case 5: SEA_CONV(5, KSV); break; case 6: SEA_CONV(6, KSV); break;              \
+    case 8: SEA_CONV(8, KSV); break;                                                                                \
+    default: return SEA_EUNSUPPORTED;                                                                               \
   }
+  if (p.KS == 3) { SEA_CONV_NT(3) }
+  else if (p.KS == 1) { SEA_CONV_NT(1) }
+  else return SEA_EUNSUPPORTED;
+#undef SEA_CONV_NT
 #undef SEA_CONV
   return SEA_OK;
 }
 
-extern "C" int sea_causal_conv_nhwc(const void* x, int dtype, int64_t N, int64_t T, int64_t W, int64_t Cin, int64_t Cout,
+extern "C" int sea_causal_conv_c8(const void* x, int dtype, int64_t N, int64_t T, int64_t W, int64_t Cin, int64_t Cout,
                                     const void* w_packed, int64_t CinP, const float* bias, int ksize, int dilation,
                                     int pad_w, int relu, void* y, sea_stream_t stream) {
-  const char* nm = "sea_causal_conv_nhwc";
+  const char* nm = "sea_causal_conv_c8";
   SEA_REQUIRE(x && w_packed && bias && y, SEA_EINVAL, "%s: null pointer", nm);
   SEA_REQUIRE(dtype == SEA_F16 || dtype == SEA_BF16, SEA_EUNSUPPORTED, "%s: 16-bit data only (dtype %d)", nm, dtype);
   SEA_REQUIRE(N > 0 && T > 0 && W > 0 && Cin > 0 && Cout > 0 && ksize > 0 && dilation > 0 && pad_w >= 0, SEA_EINVAL,
               "%s: bad shape", nm);
-  SEA_REQUIRE(Cin % 8 == 0 && CinP % 32 == 0 && CinP >= Cin && Cout <= 128, SEA_EUNSUPPORTED,
-              "%s: needs Cin %% 8 == 0, CinP %% 32 == 0, Cout <= 128", nm);
+  SEA_REQUIRE(Cin % 8 == 0 && Cout % 8 == 0 && CinP % 32 == 0 && CinP >= Cin && CinP - Cin < 32 && Cout <= 128, SEA_EUNSUPPORTED,
+              "%s: needs Cin %% 8 == 0, Cout %% 8 == 0, CinP = Cin rounded up to 32, Cout <= 128", nm);
   SEA_REQUIRE(W + dilation * (ksize - 1) - 2 * pad_w == W, SEA_EUNSUPPORTED, "%s: width-preserving padding only", nm);
   SEA_REQUIRE((((uintptr_t)x | (uintptr_t)y | (uintptr_t)w_packed) & 15) == 0, SEA_EUNSUPPORTED, "%s: 16-byte alignment", nm);
   ConvParams p;
@@ -232,14 +318,14 @@ extern "C" int sea_causal_conv_nhwc(const void* x, int dtype, int64_t N, int64_t
   p.KS = ksize; p.dil = dilation; p.pad_w = pad_w; p.relu = relu;
   hipStream_t s = (hipStream_t)stream;
   const int rc = dtype == SEA_BF16 ? launch_conv<__hip_bfloat16>(p, s) : launch_conv<__half>(p, s);
-  SEA_REQUIRE(rc == SEA_OK, rc, "%s: unsupported channel count / kernel size for the LDS weight tile", nm);
+  SEA_REQUIRE(rc == SEA_OK, rc, "%s: unsupported channel count / kernel size (1 or 3) / image size for the LDS weight tile", nm);
   SEA_CHECK_LAUNCH(nm);
   return SEA_OK;
 }
 
-extern "C" int sea_split_layernorm_nhwc(const void* x, int dtype, int64_t N, int64_t C, int64_t T, int64_t S, int64_t W,
+extern "C" int sea_split_layernorm_c8(const void* x, int dtype, int64_t N, int64_t C, int64_t T, int64_t S, int64_t W,
                                         const void* gamma, const void* beta, float eps, void* out, sea_stream_t stream) {
-  const char* nm = "sea_split_layernorm_nhwc";
+  const char* nm = "sea_split_layernorm_c8";
   SEA_REQUIRE(x && gamma && beta && out, SEA_EINVAL, "%s: null pointer", nm);
   SEA_REQUIRE(dtype == SEA_F16 || dtype == SEA_BF16, SEA_EUNSUPPORTED, "%s: 16-bit data only (dtype %d)", nm, dtype);
   SEA_REQUIRE(N > 0 && C > 0 && T > 0 && S > 0 && W > 0, SEA_EINVAL, "%s: bad shape", nm);
@@ -253,10 +339,10 @@ extern "C" int sea_split_layernorm_nhwc(const void* x, int dtype, int64_t N, int
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)(N * T)), block(256);
   if (dtype == SEA_BF16)
-    hipLaunchKernelGGL((split_layernorm_nhwc_kernel<__hip_bfloat16>), grid, block, lds, s, (const __hip_bfloat16*)x,
+    hipLaunchKernelGGL((split_layernorm_c8_kernel<__hip_bfloat16>), grid, block, lds, s, (const __hip_bfloat16*)x,
                        (__hip_bfloat16*)out, (const __hip_bfloat16*)gamma, (const __hip_bfloat16*)beta, eps, (int)C, (int)T, (int)S, (int)W);
   else
-    hipLaunchKernelGGL((split_layernorm_nhwc_kernel<__half>), grid, block, lds, s, (const __half*)x, (__half*)out,
+    hipLaunchKernelGGL((split_layernorm_c8_kernel<__half>), grid, block, lds, s, (const __half*)x, (__half*)out,
                        (const __half*)gamma, (const __half*)beta, eps, (int)C, (int)T, (int)S, (int)W);
   SEA_CHECK_LAUNCH(nm);
   return SEA_OK;

@@ -113,7 +113,8 @@ struct TailParams {
   void* scores;      // optional (N, H, T, T_M)
   float eps;
   int N, C, H, T, W4, UP, T_M;
-  int64_t ys_n, ys_c, ys_t, ys_w;  // element strides of y (NCHW: ys_w == 1; channels-last: ys_c == 1)
+  int64_t ys_n, ys_c, ys_t, ys_w;  // element strides of y (NCHW: ys_w == 1; channels-last / C8: ys_c == 1)
+  int64_t ys_c8;                   // stride between blocks of 8 channels (8*ys_c for plain 4-D layouts; W*8 for C8)
   const void* w16;   // MFMA variant: (HP16, Cp) 16-bit row-major copy of the conv weight, zero padded
   int Cp;            // channels padded to a multiple of 32
 };
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void predictor_tail_kernel(TailParams p) {
       for (int ch = threadIdx.x; ch < CW / VEC; ch += 256) {
         const int w = ch / cpp, c = (ch - w * cpp) * VEC;
         float f[VEC];
-        unpack16<T>(*reinterpret_cast<const uint4*>(yb + (int64_t)w * p.ys_w + c), f);
+        unpack16<T>(*reinterpret_cast<const uint4*>(yb + (int64_t)w * p.ys_w + (c >> 3) * p.ys_c8 + (c & 7)), f);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) s_y[(c + j) * LDY + w] = f[j];
       }
@@ -329,7 +330,7 @@ __global__ __launch_bounds__(256) void predictor_tail_mfma_kernel(TailParams p) 
       for (int kc = 0; kc < KC; ++kc) {
         const int ci = kc * 32 + 8 * lg;
         uint4 a = make_uint4(0, 0, 0, 0);
-        if (ci < p.C && wpix < p.W4) a = *reinterpret_cast<const uint4*>(yb + (int64_t)wpix * p.ys_w + ci);
+        if (ci < p.C && wpix < p.W4) a = *reinterpret_cast<const uint4*>(yb + (int64_t)wpix * p.ys_w + (ci >> 3) * p.ys_c8);
         const uint4 b = *reinterpret_cast<const uint4*>(w16 + (nt * 16 + li) * p.Cp + ci);
         acc = tail_mfma<T>(a, b, acc);
       }
@@ -555,7 +556,9 @@ extern "C" int sea_predictor_tail(const void* y, int dtype, int64_t N, int64_t C
   const int vec = dtype == SEA_F32 ? 4 : 8;
   const bool nchw = y_strides[3] == 1, nhwc = y_strides[1] == 1;
   SEA_REQUIRE(nchw || nhwc, SEA_EUNSUPPORTED, "%s: y must have unit stride along the width (NCHW) or the channels (NHWC)", nm);
-  SEA_REQUIRE((nchw ? (W4 % vec == 0 && y_strides[1] % vec == 0) : (C % vec == 0 && y_strides[3] % vec == 0)) &&
+  SEA_REQUIRE(nchw ? y_strides[4] == 8 * y_strides[1] : (C % 8 == 0 || y_strides[4] == 8), SEA_EUNSUPPORTED,
+              "%s: the block-of-8 stride must be 8x the channel stride unless y is channel-blocked with C %% 8 == 0", nm);
+  SEA_REQUIRE((nchw ? (W4 % vec == 0 && y_strides[1] % vec == 0) : (C % vec == 0 && y_strides[3] % vec == 0 && y_strides[4] % vec == 0)) &&
                   y_strides[0] % vec == 0 && y_strides[2] % vec == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)conv_w & 15) == 0,
               SEA_EUNSUPPORTED, "%s: y vectors must be 16-byte aligned", nm);
   const size_t lds = (size_t)(C * (W4 + 1) + 4 * 8 * W4) * sizeof(float);
@@ -563,7 +566,7 @@ extern "C" int sea_predictor_tail(const void* y, int dtype, int64_t N, int64_t C
   TailParams p;
   p.y = y; p.w4 = conv_w; p.b4 = conv_b; p.gamma = gamma; p.beta = beta; p.probs = probs; p.scores = scores; p.eps = eps;
   p.N = (int)N; p.C = (int)C; p.H = (int)H; p.T = (int)T; p.W4 = (int)W4; p.UP = (int)up; p.T_M = (int)T_m;
-  p.ys_n = y_strides[0]; p.ys_c = y_strides[1]; p.ys_t = y_strides[2]; p.ys_w = y_strides[3];
+  p.ys_n = y_strides[0]; p.ys_c = y_strides[1]; p.ys_t = y_strides[2]; p.ys_w = y_strides[3]; p.ys_c8 = y_strides[4];
   p.w16 = conv_w16; p.Cp = (int)Cp;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)(N * T));

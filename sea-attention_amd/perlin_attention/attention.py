@@ -217,8 +217,8 @@ class PerlinAttention(nn.Module):
                 and T_M % 4 == 0 and T_M <= 512 and (T_M // 4) % vec == 0
                 and ((T_M // 4 + 63) // 64) * ((self.num_attention_heads + 7) // 8) <= 16)
 
-    def _nhwc_cnn_ok(self, x, body):
-        """Channels-last MFMA conv pipeline: 16-bit data, body = (CausalConv2d k x k, ReLU)* + upsample + 1x1 conv."""
+    def _c8_cnn_ok(self, x, body):
+        """Channel-blocked (C8) MFMA conv pipeline: 16-bit data, body = (CausalConv2d k x k, ReLU)* + upsample + 1x1 conv."""
         if x.dtype not in (torch.float16, torch.bfloat16):
             return False
         W = self.pconfig.attention_predictor_length // 4
@@ -229,8 +229,9 @@ class PerlinAttention(nn.Module):
             if not (isinstance(conv, CausalConv2d) and conv.causal and isinstance(body[i + 1], nn.ReLU)
                     and conv.stride in (1, (1, 1)) and isinstance(conv.dilation, int)
                     and conv.dilation * (conv.kernel_size - 1) == 2 * conv.padding[1]
-                    and conv.in_channels % 8 == 0 and conv.out_channels <= 128
-                    and 16 * ((conv.out_channels + 15) // 16) * (conv.kernel_size ** 2 * ((conv.in_channels + 31) // 32 * 32) + 8) * 2 <= 160 * 1024
+                    and conv.kernel_size in (1, 3)
+                    and conv.in_channels % 8 == 0 and conv.out_channels % 8 == 0 and conv.out_channels <= 128
+                    and 16 * ((conv.out_channels + 15) // 16) * (conv.kernel_size ** 2 * ((conv.in_channels + 31) // 32 * 32) * 2 + 4) <= 160 * 1024
                     and (conv.out_channels + 15) // 16 in (1, 2, 3, 4, 5, 6, 8)):
                 return False
         return True
@@ -301,18 +302,18 @@ class PerlinAttention(nn.Module):
                                                lazy=lambda: self.attention_predictor_dec_row[1](dec))
                 with timer("predictor.cnn"):
                     body = list(keepres.net.children())
-                    nhwc = self._nhwc_cnn_ok(dec, body)
+                    c8 = self._c8_cnn_ok(dec, body)
                     with timer("cnn.lnorm1"):
-                        if nhwc:   # 16-bit data: the CNN runs channels-last on the hand-written MFMA conv kernel
-                            x = ops.split_layernorm_nhwc(dec, self.attention_predictor_dec_row_splits, ln1.weight, ln1.bias, ln1.eps)
+                        if c8:   # 16-bit data: the CNN runs channel-blocked (C8) on the hand-written MFMA conv kernel
+                            x = ops.split_layernorm_c8(dec, self.attention_predictor_dec_row_splits, ln1.weight, ln1.bias, ln1.eps)
                         else:
                             x = ops.split_layernorm(dec, self.attention_predictor_dec_row_splits, ln1.weight, ln1.bias, ln1.eps)
                     with timer("cnn.keepres"):
-                        if nhwc:
+                        if c8:
                             for li_ in range(0, len(body) - 2, 2):                          # (conv, ReLU) pairs
                                 conv = body[li_].module
                                 with timer(body[li_].name):
-                                    x = ops.causal_conv_nhwc(x, conv.weight, conv.bias, conv.kernel_size, conv.dilation,
+                                    x = ops.causal_conv_c8(x, conv.weight, conv.bias, conv.kernel_size, conv.dilation,
                                                              conv.padding[1], relu=True)
                         else:
                             for layer in body[:-2]:                                           # causal convs + ReLUs

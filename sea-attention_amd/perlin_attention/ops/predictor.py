@@ -4,6 +4,8 @@ Not part of the reference's operator package: there these steps are chains of fr
 from ctypes import c_void_p
 from typing import Optional
 
+import weakref
+
 import torch
 
 from ... import _lib
@@ -17,15 +19,21 @@ _prep_cache = {}
 
 
 def _cached(tag, tensors, dtype, build):
-    """Small per-call re-layouts of constant weights (inference): cached on (storage, version, dtype)."""
-    key = (tag, dtype) + tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+    """Small re-layouts of constant weights (inference), cached per source tensor.  An entry is valid only while
+    the very same tensor objects (weak references to the view bases) are alive and unmodified (`_version`): a freed
+    tensor whose address is handed to a new one of the same shape must not hit."""
+    bases = [t._base if t._base is not None else t for t in tensors]
+    key = (tag, dtype) + tuple((id(b), t.storage_offset(), tuple(t.shape), tuple(t.stride())) for b, t in zip(bases, tensors))
     hit = _prep_cache.get(key)
-    if hit is None:
-        if len(_prep_cache) > 256:
-            _prep_cache.clear()
-        hit = build()
-        _prep_cache[key] = hit
-    return hit
+    if hit is not None:
+        refs, versions, value = hit
+        if all(r() is b for r, b in zip(refs, bases)) and versions == [b._version for b in bases]:
+            return value
+    if len(_prep_cache) > 256:
+        _prep_cache.clear()
+    value = build()
+    _prep_cache[key] = ([weakref.ref(b) for b in bases], [b._version for b in bases], value)
+    return value
 
 
 def split_layernorm(x: torch.Tensor, splits: int, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5,
@@ -48,14 +56,20 @@ def split_layernorm(x: torch.Tensor, splits: int, weight: torch.Tensor, bias: to
 def predictor_tail(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor,
                    up: int, T_m: int, eps: float = 1e-5, want_scores: bool = False):
     """upsample(1,up) -> 1x1 conv (pad 1 on width) -> area resize to T_m -> LayerNorm(T_m) -> softmax.
-    y (N,C,T,W4) -> probs (N,H,T,T_m) [, scores].  conv_w (H,C) is the live row of the causal 1x1 kernel."""
+    y (N,C,T,W4) -- or its 5-D C8 form (N,T,C/8,W4,8) -- -> probs (N,H,T,T_m) [, scores].
+    conv_w (H,C) is the live row of the causal 1x1 kernel."""
     lib = _lib.load()
     _lib.require_gpu(y, conv_w, conv_b, ln_w, ln_b)
-    N, C, T, W4 = y.shape
+    if y.dim() == 5:
+        N, T, C8, W4, _e = y.shape
+        assert _e == 8 and y.is_contiguous(), "C8 activations are dense (N, T, C/8, W, 8)"
+        C = C8 * 8
+    else:
+        N, C, T, W4 = y.shape
+        if y.stride(-1) != 1 and y.stride(1) != 1:
+            y = y.contiguous()
     H = conv_w.shape[0]
     assert conv_w.shape == (H, C) and W4 * up == T_m
-    if y.stride(-1) != 1 and y.stride(1) != 1:
-        y = y.contiguous()
     dt = y.dtype
     Hpad = (H + 7) // 8 * 8
 
@@ -73,7 +87,7 @@ def predictor_tail(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.Tensor, 
     cw, cb, g, b, w16, Cp = _cached("tail", (conv_w, conv_b, ln_w, ln_b), dt, build)
     probs = torch.empty((N, H, T, T_m), dtype=dt, device=y.device)
     scores = torch.empty_like(probs) if want_scores else None
-    _lib.check(lib.sea_predictor_tail(_p(y), _lib.dtype_code(dt), N, C, H, T, W4, up, T_m, _lib.strides4(y),
+    _lib.check(lib.sea_predictor_tail(_p(y), _lib.dtype_code(dt), N, C, H, T, W4, up, T_m, _lib.strides5_blocked(y),
                                       _p(cw), _p(cb), _p(w16), Cp, _p(g), _p(b), float(eps), _p(probs), _p(scores),
                                       _lib.stream_ptr()), "sea_predictor_tail")
     return probs, scores
@@ -122,19 +136,31 @@ def performer_value(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torc
     return out
 
 
-def split_layernorm_nhwc(x: torch.Tensor, splits: int, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5):
-    """ChannelSplit + LayerNorm writing channels-last: returns a tensor of logical shape (N, C*splits, T, W) whose
-    memory is (N, T, W, C*splits) (torch.channels_last strides).  16-bit dtypes only."""
+def to_c8(x: torch.Tensor) -> torch.Tensor:
+    """(N, C, T, W) -> the channel-blocked layout of the conv kernels, a dense 5-D tensor (N, T, C/8, W, 8)."""
+    N, C, T, W = x.shape
+    assert C % 8 == 0
+    return x.reshape(N, C // 8, 8, T, W).permute(0, 3, 1, 4, 2).contiguous()
+
+
+def from_c8(y: torch.Tensor) -> torch.Tensor:
+    """Inverse of to_c8: (N, T, C/8, W, 8) -> contiguous (N, C, T, W)."""
+    N, T, C8, W, _e = y.shape
+    return y.permute(0, 2, 4, 1, 3).reshape(N, C8 * 8, T, W).contiguous()
+
+
+def split_layernorm_c8(x: torch.Tensor, splits: int, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5):
+    """ChannelSplit + LayerNorm writing the C8 layout: (N, C, T, splits*W) -> (N, T, C*splits/8, W, 8).  16-bit only."""
     lib = _lib.load()
     _lib.require_gpu(x, weight, bias)
     N, C, T, SW = x.shape
     W = SW // splits
     x = x.contiguous()
     w, b = _cached("ln", (weight, bias), x.dtype, lambda: (weight.to(x.dtype).contiguous(), bias.to(x.dtype).contiguous()))
-    out = torch.empty((N, T, W, C * splits), dtype=x.dtype, device=x.device)
-    _lib.check(lib.sea_split_layernorm_nhwc(_p(x), _lib.dtype_code(x.dtype), N, C, T, splits, W, _p(w), _p(b), float(eps),
-                                            _p(out), _lib.stream_ptr()), "sea_split_layernorm_nhwc")
-    return out.permute(0, 3, 1, 2)
+    out = torch.empty((N, T, C * splits // 8, W, 8), dtype=x.dtype, device=x.device)
+    _lib.check(lib.sea_split_layernorm_c8(_p(x), _lib.dtype_code(x.dtype), N, C, T, splits, W, _p(w), _p(b), float(eps),
+                                          _p(out), _lib.stream_ptr()), "sea_split_layernorm_c8")
+    return out
 
 
 def pack_conv_weight(weight: torch.Tensor, ksize: int, dtype: torch.dtype):
@@ -148,19 +174,20 @@ def pack_conv_weight(weight: torch.Tensor, ksize: int, dtype: torch.dtype):
     return packed.reshape(Cout, ksize * ksize * CinP).contiguous(), CinP
 
 
-def causal_conv_nhwc(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, ksize: int, dilation: int, pad_w: int,
-                     relu: bool = True) -> torch.Tensor:
-    """Causal (along T) dilated conv + bias (+ReLU) on a channels-last tensor of logical shape (N, Cin, T, W).
-    `weight` is the module's (Cout, Cin, 2k-1, k) parameter.  Returns logical (N, Cout, T, W), channels-last memory."""
+def causal_conv_c8(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, ksize: int, dilation: int, pad_w: int,
+                   relu: bool = True) -> torch.Tensor:
+    """Causal (along T) dilated conv + bias (+ReLU) on a C8 activation (N, T, Cin/8, W, 8).
+    `weight` is the module's (Cout, Cin, 2k-1, k) parameter.  Returns (N, T, Cout/8, W, 8)."""
     lib = _lib.load()
     _lib.require_gpu(x, weight, bias)
-    N, Cin, T, W = x.shape
-    assert x.stride(1) == 1 and x.stride(3) == Cin and x.stride(2) == W * Cin, "input must be channels-last dense"
-    Cout = weight.shape[0]
+    N, T, C8, W, _e = x.shape
+    assert _e == 8 and x.is_contiguous(), "input must be a dense C8 activation (N, T, Cin/8, W, 8)"
+    Cin, Cout = C8 * 8, weight.shape[0]
+    assert weight.shape[1] == Cin and Cout % 8 == 0
     (wp, CinP), bf = _cached("conv", (weight, bias), x.dtype,
                              lambda: (pack_conv_weight(weight, ksize, x.dtype), bias.to(x.dtype).float().contiguous()))
-    y = torch.empty((N, T, W, Cout), dtype=x.dtype, device=x.device)
-    _lib.check(lib.sea_causal_conv_nhwc(_p(x), _lib.dtype_code(x.dtype), N, T, W, Cin, Cout, _p(wp), CinP, _p(bf),
-                                        int(ksize), int(dilation), int(pad_w), int(relu), _p(y), _lib.stream_ptr()),
-               "sea_causal_conv_nhwc")
-    return y.permute(0, 3, 1, 2)
+    y = torch.empty((N, T, Cout // 8, W, 8), dtype=x.dtype, device=x.device)
+    _lib.check(lib.sea_causal_conv_c8(_p(x), _lib.dtype_code(x.dtype), N, T, W, Cin, Cout, _p(wp), CinP, _p(bf),
+                                      int(ksize), int(dilation), int(pad_w), int(relu), _p(y), _lib.stream_ptr()),
+               "sea_causal_conv_c8")
+    return y

@@ -41,7 +41,7 @@ def test_split_layernorm(ops, dtype, N, C, T, S, W):
         torch.testing.assert_close(out_g.float().cpu(), torch.nn.functional.gelu(ref), atol=atol * 4, rtol=rtol)
 
 
-@pytest.mark.parametrize("layout", ["nchw", "nhwc"])
+@pytest.mark.parametrize("layout", ["nchw", "nhwc", "c8"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,H,T,T_M", [(2, 12, 128, 64), (1, 32, 300, 256), (1, 40, 64, 256), (1, 4, 50, 128),
                                        (1, 6, 40, 512), (1, 3, 20, 32)])
@@ -61,6 +61,10 @@ def test_predictor_tail(ops, dtype, N, H, T, T_M, layout):
         if C % (4 if dtype == torch.float32 else 8):
             pytest.skip("channels-last rows need C % vec == 0")
         yd = yd.contiguous(memory_format=torch.channels_last)
+    if layout == "c8":                       # the conv kernels' channel-blocked layout (MFMA variant for 16-bit data)
+        if C % 8:
+            pytest.skip("C8 needs C % 8 == 0")
+        yd = ops.to_c8(yd)
     probs, scores = ops.predictor_tail(yd, cw[:, :, 0, 0].to(DEV), cb.to(DEV), lw.to(DEV), lb.to(DEV),
                                        up=4, T_m=T_M, want_scores=True)
     assert probs.dtype == dtype and tuple(probs.shape) == (N, H, T, T_M)
@@ -158,37 +162,43 @@ def _causal_conv_ref(x, weight, bias, k, dil, pad_w, relu):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,Cin,Cout,T,W", [(2, 64, 64, 40, 64), (1, 24, 24, 33, 16), (1, 80, 80, 20, 64), (1, 64, 64, 9, 32),
                                             (1, 32, 48, 17, 128)])
-def test_causal_conv_nhwc(ops, dtype, N, Cin, Cout, T, W):
+def test_causal_conv_c8(ops, dtype, N, Cin, Cout, T, W):
     g = torch.Generator().manual_seed(3)
     x = torch.randn((N, Cin, T, W), generator=g).to(dtype)
     wt = (torch.randn((Cout, Cin, 5, 3), generator=g) * (Cin * 9) ** -0.5).to(dtype)
     b = (torch.randn(Cout, generator=g) * 0.1).to(dtype)
     for relu in (True, False):
         ref = _causal_conv_ref(x, wt, b, 3, 2, 2, relu)
-        xd = x.to(DEV).contiguous(memory_format=torch.channels_last)
-        y = ops.causal_conv_nhwc(xd, wt.to(DEV), b.to(DEV), 3, 2, 2, relu=relu)
-        assert tuple(y.shape) == (N, Cout, T, W) and y.stride(1) == 1
-        torch.testing.assert_close(y.float().cpu(), ref, atol=2e-2, rtol=2e-2)
+        xd = ops.to_c8(x.to(DEV))
+        y = ops.causal_conv_c8(xd, wt.to(DEV), b.to(DEV), 3, 2, 2, relu=relu)
+        assert tuple(y.shape) == (N, T, Cout // 8, W, 8) and y.is_contiguous()
+        torch.testing.assert_close(ops.from_c8(y).float().cpu(), ref, atol=2e-2, rtol=2e-2)
     # causality along T: future rows do not leak
     x2 = x.clone(); x2[:, :, T // 2:] += 50
-    y1 = ops.causal_conv_nhwc(x.to(DEV).contiguous(memory_format=torch.channels_last), wt.to(DEV), b.to(DEV), 3, 2, 2)
-    y2 = ops.causal_conv_nhwc(x2.to(DEV).contiguous(memory_format=torch.channels_last), wt.to(DEV), b.to(DEV), 3, 2, 2)
-    assert torch.equal(y1[:, :, :T // 2], y2[:, :, :T // 2])
+    y1 = ops.causal_conv_c8(ops.to_c8(x.to(DEV)), wt.to(DEV), b.to(DEV), 3, 2, 2)
+    y2 = ops.causal_conv_c8(ops.to_c8(x2.to(DEV)), wt.to(DEV), b.to(DEV), 3, 2, 2)
+    assert torch.equal(y1[:, :T // 2], y2[:, :T // 2])
+    # 1x1 kernel (no taps to shift): plain channel GEMM per pixel
+    w1 = (torch.randn((Cout, Cin, 1, 1), generator=g) * Cin ** -0.5).to(dtype)
+    y = ops.causal_conv_c8(ops.to_c8(x.to(DEV)), w1.to(DEV), b.to(DEV), 1, 1, 0, relu=False)
+    ref1 = torch.nn.functional.conv2d(x.float(), w1.float(), b.float())
+    torch.testing.assert_close(ops.from_c8(y).float().cpu(), ref1, atol=2e-2, rtol=2e-2)
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,C,T,S,W", [(2, 12, 40, 2, 16), (1, 32, 70, 2, 64), (1, 40, 9, 2, 64), (1, 4, 5, 2, 128)])
-def test_split_layernorm_nhwc(ops, dtype, N, C, T, S, W):
+def test_split_layernorm_c8(ops, dtype, N, C, T, S, W):
     g = torch.Generator().manual_seed(0)
     x = (torch.randn((N, C, T, S * W), generator=g) * 2 + 0.3).to(dtype)
     w = (torch.rand(W, generator=g) + 0.5).to(dtype)
     b = torch.randn(W, generator=g).to(dtype)
     a = ops.split_layernorm(x.to(DEV), S, w.to(DEV), b.to(DEV), 1e-5)
-    c = ops.split_layernorm_nhwc(x.to(DEV), S, w.to(DEV), b.to(DEV), 1e-5)
-    assert tuple(c.shape) == tuple(a.shape) and c.stride(1) == 1
+    c = ops.split_layernorm_c8(x.to(DEV), S, w.to(DEV), b.to(DEV), 1e-5)
+    assert tuple(c.shape) == (N, T, C * S // 8, W, 8)
+    c = ops.from_c8(c)
     # same arithmetic, different layout; the two kernels may contract one FMA differently: <= 1 ulp of the 16-bit type
-    torch.testing.assert_close(a.float(), c.contiguous().float(), atol=1e-3, rtol=8e-3)
-    assert (a != c.contiguous()).float().mean().item() < 1e-3
+    torch.testing.assert_close(a.float(), c.float(), atol=1e-3, rtol=8e-3)
+    assert (a != c).float().mean().item() < 1e-3
 
 
 def test_predictor_tail_accepts_channels_last(ops):
@@ -244,12 +254,12 @@ def test_estimator_kernels_are_bitwise_reproducible(ops):
     a = ops.performer_value(q, k, v, pos, fa.projection_matrix)
     for _ in range(3):
         assert torch.equal(a, ops.performer_value(q, k, v, pos, fa.projection_matrix))
-    y = torch.relu(torch.randn(N, 2 * H, T, T_M // 4, device=DEV)).bfloat16().contiguous(memory_format=torch.channels_last)
+    y = ops.to_c8(torch.relu(torch.randn(N, 2 * H, T, T_M // 4, device=DEV)).bfloat16())
     cw = torch.randn(H, 2 * H, device=DEV).bfloat16(); cb = torch.zeros(H, device=DEV).bfloat16()
     lw = torch.ones(T_M, device=DEV).bfloat16(); lb = torch.zeros(T_M, device=DEV).bfloat16()
     p0, _ = ops.predictor_tail(y, cw, cb, lw, lb, up=4, T_m=T_M)
     wt = torch.randn(2 * H, 2 * H, 5, 3, device=DEV).bfloat16() * 0.05; b = torch.zeros(2 * H, device=DEV).bfloat16()
-    c0 = ops.causal_conv_nhwc(y, wt, b, 3, 2, 2)
+    c0 = ops.causal_conv_c8(y, wt, b, 3, 2, 2)
     for _ in range(3):
         assert torch.equal(p0, ops.predictor_tail(y, cw, cb, lw, lb, up=4, T_m=T_M)[0])
-        assert torch.equal(c0, ops.causal_conv_nhwc(y, wt, b, 3, 2, 2))
+        assert torch.equal(c0, ops.causal_conv_c8(y, wt, b, 3, 2, 2))

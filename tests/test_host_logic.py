@@ -228,3 +228,25 @@ def test_bench_regions_and_tracetree():
             pass
     assert set(b.todict()) == {"outer", "inner"}
     assert "> outer" in b.format_tracetree() and "inner" in b.format_tracetree()
+
+
+def test_weight_prep_cache_is_keyed_on_tensor_identity():
+    """A freed weight whose address is reused by a new tensor of the same shape must not hit the re-layout cache;
+    views of one live parameter (fresh view objects per call) must."""
+    from sea_attention_amd.perlin_attention.ops import predictor as P
+    P._prep_cache.clear()
+    builds = []
+    def prep(t):
+        return P._cached("t", (t,), torch.float32, lambda: (builds.append(1), t.clone())[1])
+    for i in range(8):                         # same shape, same allocator bucket: addresses get recycled
+        t = torch.full((64, 64), float(i))
+        assert torch.equal(prep(t), t)
+        del t
+    w = torch.nn.Parameter(torch.randn(4, 6, 1, 1))
+    n0 = len(builds)
+    a = prep(w[:, :, 0, 0]); b = prep(w[:, :, 0, 0])
+    assert a is b and len(builds) == n0 + 1
+    with torch.no_grad():
+        w.mul_(2)                              # in-place update bumps the version: rebuilt
+    c = prep(w[:, :, 0, 0])
+    assert len(builds) == n0 + 2 and torch.equal(c, w[:, :, 0, 0])
