@@ -97,85 +97,88 @@ __global__ __launch_bounds__(CONV_WAVES * 64, (NT <= 4 ? 3 : 2)) void causal_con
   const int C8i = p.Cin >> 3, C8o = p.Cout >> 3;
   const unsigned img_bytes = (unsigned)p.T * (unsigned)p.W * (unsigned)p.Cin * (unsigned)sizeof(T);
   const T* wlane = sW + (lg * ROWS + li) * 8;                // + st*4*ROWS*8 + nt*16*8
-  const int64_t nwork = (int64_t)p.N * p.T * segs;
-  for (int64_t work = (int64_t)blockIdx.x * CONV_WAVES + wv; work < nwork; work += (int64_t)gridDim.x * CONV_WAVES) {
-    const int seg = (int)(work % segs);
-    const int64_t nt_ = work / segs;
-    const int t = (int)(nt_ % p.T), n = (int)(nt_ / p.T);
-    const int w0 = seg * 64;
+  const int ngrp = KS * kchunks;
+  const int nwork = p.N * p.T * segs;                        // launcher: < 2^31
+  // a workgroup owns a contiguous run of rows: a row's two upper tap rows were fetched by the previous pass of
+  // the same workgroup (same XCD, same L2), only the newest row is a compulsory miss
+  const int per = (nwork + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int wend = min(nwork, ((int)blockIdx.x + 1) * per);
+
+  // A cursor walks this wave's (row segment, tap-row x channel-chunk group) sequence.  The load cursor runs
+  // ahead of the MFMA cursor ACROSS row boundaries, so the first fragments of the next row are already in flight
+  // while the current row's epilogue stores drain.  Everything in it is wave-uniform (kept in SGPRs).
+  struct Cursor {
+    int work, grp, ti, cci, t, w0;
+    int row_soff;                                            // byte offset of (tap row tr, block 0) in the image
+    __amdgpu_buffer_rsrc_t rsrc;                             // the image of batch entry n
+    int64_t ybase;                                           // element offset of output row (n, t)
+    bool live;
+  };
+  const int row_bytes = p.W * p.Cin * (int)sizeof(T);
+  auto open_work = [&](Cursor& c) {                          // position on the first live group of c.work
+    c.live = c.work < wend;
+    const int wk = c.live ? c.work : 0;
+    const int nt_ = wk / segs;
+    const int seg = wk - nt_ * segs;
+    const int n = __builtin_amdgcn_readfirstlane(nt_ / p.T);
+    c.t = __builtin_amdgcn_readfirstlane(nt_ - n * p.T);
+    c.w0 = __builtin_amdgcn_readfirstlane(seg * 64);
     const T* xn = reinterpret_cast<const T*>(p.x) + (int64_t)n * p.T * p.W * p.Cin;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xn), 0, (int)img_bytes, 0x00020000);
+    c.rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(xn), 0, (int)img_bytes, 0x00020000);
+    c.ybase = ((int64_t)n * p.T + c.t) * p.W * p.Cout;
+    int ti0 = 0;                                             // tap rows entirely in the causal padding: skipped
+    while (ti0 < KS - 1 && c.t + p.dil * (ti0 - (KS - 1)) < 0) ++ti0;
+    c.ti = ti0; c.cci = 0; c.grp = ti0 * kchunks;
+    c.row_soff = (c.t + p.dil * (ti0 - (KS - 1))) * row_bytes;   // tr >= 0 for every group the cursor visits
+  };
+  auto advance = [&](Cursor& c) {
+    ++c.grp;
+    if (++c.cci == kchunks) {
+      c.cci = 0; c.row_soff += p.dil * row_bytes;
+      if (++c.ti == KS) { c.work += CONV_WAVES; open_work(c); }
+    }
+  };
+  auto issue = [&](const Cursor& c, int tj, cu4 (&a)[4]) {   // request the 4 pixel fragments of step (c.grp, tj)
+    const int soff = c.row_soff + c.cci * 4 * p.W * 16;      // byte offset of the (row, 4-block chunk) slab
+    // dead cursor / K-padding blocks: an all-ones-ish mask OR-ed into the offset keeps it beyond num_records
+    // (pure arithmetic on purpose: a boolean here gets jump-threaded into divergent load paths)
+    const unsigned dead = (c.live && (c.cci * 4 + lg < C8i)) ? 0u : CONV_OOB;
+    const int px = c.w0 + li;                                // this lane's pixel of N-tile 0
+    const unsigned lbase = (unsigned)((lg * p.W + px) * 16) | dead;
+    const int dw = p.dil * tj - p.pad_w;                     // column shift of this tap (pixels outside the row: zeros;
+#pragma unroll                                               //  pixels >= W of a ragged last segment are never stored)
+    for (int mt = 0; mt < 4; ++mt) {
+      const bool in_row = (unsigned)(px + mt * 16 + dw) < (unsigned)p.W;
+      a[mt] = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(in_row ? lbase + (unsigned)((mt * 16 + dw) * 16) : CONV_OOB), soff, 0);
+    }
+  };
 
-    const int px = w0 + li;                                  // this lane's pixel of M-tile 0
-    const unsigned lbase = (unsigned)((lg * p.W + px) * 16);  // its byte offset inside one (row, 4-block chunk) slab
-
-    cf4 acc[NT][4];
+  cf4 acc[NT][4];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = cf4{0.f, 0.f, 0.f, 0.f};
+  // one k-step = NT x 4 MFMAs.  wf0 carries the first weight fragment across steps: it is read from LDS during
+  // the previous step, so a step starts its MFMAs without an exposed LDS round trip.
+  auto wptr = [&](int grp, int tj) { return wlane + (grp * KS + tj) * (4 * ROWS * 8); };
+  auto compute = [&](const T* wst, const T* wnext, const cu4 (&a)[4], uint4& wf0) {
+    uint4 wf[NT];
+    wf[0] = wf0;
+#pragma unroll
+    for (int nt = 1; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const uint4*>(wst + nt * 128);
+    wf0 = *reinterpret_cast<const uint4*>(wnext);
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-      for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = cf4{0.f, 0.f, 0.f, 0.f};
-
-    // tap rows that lie entirely in the causal padding are a prefix of the step order (wave-uniform skip)
-    int ti0 = 0;
-    while (ti0 < KS && t + p.dil * (ti0 - (KS - 1)) < 0) ++ti0;
-
-    // step cursor: (ti, cci) group + compile-time tj
-    auto issue = [&](int grp, int tj, cu4 (&a)[4]) {        // grp = ti*kchunks + cci
-      const int ngrp = KS * kchunks;
-      const bool live = grp < ngrp;
-      const int gc = live ? grp : ngrp - 1;
-      const int ti = gc / kchunks, cci = gc - ti * kchunks;
-      const int tr = t + p.dil * (ti - (KS - 1));
-      const int soff = ((tr * C8i + cci * 4) * p.W) * 16;   // bytes; tr >= 0 for every live group
-      const bool lane_live = live && (cci * 4 + lg < C8i);
-      const int dw = p.dil * tj - p.pad_w;                   // column shift of this tap (pixels outside the row: zeros;
-#pragma unroll                                               //  pixels >= W of a ragged last segment are never stored)
-      for (int mt = 0; mt < 4; ++mt) {
-        const bool ok = lane_live && (unsigned)(px + mt * 16 + dw) < (unsigned)p.W;
-        a[mt] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(ok ? lbase + (unsigned)((mt * 16 + dw) * 16) : CONV_OOB),
-                                                      live ? soff : 0, 0);
-      }
-    };
-    auto compute = [&](int grp, int tj, const cu4 (&a)[4]) {   // a dead group multiplies zeros: clamp its weight index
-      const int gc = grp < KS * kchunks ? grp : KS * kchunks - 1;
-      const T* wst = wlane + (gc * KS + tj) * (4 * ROWS * 8);
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) {
-        const uint4 wf = *reinterpret_cast<const uint4*>(wst + nt * 128);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = Mfma16<T>::run(wf, a[mt], acc[nt][mt]);
-      }
-    };
-
-    const int ngrp = KS * kchunks;
-    if constexpr (KS == 3) {
-      // 3 steps per group, prefetch distance 1, two register buffers whose roles swap every group: the body is two
-      // groups = 6 straight-line steps (an odd group count runs one dead group on zeros)
-      cu4 a0[4], a1[4];
-      int grp = ti0 * kchunks;
-      issue(grp, 0, a0);
-#pragma unroll 1
-      for (; grp < ngrp; grp += 2) {
-        issue(grp, 1, a1);     compute(grp, 0, a0);
-        issue(grp, 2, a0);     compute(grp, 1, a1);
-        issue(grp + 1, 0, a1); compute(grp, 2, a0);
-        issue(grp + 1, 1, a0); compute(grp + 1, 0, a1);
-        issue(grp + 1, 2, a1); compute(grp + 1, 1, a0);
-        issue(grp + 2, 0, a0); compute(grp + 1, 2, a1);
-      }
-    } else {
-      cu4 a0[4];
-      for (int grp = ti0 * kchunks; grp < ngrp; ++grp)
-#pragma unroll
-        for (int tj = 0; tj < KS; ++tj) { issue(grp, tj, a0); compute(grp, tj, a0); }
-    }
-
-    // ---- epilogue: bias (+ ReLU), C8 store: lane = pixel (mt, li), channels lg*4*NT + nt*4 + r ------------
-    T* yn = reinterpret_cast<T*>(p.y) + ((int64_t)n * p.T + t) * p.W * p.Cout;
+      for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = Mfma16<T>::run(wf[nt], a[mt], acc[nt][mt]);
+  };
+  // bias (+ ReLU), C8 store: lane = pixel (mt, li), channels lg*4*NT + nt*4 + r; then clear the accumulators
+  auto epilogue = [&](const Cursor& c) {
+    T* yn = reinterpret_cast<T*>(p.y) + c.ybase;
     const int cbase = lg * 4 * NT;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-      const int wpix = w0 + mt * 16 + li;
+      const int wpix = c.w0 + mt * 16 + li;
       unsigned pk[2 * NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -184,6 +187,7 @@ __global__ __launch_bounds__(CONV_WAVES * 64, (NT <= 4 ? 3 : 2)) void causal_con
         if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
         pk[2 * nt] = pack2<T>(v0, v1);
         pk[2 * nt + 1] = pack2<T>(v2, v3);
+        acc[nt][mt] = cf4{0.f, 0.f, 0.f, 0.f};
       }
       if (wpix < p.W) {
         if constexpr ((NT & 1) == 0) {           // whole 8-channel blocks per lane: 16-byte stores
@@ -202,6 +206,45 @@ __global__ __launch_bounds__(CONV_WAVES * 64, (NT <= 4 ? 3 : 2)) void causal_con
           }
         }
       }
+    }
+  };
+
+  Cursor cc;                                                 // MFMA cursor
+  cc.work = (int)blockIdx.x * per + wv;
+  open_work(cc);
+  if constexpr (KS == 3) {
+    // three register buffers, one per column tap: a fragment is requested two steps (32 MFMAs) before its use
+    Cursor cl = cc;                                          // load cursor, one group ahead after the prologue
+    cu4 a0[4], a1[4], a2[4];
+    issue(cl, 0, a0);  __builtin_amdgcn_sched_barrier(0);   // (program order = queue order the waits are counted in)
+    issue(cl, 1, a1);  __builtin_amdgcn_sched_barrier(0);
+    uint4 wf0 = *reinterpret_cast<const uint4*>(wptr(cc.grp, 0));
+#pragma unroll 1
+    while (cc.live) {
+      // (scheduling fences: the loads must leave BEFORE the MFMA block they overlap, not sink below it)
+      const T* w0p = wptr(cc.grp, 0);
+      issue(cl, 2, a2);  __builtin_amdgcn_sched_barrier(0);
+      compute(w0p, w0p + 4 * ROWS * 8, a0, wf0);  __builtin_amdgcn_sched_barrier(0);
+      advance(cl);
+      issue(cl, 0, a0);  __builtin_amdgcn_sched_barrier(0);
+      compute(w0p + 4 * ROWS * 8, w0p + 8 * ROWS * 8, a1, wf0);  __builtin_amdgcn_sched_barrier(0);
+      issue(cl, 1, a1);  __builtin_amdgcn_sched_barrier(0);
+      compute(w0p + 8 * ROWS * 8, wptr(cl.grp, 0), a2, wf0);  __builtin_amdgcn_sched_barrier(0);   // cl == next(cc)
+      if (cc.ti == KS - 1 && cc.cci == kchunks - 1) epilogue(cc);   // wave-uniform
+      advance(cc);
+    }
+  } else {
+    cu4 a0[4];
+#pragma unroll 1
+    while (cc.live) {
+#pragma unroll
+      for (int tj = 0; tj < KS; ++tj) {
+        issue(cc, tj, a0);
+        uint4 wf0 = *reinterpret_cast<const uint4*>(wptr(cc.grp, tj));
+        compute(wptr(cc.grp, tj), wptr(cc.grp, tj), a0, wf0);
+      }
+      if (cc.ti == KS - 1 && cc.cci == kchunks - 1) epilogue(cc);
+      advance(cc);
     }
   }
 }
@@ -273,8 +316,9 @@ static int launch_conv(const ConvParams& p, hipStream_t s) {
   if (lds > 160 * 1024) return SEA_EUNSUPPORTED;
   if ((int64_t)p.T * p.W * p.Cin * (int64_t)sizeof(T) >= (int64_t)(1u << 30)) return SEA_EUNSUPPORTED;   // 32-bit buffer offsets
   const int64_t nwork = (int64_t)p.N * p.T * ((p.W + 63) / 64);
+  if (nwork >= (int64_t)1 << 30) return SEA_EUNSUPPORTED;
   int64_t blocks = (nwork + CONV_WAVES - 1) / CONV_WAVES;
-  if (blocks > 256 * 4) blocks = 256 * 4;      // persistent-ish: weights are staged once per workgroup
+  if (blocks > 256 * 2) blocks = 256 * 2;      // persistent: two resident workgroups per CU, weights staged once each
   dim3 grid((unsigned)blocks), block(CONV_WAVES * 64);
 #define SEA_CONV(NTV, KSV)                                                                                          \
   do {                                                                                                              \
