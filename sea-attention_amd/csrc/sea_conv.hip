@@ -97,7 +97,6 @@ __global__ __launch_bounds__(CONV_WAVES * 64, (NT <= 4 ? 3 : 2)) void causal_con
   const int C8i = p.Cin >> 3, C8o = p.Cout >> 3;
   const unsigned img_bytes = (unsigned)p.T * (unsigned)p.W * (unsigned)p.Cin * (unsigned)sizeof(T);
   const T* wlane = sW + (lg * ROWS + li) * 8;                // + st*4*ROWS*8 + nt*16*8
-  const int ngrp = KS * kchunks;
   const int nwork = p.N * p.T * segs;                        // launcher: < 2^31
   // a workgroup owns a contiguous run of rows: a row's two upper tap rows were fetched by the previous pass of
   // the same workgroup (same XCD, same L2), only the newest row is a compulsory miss

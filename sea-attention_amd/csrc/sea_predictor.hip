@@ -449,6 +449,78 @@ __global__ __launch_bounds__(1024) void cumavg_kernel(const T* v, T* out, int Tn
   }
 }
 
+// 16-bit fast path (D = 8*FG, FG | 64): a thread owns 8 adjacent features (one 16-byte vector) and a run of
+// consecutive rows; a wave is RL = 64/FG row-lanes x FG feature groups, 16 waves split T.  Pass 1 sums the runs,
+// the run prefixes come from RL-1 shuffles inside the wave plus the 16 wave totals in LDS, pass 2 re-reads the
+// rows (L2 / Infinity Cache) and writes the averages.  Every load and store moves whole 128-byte lines.
+template <typename T, int FG>
+__global__ __launch_bounds__(1024) void cumavg_vec_kernel(const T* v, T* out, int Tn, int64_t vs_n, int64_t vs_h, int64_t vs_t,
+                                                         int H) {
+  constexpr int D = FG * 8, RL = 64 / FG;
+  __shared__ float s_tot[16][D];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int fg = lane % FG, r = lane / FG;
+  const int nh = blockIdx.x;
+  const int n = nh / H, h = nh - n * H;
+  const int seg_len = (Tn + 16 * RL - 1) / (16 * RL);
+  const int t0 = min(Tn, (wv * RL + r) * seg_len), t1 = min(Tn, t0 + seg_len);
+  const T* vb = v + n * vs_n + h * vs_h + fg * 8;
+  T* ob = out + (int64_t)nh * Tn * D + fg * 8;
+  float s[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s[j] = 0.f;
+  {
+    int t = t0;
+    for (; t + 4 <= t1; t += 4) {                       // 4 independent 16-byte loads in flight
+      uint4 x[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const uint4*>(vb + (int64_t)(t + u) * vs_t);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float f[8];
+        unpack16<T>(x[u], f);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] += f[j];
+      }
+    }
+    for (; t < t1; ++t) {
+      float f[8];
+      unpack16<T>(*reinterpret_cast<const uint4*>(vb + (int64_t)t * vs_t), f);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s[j] += f[j];
+    }
+  }
+  float run[8];                                          // exclusive prefix over the row-lanes of this wave
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float inc = s[j];
+#pragma unroll
+    for (int k = 1; k < RL; k <<= 1) {
+      const float up = __shfl_up(inc, k * FG);
+      if (r >= k) inc += up;
+    }
+    run[j] = inc - s[j];
+    if (r == RL - 1) s_tot[wv][fg * 8 + j] = inc;
+  }
+  __syncthreads();
+  for (int w = 0; w < wv; ++w) {
+    const float4 a = *reinterpret_cast<const float4*>(&s_tot[w][fg * 8]);
+    const float4 b = *reinterpret_cast<const float4*>(&s_tot[w][fg * 8 + 4]);
+    run[0] += a.x; run[1] += a.y; run[2] += a.z; run[3] += a.w;
+    run[4] += b.x; run[5] += b.y; run[6] += b.z; run[7] += b.w;
+  }
+  for (int t = t0; t < t1; ++t) {
+    float f[8];
+    unpack16<T>(*reinterpret_cast<const uint4*>(vb + (int64_t)t * vs_t), f);
+    const float den = (float)(t + 1);
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { run[j] += f[j]; o[j] = run[j] / den; }
+    *reinterpret_cast<uint4*>(ob + (int64_t)t * D) =
+        make_uint4(pack2<T>(o[0], o[1]), pack2<T>(o[2], o[3]), pack2<T>(o[4], o[5]), pack2<T>(o[6], o[7]));
+  }
+}
+
 }  // namespace sea
 
 using namespace sea;
@@ -592,6 +664,19 @@ extern "C" int sea_cumavg(const void* v, int dtype, int64_t N, int64_t H, int64_
   SEA_REQUIRE(N * H * dslabs < (1ll << 31), SEA_EUNSUPPORTED, "%s: grid too large", nm);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)(N * H * dslabs)), block(1024);
+  // 16-byte vector path: 16-bit data, D in {32, 64, 128}, everything 16-byte aligned
+  const bool vec = dtype != SEA_F32 && (D == 32 || D == 64 || D == 128) && v_strides[0] % 8 == 0 && v_strides[1] % 8 == 0 &&
+                   v_strides[2] % 8 == 0 && (((uintptr_t)v | (uintptr_t)out) & 15) == 0;
+  if (vec) {
+    dim3 g2((unsigned)(N * H));
+#define SEA_CUMAVG(TT, FGV) hipLaunchKernelGGL((cumavg_vec_kernel<TT, FGV>), g2, block, 0, s, (const TT*)v, (TT*)out, (int)T, \
+                                               v_strides[0], v_strides[1], v_strides[2], (int)H)
+    if (dtype == SEA_F16) { if (D == 32) SEA_CUMAVG(__half, 4); else if (D == 64) SEA_CUMAVG(__half, 8); else SEA_CUMAVG(__half, 16); }
+    else { if (D == 32) SEA_CUMAVG(__hip_bfloat16, 4); else if (D == 64) SEA_CUMAVG(__hip_bfloat16, 8); else SEA_CUMAVG(__hip_bfloat16, 16); }
+#undef SEA_CUMAVG
+    SEA_CHECK_LAUNCH(nm);
+    return SEA_OK;
+  }
   if (dtype == SEA_F32)
     hipLaunchKernelGGL((cumavg_kernel<float>), grid, block, 0, s, (const float*)v, (float*)out, (int)T, (int)D, v_strides[0],
                        v_strides[1], v_strides[2], (int)H, dslabs);

@@ -459,18 +459,22 @@ struct EmitParams {
   float* values_out;
 };
 
-// One workgroup per row.  The kept pixels of the row are first compacted, in order, into an LDS list
-// (pixel id, output offset); then groups of G lanes (G = next pow2 of the widest pixel of this row) expand one
-// pixel each, so a store instruction writes 256/G complete, adjacent runs: contiguous 4-byte stores instead of a
-// per-lane serial walk.  Rows are processed in chunks of 4096 pixels (128 bit-mask words).
-constexpr int EM_CHUNK_WORDS = 128;
-constexpr int EM_CHUNK_PIX = EM_CHUNK_WORDS * 32;
+// One workgroup per row.
+//   1. the T_m+1 pixel bounds of this row (round_half_away(m * w_t / T_m)) go to LDS once -- every head shares them;
+//   2. each thread owns 32-pixel mask words (word w, w+256, ...): it counts the entries its kept pixels expand to;
+//   3. one block scan turns the counts into output offsets (flat order = head-major, pixels ascending);
+//   4. the threads write their runs (keys descending inside a pixel, causal_resize_m_to_t.py:569) into an LDS
+//      window of the row, which is flushed with fully coalesced stores.
+// A pixel whose width exceeds max_k is thinned with the reference's fp32 step arithmetic; every other pixel is
+// plain integer work (ids stay below 2^24, so the reference's fp32 ids are exact integers there).
+constexpr int EM_TABLE = 1024;                        // pixel-bound table (T_m <= 1024; else bounds on the fly)
+constexpr int EM_WIN = 4096;                          // entries staged per flush
 
 template <typename I>
 __global__ __launch_bounds__(TK_THREADS) void csr_emit_kernel(EmitParams p) {
-  __shared__ long long s_wave[TK_WAVES];
-  __shared__ unsigned short s_pix[EM_CHUNK_PIX];      // pixel id relative to the chunk
-  __shared__ int s_off[EM_CHUNK_PIX + 1];             // output offset of the pixel inside the row
+  __shared__ int s_wave[TK_WAVES];
+  __shared__ int s_bound[EM_TABLE + 1];
+  __shared__ int s_out[EM_WIN];
   const int tid = threadIdx.x;
   const int row = blockIdx.x;
   const int n = row / p.T_dst, t = row - n * p.T_dst;
@@ -483,73 +487,78 @@ __global__ __launch_bounds__(TK_THREADS) void csr_emit_kernel(EmitParams p) {
   const uint32_t* bits = p.bits + (int64_t)row * p.W;
   const int w_t = row_width(t, p.T_dst, p.T_src, p.is_causal);
   const float scale = interp_scale(w_t, p.T_m);
-  int wmax = (w_t + p.T_m - 1) / p.T_m;               // widest pixel of this row, after the max_k clamp
-  wmax = wmax < p.max_k ? wmax : p.max_k;
-  int G = 1;
-  while (G < wmax) G <<= 1;                           // lanes per pixel (<= 256: max_k is far below)
-  if (G > TK_THREADS) G = TK_THREADS;
+  const bool table = p.T_m <= EM_TABLE;
+  if (table)
+    for (int m = tid; m <= p.T_m; m += TK_THREADS) s_bound[m] = (int)interp_bound(m, scale);
+  __syncthreads();
+  auto bnd = [&](int m) { return table ? s_bound[m] : (int)interp_bound(m, scale); };
+  const bool aligned = (p.T_m & 31) == 0;             // a mask word never straddles two heads
 
-  int carry = 0;                                      // entries emitted by earlier chunks of this row
-  for (int w0 = 0; w0 < p.W; w0 += EM_CHUNK_WORDS) {
-    // ---- compaction: thread owns one 16-pixel half word --------------------------------------------------
-    const int wi = w0 + (tid >> 1);
-    uint32_t half = 0;
-    if (wi < p.W) half = (bits[wi] >> (16 * (tid & 1))) & 0xFFFFu;
-    const int fbase = (tid >> 1) * 32 + (tid & 1) * 16;    // first pixel of this half word, relative to the chunk
-    int npix = __popc(half), nent = 0;
-    {
-      uint32_t m = half;
-      while (m) {
-        const int bit = __ffs(m) - 1;
-        m &= m - 1;
-        const int b = (w0 * 32 + fbase + bit) % p.T_m;
-        const int w = (int)(interp_bound(b + 1, scale) - interp_bound(b, scale));
-        nent += w < p.max_k ? w : p.max_k;
-      }
+  // the row is walked in passes of 256 mask words (flat order); carry = entries of the earlier passes
+  int carry = 0;
+  for (int w0 = 0; w0 < p.W; w0 += TK_THREADS) {
+    const int wi = w0 + tid;
+    uint32_t word = wi < p.W ? bits[wi] : 0u;
+    const int f0 = wi * 32;
+    const int h0 = f0 / p.T_m, b0 = f0 - h0 * p.T_m;
+    int nent = 0;
+    for (uint32_t m = word; m;) {
+      const int bit = __ffs(m) - 1;
+      m &= m - 1;
+      int b = b0 + bit;
+      if (!aligned) b %= p.T_m;
+      const int wd = bnd(b + 1) - bnd(b);
+      nent += wd < p.max_k ? wd : p.max_k;
     }
-    long long total;
-    const long long excl = block_excl_scan64(((long long)npix << 32) | (long long)nent, s_wave, &total);   // pixels | entries
-    {
-      int pos = (int)(excl >> 32), off = carry + (int)(excl & 0xFFFFFFFFll);
-      uint32_t m = half;
-      while (m) {
-        const int bit = __ffs(m) - 1;
-        m &= m - 1;
-        const int b = (w0 * 32 + fbase + bit) % p.T_m;
-        int w = (int)(interp_bound(b + 1, scale) - interp_bound(b, scale));
-        w = w < p.max_k ? w : p.max_k;
-        s_pix[pos] = (unsigned short)(fbase + bit);
-        s_off[pos] = off;
-        ++pos;
-        off += w;
+    int total;
+    const int excl = block_excl_scan(nent, s_wave, &total);
+#if SEA_EXP != 11
+    // windows of the row covered by this pass: [carry, carry + total)
+    for (int win = (carry / EM_WIN) * EM_WIN; win < carry + total; win += EM_WIN) {
+      int off = carry + excl;                                       // row-relative offset of this thread's first entry
+      if (nent > 0 && off < win + EM_WIN && off + nent > win) {
+        for (uint32_t m = word; m;) {
+          const int bit = __ffs(m) - 1;
+          m &= m - 1;
+          int h = h0, b = b0 + bit;
+          if (!aligned) { const int q = b / p.T_m; h += q; b -= q * p.T_m; }
+          const int lo = bnd(b), hi = bnd(b + 1);
+          const int wd = hi - lo;
+          const int hb = h * p.T_src;
+          if (wd <= p.max_k) {
+            for (int j = 0; j < wd; ++j) {
+              const int o = off + j - win;
+              if ((unsigned)o < (unsigned)EM_WIN) s_out[o] = hb + hi - 1 - j;
+            }
+            off += wd;
+          } else {                                                  // thinned pixel: the reference's fp32 stepping
+            const float rs = (float)lo + (float)hb, re = (float)hi + (float)hb;
+            const float step = __fdiv_rn(re - rs, (float)p.max_k);
+            for (int j = 0; j < p.max_k; ++j) {
+              const int o = off + j - win;
+              if ((unsigned)o < (unsigned)EM_WIN) s_out[o] = (int)((re - (float)(int)__fmul_rn((float)j, step)) - 1.0f);
+            }
+            off += p.max_k;
+          }
+        }
       }
-    }
-    const int S = (int)(total >> 32);
-    const int chunk_entries = (int)(total & 0xFFFFFFFFll);
-    if (tid == 0) s_off[S] = carry + chunk_entries;
-    __syncthreads();
-    // ---- expansion: G lanes per pixel, keys descending inside a pixel (causal_resize_m_to_t.py:569) -----------
-    const int j = tid & (G - 1);
-    for (int i = tid / G; i < S; i += TK_THREADS / G) {
-      const int f = w0 * 32 + (int)s_pix[i];
-      const int o = s_off[i];
-      const int cnt = s_off[i + 1] - o;
-      if (j < cnt) {
-        const int h = f / p.T_m, b = f - h * p.T_m;
-        const float vs = interp_bound(b, scale), ve = interp_bound(b + 1, scale);
-        const float hbase = (float)(h * p.T_src);
-        const float rs = vs + hbase, re = ve + hbase;
-        const float step = __fdiv_rn(re - rs, (float)cnt);
-        const float c = (re - (float)(int)__fmul_rn((float)j, step)) - 1.0f;
-        const int64_t dst = row_beg + o + j;
+      __syncthreads();
+#if SEA_EXP != 12
+      // flush the part of the window this pass has completed: [max(win, carry), min(win + EM_WIN, carry + total))
+      const int fb = win > carry ? win : carry;
+      const int fe = (win + EM_WIN < carry + total) ? win + EM_WIN : carry + total;
+      for (int i = fb + tid; i < fe; i += TK_THREADS) {
+        const int64_t dst = row_beg + i;
         if (dst < p.z_cap) {
-          col[dst] = (I)c;
+          col[dst] = (I)s_out[i - win];
           if (vals) vals[dst] = 1.0f;
         }
       }
+#endif
+      __syncthreads();
     }
-    carry += chunk_entries;
-    __syncthreads();
+#endif
+    carry += total;
   }
 }
 

@@ -83,7 +83,7 @@ def test_predictor_tail(ops, dtype, N, H, T, T_M, layout):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("N,H,T,D", [(2, 3, 100, 64), (1, 4, 4096, 64), (1, 2, 33, 80), (1, 2, 257, 128), (1, 1, 7, 16)])
+@pytest.mark.parametrize("N,H,T,D", [(2, 3, 100, 64), (1, 4, 4096, 64), (1, 2, 33, 80), (1, 2, 257, 128), (1, 1, 7, 16), (1, 2, 50, 32)])
 def test_cumavg(ops, dtype, N, H, T, D):
     g = torch.Generator().manual_seed(2)
     v = torch.randn((N, H, T, D), generator=g).to(dtype)
