@@ -208,6 +208,27 @@ int sea_causal_conv_c8(const void* x, int dtype, int64_t N, int64_t T, int64_t W
                        const void* w_packed, int64_t CinP, const float* bias, int ksize, int dilation, int pad_w,
                        int relu, void* y, sea_stream_t stream);
 
+/* Predictor MLP of SEA's estimator in one launch, 16-bit data, bf16/f16 MFMA:
+ *   enc  = GELU(LayerNorm_D1(x W1^T + b1))                      attention_predictor_enc      (attention.py:190-196)
+ *   dec  = enc W2^T + b2, split into S = 2 halves of Wd = D2/2      attention_predictor_dec_row  (attention.py:123-131,623)
+ *   y    = LayerNorm_Wd(dec half) * g2 + be2, written in the C8 layout of sea_causal_conv_c8 with channel = 2*h + half
+ *                                                                   cnn.lnorm1                   (attention.py:266)
+ *   gate = sigmoid(enc Wsc^T + bsc)  (2 values per row)             attention_predictor_dec_scaler (attention.py:1158-1166)
+ * Every Linear / LayerNorm output is rounded to `dtype` exactly where the reference's module chain rounds it.
+ * x (N,H,T,Din) of `dtype`, element strides x_strides[n,h,t], Din contiguous.
+ * w1_packed: W1 (D1,Din) as MFMA A fragments  [ks][tile][lane][j] = W1[16*tile + lane%16][32*ks + 8*(lane/16) + j]
+ *            (ks < ceil(Din/32), tile < D1/16, zero beyond Din);
+ * w2_packed: [ks][tile][lane][j] = W2'[16*tile + lane%16][f(ks, lane/16, j)],  f(ks,g,j) = 16*(2*ks + j/4) + 4*g + j%4,
+ *            ks < D1/32, tile <= D2/16, where W2' = W2 (D2,D1) followed by one extra tile whose rows 0,1 are Wsc (2,D1);
+ * vectors (fp32): b1[D1] g1[D1] be1[D1] b2[D2] g2[Wd] be2[Wd] bsc[2].
+ * Outputs: x_c8 (N, T, H*2/8, Wd, 8) of `dtype`; optional tpred (N,H,T,D1) of `dtype` (= enc); optional
+ * row_scale / avg_scale (N,H,T) FP32 = gate[...,0] / gate[...,1].
+ * Supported (D1, D2): (128,128) (128,64) (128,256) (160,128) (the weights must fit 160 KB of LDS); H % 4 == 0; Din % 8 == 0. */
+int sea_predictor_mlp(const void* x, int dtype, int64_t N, int64_t H, int64_t T, int64_t Din, const int64_t* x_strides,
+                      int64_t D1, int64_t D2, const void* w1_packed, const void* w2_packed, const float* vectors,
+                      float eps1, float eps2, void* x_c8, void* tpred, float* row_scale, float* avg_scale,
+                      sea_stream_t stream);
+
 /* Causal Performer of SEA's estimator in one launch, fp32 MFMA:
  *   phi(x) = relu(D^-1/4 x W^T) + 1e-3;  ctx_t = sum_{s<=t} (phi(q_t).phi(k_s)) V_s / (phi(q_t).(sum_{s<=t} phi(k_s) + 1e-6))
  * with V = [pos | v] (the learned causal value embedding concatenated in front of v, attention.py:506-510).

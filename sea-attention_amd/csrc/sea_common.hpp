@@ -73,6 +73,21 @@ template <> __device__ inline float from_f<float>(float x) { return x; }
 template <> __device__ inline __half from_f<__half>(float x) { return __float2half(x); }
 template <> __device__ inline __hip_bfloat16 from_f<__hip_bfloat16>(float x) { return __float2bfloat16(x); }
 
+// erf to ~2e-7 absolute (Abramowitz & Stegun 7.1.26 on hardware rcp / exp2): 12 VALU + 2 transcendental slots, branch
+// free, against ~35 slots of the two-branch libm erff.  Used for GELU(x) = 0.5 x (1 + erf(x / sqrt 2)), where the
+// error is absolute on a term that is added to 1 -- far below the 16-bit rounding the result goes through.
+__device__ inline float erf_as(float z) {
+  const float a = fabsf(z);
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, a, 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(a * a * -1.4426950408889634f);
+  return copysignf(fmaf(-(p * t), e, 1.0f), z);
+}
+__device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
+
 // Two floats -> one dword of packed 16-bit values (low half = a), same rounding as from_f<T>.
 template <typename T> __device__ inline uint32_t pack2(float a, float b) {
   const T x = from_f<T>(a), y = from_f<T>(b);

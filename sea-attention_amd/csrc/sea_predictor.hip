@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256) void split_layernorm_kernel(const T* x, T* out
       for (int j = 0; j < VEC; ++j) o[j] = (f[j] - mean) * rstd * g[j] + b[j];
       if (act_gelu) {   // nn.GELU() default: exact erf form
 #pragma unroll
-        for (int j = 0; j < VEC; ++j) o[j] = 0.5f * o[j] * (1.0f + erff(o[j] * 0.70710678118654752f));
+        for (int j = 0; j < VEC; ++j) o[j] = gelu_erf(o[j]);
       }
       if (VEC == 4) {
         *reinterpret_cast<float4*>(reinterpret_cast<float*>(out) + o_off) = make_float4(o[0], o[1], o[2], o[3]);

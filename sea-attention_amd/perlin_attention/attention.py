@@ -121,6 +121,7 @@ class PerlinAttention(nn.Module):
         self.materialize_csr = False
         # debugging / parity: run the estimator's LayerNorm / conv tail through the torch modules even on GPU
         self.force_torch_estimator = False
+        self._fused_gates = None            # (row_scale, average_scale) when the fused predictor MLP produced them
 
         d, H = self.attention_head_size, self.num_attention_heads
         pc = self.pconfig
@@ -217,6 +218,30 @@ class PerlinAttention(nn.Module):
                 and T_M % 4 == 0 and T_M <= 512 and (T_M // 4) % vec == 0
                 and ((T_M // 4 + 63) // 64) * ((self.num_attention_heads + 7) // 8) <= 16)
 
+    def _fused_mlp_ok(self, x):
+        """One-launch predictor MLP (csrc/sea_mlp.hip): inference on 16-bit data with the standard
+        enc = Linear+LayerNorm+GELU / dec_row = Linear+ChannelSplit(2) / 2-way gate modules, C8 CNN available.
+        Dense and sparse mode share it (so both see the same probability map); dense mode also asks for the
+        encoder output, which its gate / probing code reads."""
+        if not (self._hip_estimator_ok(x) and x.dtype in (torch.float16, torch.bfloat16)):
+            return False
+        if self.pconfig.attention_predictor_enc_per_layer or int(os.environ.get('QUERY_SKIPS', '1')) != 1:
+            return False
+        enc, dec, sc = self.attention_predictor_enc, self.attention_predictor_dec_row, self.attention_predictor_dec_scaler
+        if not (len(enc) == 3 and isinstance(enc[0], nn.Linear) and isinstance(enc[1], nn.LayerNorm)
+                and isinstance(enc[2], nn.GELU) and getattr(enc[2], 'approximate', 'none') == 'none'
+                and len(dec) == 2 and isinstance(dec[0], nn.Linear) and self.attention_predictor_dec_row_splits == 2
+                and len(sc) == 1 and isinstance(sc[0], nn.Linear) and sc[0].out_features == 2):
+            return False
+        if any(m.bias is None for m in (enc[0], dec[0], sc[0])) or not enc[1].elementwise_affine:
+            return False
+        ln1 = self.attention_predictor_cnn[0].module
+        body = list(self.attention_predictor_cnn[1].module.net.children())
+        return (isinstance(ln1, nn.LayerNorm) and ln1.elementwise_affine
+                and tuple(ln1.normalized_shape) == (dec[0].out_features // 2,)
+                and ops.predictor_mlp_supported(enc[0].out_features, dec[0].out_features, x.shape[1], x.shape[-1])
+                and self._c8_cnn_ok(x, body))
+
     def _c8_cnn_ok(self, x, body):
         """Channel-blocked (C8) MFMA conv pipeline: 16-bit data, body = (CausalConv2d k x k, ReLU)* + upsample + 1x1 conv."""
         if x.dtype not in (torch.float16, torch.bfloat16):
@@ -270,6 +295,36 @@ class PerlinAttention(nn.Module):
             with timer("performer_value"):
                 performer_value = torch.cat([performer_context_layer, v], dim=-1)
                 bench.register_temp_buffer('performer_value', performer_value)
+        fused_mlp = self._fused_mlp_ok(performer_value)
+        self._fused_gates = None
+        if fused_mlp:
+            with timer("predictor"):
+                want_scores = get_bench().activate_temp_buffers or (not self.benchmarking)
+                with timer("predictor.mlp"):   # enc + dec_row + lnorm1 (+ the two gates) in one launch
+                    x, t_attention_predictor, row_scale, avg_scale = ops.predictor_mlp(
+                        performer_value, self.attention_predictor_enc[0], self.attention_predictor_enc[1],
+                        self.attention_predictor_dec_row[0], self.attention_predictor_cnn[0].module,
+                        self.attention_predictor_dec_scaler[0], want_tpred=want_scores)
+                    if self.benchmarking:
+                        self._fused_gates = (row_scale, avg_scale)
+                with timer("predictor.cnn"):
+                    keepres, ln2 = self.attention_predictor_cnn[1].module, self.attention_predictor_cnn[2].module
+                    body = list(keepres.net.children())
+                    with timer("cnn.keepres"):
+                        for li_ in range(0, len(body) - 2, 2):                              # (conv, ReLU) pairs
+                            conv = body[li_].module
+                            with timer(body[li_].name):
+                                x = ops.causal_conv_c8(x, conv.weight, conv.bias, conv.kernel_size, conv.dilation,
+                                                       conv.padding[1], relu=True)
+                        conv4 = body[-1].module
+                        with timer("cnn.tail"):
+                            estimated_attention_probs, estimated_attention_score = ops.predictor_tail(
+                                x, conv4.weight[:, :, 0, 0], conv4.bias, ln2.weight, ln2.bias, up=4,
+                                T_m=self.pconfig.attention_predictor_length, eps=ln2.eps, want_scores=want_scores)
+                bench.register_temp_buffer('t_attention_predictor', t_attention_predictor)
+            bench.register_temp_buffer('estimated_attention_score', estimated_attention_score)
+            bench.register_temp_buffer('estimated_attention_probs', estimated_attention_probs)
+            return v, t_attention_predictor, estimated_attention_score, estimated_attention_probs
         with timer("predictor"):
             query_skips = int(os.environ.get('QUERY_SKIPS', '1'))
             with timer("predictor.enc"):
@@ -488,10 +543,18 @@ class PerlinAttention(nn.Module):
 
         with timer("attention"):
             with timer('attention.sparse.scaler'):
-                estimated_scales = self.attention_predictor_dec_scaler(t_attention_predictor)      # (N,H,T,2)
-                sig = torch.sigmoid(estimated_scales.float())
-                row_scale = sig[..., 0].contiguous() if self.pconfig.partial_attention_scaler else None
-                average_scale = sig[..., 1].contiguous()
+                if self._fused_gates is not None:                       # already produced by the fused predictor MLP
+                    row_scale, average_scale = self._fused_gates
+                    if not self.pconfig.partial_attention_scaler:
+                        row_scale = None
+                    # probing (temp buffers on) keeps the pre-sigmoid tensor of the reference available
+                    estimated_scales = (self.attention_predictor_dec_scaler(t_attention_predictor)
+                                        if t_attention_predictor is not None else None)
+                else:
+                    estimated_scales = self.attention_predictor_dec_scaler(t_attention_predictor)      # (N,H,T,2)
+                    sig = torch.sigmoid(estimated_scales.float())
+                    row_scale = sig[..., 0].contiguous() if self.pconfig.partial_attention_scaler else None
+                    average_scale = sig[..., 1].contiguous()
             with timer("attention.avg_pool"):
                 avg_v = v if not_padded else v * (dst_attention_mask > -1)
                 average_context_layer = ops.cumavg(avg_v)              # HIP scan, fp32 accumulation

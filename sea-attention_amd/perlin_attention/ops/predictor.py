@@ -136,6 +136,63 @@ def performer_value(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torc
     return out
 
 
+def predictor_mlp_supported(D1: int, D2: int, H: int, Din: int) -> bool:
+    """Shapes csrc/sea_mlp.hip is instantiated for (launch_mlp)."""
+    return (D1, D2) in ((128, 128), (128, 64), (128, 256), (160, 128)) and H % 4 == 0 and Din % 8 == 0 and Din <= 256
+
+
+def _pack_a_fragments(w: torch.Tensor, kperm=None) -> torch.Tensor:
+    """(M, K) weight -> MFMA 16x16x32 A fragments [K/32][M/16][64 lanes][8]: lane l holds W[16*tile + l%16][k(ks, l//16, j)],
+    k = 32*ks + 8*g + j by default, or kperm[ks, g, j].  M, K already padded to multiples of 16 / 32."""
+    M, K = w.shape
+    ks = torch.arange(K // 32, device=w.device).view(-1, 1, 1, 1, 1)
+    tile = torch.arange(M // 16, device=w.device).view(1, -1, 1, 1, 1)
+    g = torch.arange(4, device=w.device).view(1, 1, -1, 1, 1)
+    li = torch.arange(16, device=w.device).view(1, 1, 1, -1, 1)
+    j = torch.arange(8, device=w.device).view(1, 1, 1, 1, -1)
+    k = (32 * ks + 8 * g + j) if kperm is None else kperm(ks, g, j)
+    return w[(16 * tile + li).expand(K // 32, M // 16, 4, 16, 8), k.expand(K // 32, M // 16, 4, 16, 8)].contiguous()
+
+
+def predictor_mlp(x: torch.Tensor, enc_lin, enc_ln, dec_lin, ln1, scaler_lin, want_tpred: bool = False):
+    """Fused predictor MLP (csrc/sea_mlp.hip): x (N,H,T,Din) -> (x_c8 (N,T,H*2/8,Wd,8), t_pred or None,
+    row_scale (N,H,T) fp32, avg_scale (N,H,T) fp32).  enc_lin/dec_lin/scaler_lin: nn.Linear; enc_ln/ln1: nn.LayerNorm."""
+    lib = _lib.load()
+    _lib.require_gpu(x)
+    N, H, T, Din = x.shape
+    dt = x.dtype
+    D1, D2 = enc_lin.out_features, dec_lin.out_features
+    Wd = D2 // 2
+    assert enc_lin.in_features == Din and dec_lin.in_features == D1 and scaler_lin.in_features == D1 and scaler_lin.out_features == 2
+    assert predictor_mlp_supported(D1, D2, H, Din) and tuple(ln1.normalized_shape) == (Wd,)
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+
+    def build():
+        KP = (Din + 31) // 32 * 32
+        w1 = torch.zeros((D1, KP), dtype=dt, device=x.device)
+        w1[:, :Din] = enc_lin.weight.to(dt)
+        w2 = torch.zeros((D2 + 16, D1), dtype=dt, device=x.device)
+        w2[:D2] = dec_lin.weight.to(dt)
+        w2[D2:D2 + 2] = scaler_lin.weight.to(dt)
+        w1p = _pack_a_fragments(w1)
+        w2p = _pack_a_fragments(w2, kperm=lambda ks, g, j: 16 * (2 * ks + j // 4) + 4 * g + j % 4)
+        f = lambda t: t.to(dt).float().reshape(-1)
+        vec = torch.cat([f(enc_lin.bias), f(enc_ln.weight), f(enc_ln.bias), f(dec_lin.bias), f(ln1.weight), f(ln1.bias),
+                         f(scaler_lin.bias)]).contiguous()
+        return w1p, w2p, vec
+    w1p, w2p, vec = _cached("mlp", (enc_lin.weight, enc_lin.bias, enc_ln.weight, enc_ln.bias, dec_lin.weight, dec_lin.bias,
+                                    ln1.weight, ln1.bias, scaler_lin.weight, scaler_lin.bias), dt, build)
+    x_c8 = torch.empty((N, T, H * 2 // 8, Wd, 8), dtype=dt, device=x.device)
+    tpred = torch.empty((N, H, T, D1), dtype=dt, device=x.device) if want_tpred else None
+    row_scale = torch.empty((N, H, T), dtype=torch.float32, device=x.device)
+    avg_scale = torch.empty((N, H, T), dtype=torch.float32, device=x.device)
+    _lib.check(lib.sea_predictor_mlp(_p(x), _lib.dtype_code(dt), N, H, T, Din, _lib.strides3(x), D1, D2, _p(w1p), _p(w2p),
+                                     _p(vec), float(enc_ln.eps), float(ln1.eps), _p(x_c8), _p(tpred), _p(row_scale),
+                                     _p(avg_scale), _lib.stream_ptr()), "sea_predictor_mlp")
+    return x_c8, tpred, row_scale, avg_scale
+
+
 def to_c8(x: torch.Tensor) -> torch.Tensor:
     """(N, C, T, W) -> the channel-blocked layout of the conv kernels, a dense 5-D tensor (N, T, C/8, W, 8)."""
     N, C, T, W = x.shape

@@ -263,3 +263,44 @@ def test_estimator_kernels_are_bitwise_reproducible(ops):
     for _ in range(3):
         assert torch.equal(p0, ops.predictor_tail(y, cw, cb, lw, lb, up=4, T_m=T_M)[0])
         assert torch.equal(c0, ops.causal_conv_c8(y, wt, b, 3, 2, 2))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,T,d,T_M", [(2, 32, 40, 64, 256), (1, 12, 33, 64, 256), (1, 4, 70, 64, 128), (1, 8, 20, 64, 512),
+                                         (1, 20, 17, 80, 256)])
+def test_predictor_mlp(ops, dtype, N, H, T, d, T_M):
+    """Fused enc Linear+LN+GELU -> dec_row Linear+ChannelSplit+LN (C8) + gate Linear+sigmoid vs the module chain in fp32
+    with the 16-bit rounding of every module output."""
+    nn = torch.nn
+    g = torch.Generator().manual_seed(5)
+    Din, D1, Wd = 3 * d, 2 * d, T_M // 4
+    D2 = 2 * Wd
+    mods = [nn.Linear(Din, D1), nn.LayerNorm(D1), nn.Linear(D1, D2), nn.LayerNorm(Wd), nn.Linear(D1, 2)]
+    with torch.no_grad():
+        for m in mods:
+            for prm in m.parameters():
+                prm.copy_(torch.randn(prm.shape, generator=g) * (0.3 if prm.dim() == 1 else prm.shape[-1] ** -0.5))
+        mods[1].weight.add_(1.0); mods[3].weight.add_(1.0)
+    import copy
+    enc_lin, enc_ln, dec_lin, ln1, sc = [copy.deepcopy(m).to(DEV).to(dtype) for m in mods]
+    x = torch.randn((N, H, T, Din), generator=g).to(dtype)
+    r = lambda t: t.to(dtype).float()
+    F = torch.nn.functional
+    xf = x.float()
+    e = r(xf @ r(mods[0].weight).T + r(mods[0].bias))
+    e = r(F.gelu(F.layer_norm(e, (D1,), r(mods[1].weight), r(mods[1].bias), mods[1].eps)))
+    dd = r(e @ r(mods[2].weight).T + r(mods[2].bias)).view(N, H, T, 2, Wd)
+    y = r(F.layer_norm(dd, (Wd,), r(mods[3].weight), r(mods[3].bias), mods[3].eps))          # (N,H,T,2,Wd)
+    y_ref = y.permute(0, 1, 3, 2, 4).reshape(N, H * 2, T, Wd)                                  # channel = 2h + split
+    gate = torch.sigmoid(r(e @ r(mods[4].weight).T + r(mods[4].bias)))
+    x_c8, tp, rs, av = ops.predictor_mlp(x.to(DEV), enc_lin, enc_ln, dec_lin, ln1, sc, want_tpred=True)
+    assert tuple(x_c8.shape) == (N, T, H * 2 // 8, Wd, 8) and tp.dtype == dtype
+    atol, rtol = (6e-2, 3e-2) if dtype == torch.bfloat16 else (8e-3, 4e-3)
+    torch.testing.assert_close(tp.float().cpu(), e, atol=atol, rtol=rtol)
+    got = ops.from_c8(x_c8).float().cpu()
+    torch.testing.assert_close(got, y_ref, atol=atol * 2, rtol=rtol)
+    assert (got - y_ref).abs().mean().item() < atol / 8
+    torch.testing.assert_close(rs.cpu(), gate[..., 0], atol=atol / 2, rtol=rtol)
+    torch.testing.assert_close(av.cpu(), gate[..., 1], atol=atol / 2, rtol=rtol)
+    x2, tp2, _, _ = ops.predictor_mlp(x.to(DEV), enc_lin, enc_ln, dec_lin, ln1, sc, want_tpred=False)
+    assert tp2 is None and torch.equal(x2, x_c8)
