@@ -17,6 +17,8 @@
 // 4g+r of lane group g -- the B operand of the carry term phi(Q_c) S, with the k index of that product
 // permuted accordingly on the A side.  All products run on v_mfma_f32_16x16x4_f32 (exact fp32).
 #include "sea_common.hpp"
+#include <cstdlib>
+#include <type_traits>
 
 #ifdef SEA_STAMP
 __device__ unsigned long long sea_dbg_perf[8];
@@ -285,6 +287,317 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
   }
 }
 
+
+// ======================================================================================================
+// bf16 variant (D = 64): the same algorithm on v_mfma_f32_16x16x32_bf16 -- 16x the fp32 MFMA rate.
+//
+// What keeps it accurate: q, k, v, pos and the projection ARE bf16 values, so the feature-map product is exact
+// in the products and fp32 in the sums, as before.  Everything that is genuinely fp32 afterwards -- phi(q),
+// phi(k), the masked tile A, the running state S -- enters the matrix cores SPLIT in two bf16 terms
+// (x = hi + lo, hi = bf16(x), lo = bf16(x - hi): 16 significand bits), and a product of two split operands
+// takes three MFMAs (hi.hi + hi.lo + lo.hi), one split against an exact bf16 operand takes two.  Relative
+// error 2^-17 per term, accumulated in fp32, in front of a result that is rounded to bf16 (2^-9).
+// The state S itself stays fp32 in the accumulators for the whole sequence.
+//
+// Layout notes (16x16x32 operand maps: A lane l = row l%16, k = 8(l/16)+j; B lane l = col l%16, same k):
+//   * X^T = W . Q^T is computed transposed, so a lane holds 4 consecutive FEATURES of one row: the split
+//     values leave as 8-byte row-major pieces, which is what the later A-operand reads want.
+//   * the tile A is computed transposed too (A^T = phi(K) . phi(Q)^T): same reason, and its row sums (the
+//     denominators) become an in-lane sum plus two cross-lane adds.
+//   * products that contract over the chunk rows (A.V, phi(K)^T.V) need V and phi(K) "k-major"; both stay
+//     row-major in LDS and are fetched with the transposing read ds_read_b64_tr_b16.
+//   * S is, as in the fp32 kernel, the B operand of phi(Q).S straight from the accumulator registers; element j
+//     of lane group g is feature 16*(2kk + j/4) + 4g + j%4, and the phi(Q) fragment is gathered in that order.
+// ======================================================================================================
+typedef __attribute__((ext_vector_type(8))) __bf16 pbf8;
+typedef __attribute__((ext_vector_type(4))) short ps4;
+#define SEA_MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pbf8, (a)), __builtin_bit_cast(pbf8, (b)), (c), 0, 0, 0)
+
+__device__ inline unsigned short bf_bits(float x) { return __builtin_bit_cast(unsigned short, __float2bfloat16(x)); }
+__device__ inline float bf_val(unsigned short b) { return __uint_as_float((uint32_t)b << 16); }
+// x -> (hi, lo) bf16 bit patterns with hi + lo ~ x to 16 significand bits
+__device__ inline void bf_split(float x, unsigned short& hi, unsigned short& lo) {
+  hi = bf_bits(x);
+  lo = bf_bits(x - bf_val(hi));
+}
+__device__ inline uint2 pack4(const unsigned short (&v)[4]) {
+  return make_uint2((uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16));
+}
+__device__ inline uint4 cat8(uint2 a, uint2 b) { return make_uint4(a.x, a.y, b.x, b.y); }
+__device__ inline uint2 lds_tr(const unsigned short* p) {      // ds_read_b64_tr_b16
+  const ps4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ps4 __attribute__((address_space(3)))*)(p));
+  return __builtin_bit_cast(uint2, v);
+}
+
+template <int NBT>
+__global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
+  using T = __hip_bfloat16;
+  constexpr int D = 64, C = 64, NW = 8, NTH = 512, E = 2 * D;
+  constexpr int NBP = NBT * 16;
+  constexpr int KF = (NBT + 1) / 2;            // 32-wide k-steps over the (padded) features
+  constexpr int FP = KF * 32;                  // padded feature count
+  constexpr int RB = C / 16, EB = E / 16;
+  static_assert(EB == NW, "one 16-column block of [pos | v] per wave");
+  constexpr int LDP = FP + 8;                  // phi rows (elements); +16 B against bank aliasing
+  constexpr int LDA = C + 8;                   // A rows
+  constexpr int DSL = RB + NTH / C;            // denominator partial slots per row
+  extern __shared__ __attribute__((aligned(16))) char smem_b[];
+  unsigned short* sW = reinterpret_cast<unsigned short*>(smem_b);   // [D/8][NBP][8]   projection, k-chunked
+  unsigned short* sQ = sW + (D / 8) * NBP * 8;                      // [D/8][C][8]
+  unsigned short* sK = sQ + (D / 8) * C * 8;                        // [D/8][C][8]
+  unsigned short* sV = sK + (D / 8) * C * 8;                        // [C][E] 256-byte rows, chunk-swizzled
+  unsigned short* sQh = sV + C * E;                                 // [C][LDP]
+  unsigned short* sQl = sQh + C * LDP;
+  unsigned short* sKh = sQl + C * LDP;
+  unsigned short* sKl = sKh + C * LDP;
+  unsigned short* sAh = sKl + C * LDP;                              // [C][LDA]
+  unsigned short* sAl = sAh + C * LDA;
+  float* sKsum = reinterpret_cast<float*>(sAl + C * LDA);           // [FP]
+  float* sDen = sKsum + FP;                                         // [C]
+  float* sDenP = sDen + C;                                          // [C][DSL]
+  float* sKsP = sDenP + C * DSL;                                    // [NTH/FP... 8][FP]
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int nh = blockIdx.x;
+  const int n = nh / p.H, h = nh - n * p.H;
+  const T* qb = reinterpret_cast<const T*>(p.q) + n * p.qs[0] + h * p.qs[1];
+  const T* kb = reinterpret_cast<const T*>(p.k) + n * p.ks[0] + h * p.ks[1];
+  const T* vb = reinterpret_cast<const T*>(p.v) + n * p.vs[0] + h * p.vs[1];
+  const T* pb = reinterpret_cast<const T*>(p.pos);
+  T* ob = reinterpret_cast<T*>(p.out) + (int64_t)nh * p.T * (3 * D);
+  const float cnorm = powf((float)D, -0.25f);
+
+  // projection (its values are bf16-exact: the reference casts the buffer to the data dtype), zero padded rows
+  for (int i = tid; i < (D / 8) * NBP * 8; i += NTH) {
+    const int j = i & 7, f = (i >> 3) % NBP, kc = (i >> 3) / NBP;
+    sW[i] = f < p.nb ? bf_bits(p.W[f * D + kc * 8 + j]) : (unsigned short)0;
+  }
+  // phi and A images: padded features / upper-triangular tiles are written once (zero) and never again
+  for (int i = tid; i < 4 * C * LDP + 2 * C * LDA; i += NTH) sQh[i] = 0;
+  for (int i = tid; i < FP; i += NTH) sKsum[i] = 0.f;
+  for (int i = tid; i < C * DSL; i += NTH) sDenP[i] = 0.f;   // slots of key blocks above the diagonal stay zero
+
+  f4 S[NBT];
+#pragma unroll
+  for (int b = 0; b < NBT; ++b) S[b] = f4{0.f, 0.f, 0.f, 0.f};
+
+  // one 16-byte piece of each tensor per thread and chunk; prefetched one chunk ahead
+  const int sr = tid >> 3, sc = tid & 7;        // staging row, 8-element column chunk
+  uint4 pq, pk, pv, pp;
+  auto issue_loads = [&](int t0n) {
+    pq = pk = pv = pp = make_uint4(0, 0, 0, 0);
+    if (t0n + sr < p.T) {
+      const int64_t t = t0n + sr;
+      pq = *reinterpret_cast<const uint4*>(qb + t * p.qs[2] + sc * 8);
+      pk = *reinterpret_cast<const uint4*>(kb + t * p.ks[2] + sc * 8);
+      pv = *reinterpret_cast<const uint4*>(vb + t * p.vs[2] + sc * 8);
+      pp = *reinterpret_cast<const uint4*>(pb + t * p.pos_stride + sc * 8);
+    }
+  };
+  issue_loads(0);
+  // swizzled chunk position inside a 256-byte row of the V image (conflict-free transposing reads)
+  auto vchunk = [](int row, int ch) { return ch ^ (((row & 3) << 2) | ((row >> 2) & 3)); };
+
+  for (int t0 = 0; t0 < p.T; t0 += C) {
+    const int rows = min(C, p.T - t0);
+    // ---- (a) staging ---------------------------------------------------------------------------------
+    if (sr < rows) *reinterpret_cast<uint4*>(ob + (int64_t)(t0 + sr) * (3 * D) + 2 * D + sc * 8) = pv;
+    *reinterpret_cast<uint4*>(sQ + (sc * C + sr) * 8) = pq;
+    *reinterpret_cast<uint4*>(sK + (sc * C + sr) * 8) = pk;
+    *reinterpret_cast<uint4*>(sV + sr * E + vchunk(sr, sc) * 8) = pp;
+    *reinterpret_cast<uint4*>(sV + sr * E + vchunk(sr, D / 8 + sc) * 8) = pv;
+    if (t0 + C < p.T) issue_loads(t0 + C);
+    __syncthreads();
+
+    // ---- (b) feature maps, transposed: X^T[f][t] = sum_d W[f][d] x[t][d]; wave = (Q | K, row block) ----------
+    {
+      const int which = wv / RB, rb = wv - which * RB;
+      const unsigned short* src = which ? sK : sQ;
+      f4 acc[NBT];
+#pragma unroll
+      for (int fb = 0; fb < NBT; ++fb) acc[fb] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < D / 32; ++ks) {
+        const uint4 bx = *reinterpret_cast<const uint4*>(src + ((4 * ks + lg) * C + rb * 16 + li) * 8);
+#pragma unroll
+        for (int fb = 0; fb < NBT; ++fb) {
+          const uint4 aw = *reinterpret_cast<const uint4*>(sW + ((4 * ks + lg) * NBP + fb * 16 + li) * 8);
+          acc[fb] = SEA_MFMA_BF(aw, bx, acc[fb]);
+        }
+      }
+      unsigned short* dh = which ? sKh : sQh;
+      unsigned short* dl = which ? sKl : sQl;
+      const int row = rb * 16 + li;                          // lane: 4 consecutive features of one row
+#pragma unroll
+      for (int fb = 0; fb < NBT; ++fb) {
+        unsigned short hh[4], ll[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = fb * 16 + lg * 4 + r;
+          float val = fmaxf(cnorm * acc[fb][r], 0.f) + 1e-3f;
+          if (f >= p.nb || row >= rows) val = 0.f;           // padded features / rows beyond T contribute nothing
+          bf_split(val, hh[r], ll[r]);
+        }
+        *reinterpret_cast<uint2*>(dh + row * LDP + fb * 16 + lg * 4) = pack4(hh);
+        *reinterpret_cast<uint2*>(dl + row * LDP + fb * 16 + lg * 4) = pack4(ll);
+      }
+    }
+    __syncthreads();
+
+    // ---- (c) A^T tiles (lower triangle), denominator and k-sum partials ------------------------------------
+    for (int tile = wv; tile < RB * (RB + 1) / 2; tile += NW) {
+      int ib = 0, rem = tile;
+      while (rem > ib) { rem -= ib + 1; ++ib; }              // tile -> (query block ib, key block jb <= ib)
+      const int jb = rem;
+      f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KF; ++ks) {
+        const int ko = ks * 32 + lg * 8;
+        const uint4 kh = *reinterpret_cast<const uint4*>(sKh + (jb * 16 + li) * LDP + ko);
+        const uint4 kl = *reinterpret_cast<const uint4*>(sKl + (jb * 16 + li) * LDP + ko);
+        const uint4 qh = *reinterpret_cast<const uint4*>(sQh + (ib * 16 + li) * LDP + ko);
+        const uint4 ql = *reinterpret_cast<const uint4*>(sQl + (ib * 16 + li) * LDP + ko);
+        acc = SEA_MFMA_BF(kh, qh, acc);
+        acc = SEA_MFMA_BF(kh, ql, acc);
+        acc = SEA_MFMA_BF(kl, qh, acc);
+      }
+      const int trow = ib * 16 + li;                         // lane: A[trow][s0 .. s0+3]
+      const int s0 = jb * 16 + lg * 4;
+      unsigned short hh[4], ll[4];
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float val = (s0 + r <= trow) ? acc[r] : 0.f;   // causal mask inside the diagonal tiles
+        rs += val;
+        bf_split(val, hh[r], ll[r]);
+      }
+      *reinterpret_cast<uint2*>(sAh + trow * LDA + s0) = pack4(hh);
+      *reinterpret_cast<uint2*>(sAl + trow * LDA + s0) = pack4(ll);
+      rs += __shfl_xor(rs, 16); rs += __shfl_xor(rs, 32);
+      if (lg == 0) sDenP[trow * DSL + jb] = rs;              // one writer per (row, key block)
+    }
+    {
+      // carry part of the denominators: phi(q_t) . (ksum + eps), and the k-sum increment of this chunk
+      const int row = tid & (C - 1), part = tid / C;         // 8 parts x (FP/8) features
+      constexpr int PER = FP / (NTH / C);
+      float s = 0.f, ks_ = 0.f;
+#pragma unroll
+      for (int j = 0; j < PER; ++j) {
+        const int f = part * PER + j;
+        const float q = bf_val(sQh[row * LDP + f]) + bf_val(sQl[row * LDP + f]);
+        s = fmaf(q, sKsum[f] + 1e-6f, s);
+      }
+      sDenP[row * DSL + RB + part] = s;
+      // k-sum increment: thread (feature f2, part part2) adds its share of the chunk rows
+      constexpr int KPARTS = NTH / FP, RPP = (C + KPARTS - 1) / KPARTS;
+      const int f2 = tid % FP, part2 = tid / FP;
+      if (part2 < KPARTS) {
+        for (int j = 0; j < RPP; ++j) {
+          const int r2 = part2 * RPP + j;
+          if (r2 < C) ks_ += bf_val(sKh[r2 * LDP + f2]) + bf_val(sKl[r2 * LDP + f2]);
+        }
+        sKsP[part2 * FP + f2] = ks_;
+      }
+    }
+    __syncthreads();
+    if (tid < C) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < DSL; ++i) s += sDenP[tid * DSL + i];
+      sDen[tid] = s;
+    } else if (tid >= C && tid < C + FP) {
+      const int f = tid - C;
+      float s = sKsum[f];
+#pragma unroll
+      for (int i = 0; i < NTH / FP; ++i) s += sKsP[i * FP + f];   // fixed order: bitwise reproducible
+      sKsum[f] = s;
+    }
+    __syncthreads();
+
+    // ---- (d) O = A V + phi(Q) S over this wave's 16 columns; (e) S += phi(K)^T V ------------------------------
+    {
+      const int jb = wv, e0 = jb * 16;
+      // V fragments (B operand, k = chunk row): rows 32ks + 8lg + {0..3 | 4..7}, columns e0 .. e0+15
+      uint4 vf[C / 32];
+      {
+        const int q = li >> 2, pp_ = li & 3;
+#pragma unroll
+        for (int ks = 0; ks < C / 32; ++ks) {
+          const int r0 = ks * 32 + lg * 8;
+          const uint2 a = lds_tr(sV + (r0 + q) * E + vchunk(r0 + q, 2 * jb + (pp_ >> 1)) * 8 + 4 * (pp_ & 1));
+          const uint2 b = lds_tr(sV + (r0 + 4 + q) * E + vchunk(r0 + 4 + q, 2 * jb + (pp_ >> 1)) * 8 + 4 * (pp_ & 1));
+          vf[ks] = cat8(a, b);
+        }
+      }
+      f4 o[RB];
+#pragma unroll
+      for (int ib = 0; ib < RB; ++ib) o[ib] = f4{0.f, 0.f, 0.f, 0.f};
+      // A V: key k-step ks covers key blocks 2ks, 2ks+1; query block ib needs k-steps <= ib/2
+#pragma unroll
+      for (int ib = 0; ib < RB; ++ib) {
+#pragma unroll
+        for (int ks = 0; ks <= ib / 2; ++ks) {
+          const uint4 ah = *reinterpret_cast<const uint4*>(sAh + (ib * 16 + li) * LDA + ks * 32 + lg * 8);
+          const uint4 al = *reinterpret_cast<const uint4*>(sAl + (ib * 16 + li) * LDA + ks * 32 + lg * 8);
+          o[ib] = SEA_MFMA_BF(ah, vf[ks], o[ib]);
+          o[ib] = SEA_MFMA_BF(al, vf[ks], o[ib]);
+        }
+      }
+      // phi(Q) S: the state tiles, split, are the B operand; k-step kk pairs feature blocks 2kk and 2kk+1
+#pragma unroll
+      for (int kk = 0; kk < KF; ++kk) {
+        unsigned short h0[4], h1[4], l0[4], l1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          bf_split(S[2 * kk][r], h0[r], l0[r]);
+          if (2 * kk + 1 < NBT) bf_split(S[(2 * kk + 1 < NBT) ? 2 * kk + 1 : 0][r], h1[r], l1[r]);
+          else h1[r] = l1[r] = 0;
+        }
+        const uint4 bh = cat8(pack4(h0), pack4(h1)), bl = cat8(pack4(l0), pack4(l1));
+#pragma unroll
+        for (int ib = 0; ib < RB; ++ib) {
+          const unsigned short* qrh = sQh + (ib * 16 + li) * LDP + kk * 32 + lg * 4;
+          const unsigned short* qrl = sQl + (ib * 16 + li) * LDP + kk * 32 + lg * 4;
+          const uint4 ah = cat8(*reinterpret_cast<const uint2*>(qrh), *reinterpret_cast<const uint2*>(qrh + 16));
+          const uint4 al = cat8(*reinterpret_cast<const uint2*>(qrl), *reinterpret_cast<const uint2*>(qrl + 16));
+          o[ib] = SEA_MFMA_BF(ah, bh, o[ib]);
+          o[ib] = SEA_MFMA_BF(ah, bl, o[ib]);
+          o[ib] = SEA_MFMA_BF(al, bh, o[ib]);
+        }
+      }
+      const int col = e0 + li;
+#pragma unroll
+      for (int ib = 0; ib < RB; ++ib) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = ib * 16 + lg * 4 + r;
+          if (row < rows) ob[(int64_t)(t0 + row) * (3 * D) + col] = from_f<T>(o[ib][r] / sDen[row]);
+        }
+      }
+      // (e) S[f][e] += sum_s phi(k_s)[f] V[s][e]: A operand = phi(K)^T by transposing reads of the row-major images
+      {
+        const int q = li >> 2, pp_ = li & 3;
+#pragma unroll
+        for (int rb = 0; rb < NBT; ++rb) {
+#pragma unroll
+          for (int ks = 0; ks < C / 32; ++ks) {
+            const int r0 = ks * 32 + lg * 8;
+            const int co = rb * 16 + 4 * pp_;
+            const uint4 kh = cat8(lds_tr(sKh + (r0 + q) * LDP + co), lds_tr(sKh + (r0 + 4 + q) * LDP + co));
+            const uint4 kl = cat8(lds_tr(sKl + (r0 + q) * LDP + co), lds_tr(sKl + (r0 + 4 + q) * LDP + co));
+            S[rb] = SEA_MFMA_BF(kh, vf[ks], S[rb]);
+            S[rb] = SEA_MFMA_BF(kl, vf[ks], S[rb]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
 }  // namespace sea
 
 using namespace sea;
@@ -304,8 +617,35 @@ static int launch_perf(const PerfParams& p, hipStream_t s) {
   return SEA_OK;
 }
 
+template <int NBT>
+static int launch_perf_bf16(const PerfParams& p, hipStream_t s) {
+  constexpr int D = 64, C = 64, NTH = 512, E = 2 * D, NBP = NBT * 16, FP = ((NBT + 1) / 2) * 32, LDP = FP + 8, LDA = C + 8;
+  constexpr size_t lds = 2 * ((D / 8) * NBP * 8 + 2 * (D / 8) * C * 8 + C * E + 4 * C * LDP + 2 * C * LDA) +
+                         sizeof(float) * (FP + C + C * (C / 16 + NTH / C) + (NTH / FP) * FP);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)performer_bf16_kernel<NBT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    configured = true;
+  }
+  hipLaunchKernelGGL((performer_bf16_kernel<NBT>), dim3((unsigned)(p.N * p.H)), dim3(NTH), lds, s, p);
+  return SEA_OK;
+}
+
+// SEA_PERFORMER_FP32=1 keeps bf16 data on the fp32-MFMA kernel (A/B timing, parity debugging)
+static bool perf_force_fp32() {
+  static const bool v = [] { const char* e = getenv("SEA_PERFORMER_FP32"); return e && e[0] == '1'; }();
+  return v;
+}
+
 template <typename T>
 static int dispatch_perf(const PerfParams& p, int D, int nbt, hipStream_t s) {
+  if constexpr (std::is_same<T, __hip_bfloat16>::value) {
+    if (D == 64 && !perf_force_fp32()) {
+      if (nbt <= 3) return launch_perf_bf16<3>(p, s);
+      if (nbt <= 5) return launch_perf_bf16<5>(p, s);
+    }
+  }
   if (D == 64 && nbt <= 3) return launch_perf<T, 64, 3, 64>(p, s);
   if (D == 64 && nbt <= 5) return launch_perf<T, 64, 5, 64>(p, s);
   if (D == 80 && nbt <= 3) return launch_perf<T, 80, 3, 64>(p, s);
