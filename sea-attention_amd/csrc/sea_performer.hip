@@ -17,6 +17,9 @@
 // 4g+r of lane group g -- the B operand of the carry term phi(Q_c) S, with the k index of that product
 // permuted accordingly on the A side.  All products run on v_mfma_f32_16x16x4_f32 (exact fp32).
 #include "sea_common.hpp"
+#ifndef SEA_EXP
+#define SEA_EXP 0
+#endif
 #include <cstdlib>
 #include <type_traits>
 
@@ -352,10 +355,12 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   unsigned short* sKl = sKh + C * LDP;
   unsigned short* sAh = sKl + C * LDP;                              // [C][LDA]
   unsigned short* sAl = sAh + C * LDA;
-  float* sKsum = reinterpret_cast<float*>(sAl + C * LDA);           // [FP]
+  constexpr int LDO = E + 8;
+  unsigned short* sO = sAl + C * LDA;                               // [C][LDO]  the chunk's result rows, flushed one chunk later
+  float* sKsum = reinterpret_cast<float*>(sO + C * LDO);            // [FP]
   float* sDen = sKsum + FP;                                         // [C]
   float* sDenP = sDen + C;                                          // [C][DSL]
-  float* sKsP = sDenP + C * DSL;                                    // [NTH/FP... 8][FP]
+  float* sKsP = sDenP + C * DSL;                                    // [NW][FP]   per-wave k-sum increments
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -386,31 +391,54 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 
   // one 16-byte piece of each tensor per thread and chunk; prefetched one chunk ahead
   const int sr = tid >> 3, sc = tid & 7;        // staging row, 8-element column chunk
-  uint4 pq, pk, pv, pp;
+  // All global traffic goes through buffer instructions with hardware range checking: a row beyond T reads zeros /
+  // drops its store WITHOUT a branch.  (Branches around loads and stores make the compiler's vmcnt bookkeeping
+  // pessimistic: the wait for the prefetched chunk then also waits for every output store of the previous one.)
+  constexpr unsigned OOB = 0x7FFFFF00u;
+  auto mk = [&](const T* base, int64_t row_stride) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (int)(((int64_t)(p.T - 1) * row_stride + D) * 2), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rq = mk(qb, p.qs[2]), rk = mk(kb, p.ks[2]), rv = mk(vb, p.vs[2]), rp = mk(pb, p.pos_stride);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((int64_t)p.T * 3 * D * 2), 0x00020000);
+  typedef __attribute__((ext_vector_type(4))) unsigned int bu4;
+  bu4 pq, pk, pv, pp;
   auto issue_loads = [&](int t0n) {
-    pq = pk = pv = pp = make_uint4(0, 0, 0, 0);
-    if (t0n + sr < p.T) {
-      const int64_t t = t0n + sr;
-      pq = *reinterpret_cast<const uint4*>(qb + t * p.qs[2] + sc * 8);
-      pk = *reinterpret_cast<const uint4*>(kb + t * p.ks[2] + sc * 8);
-      pv = *reinterpret_cast<const uint4*>(vb + t * p.vs[2] + sc * 8);
-      pp = *reinterpret_cast<const uint4*>(pb + t * p.pos_stride + sc * 8);
+    const int t = t0n + sr;
+    const bool ok = t < p.T;
+    pq = __builtin_amdgcn_raw_buffer_load_b128(rq, ok ? (int)((t * p.qs[2] + sc * 8) * 2) : (int)OOB, 0, 0);
+    pk = __builtin_amdgcn_raw_buffer_load_b128(rk, ok ? (int)((t * p.ks[2] + sc * 8) * 2) : (int)OOB, 0, 0);
+    pv = __builtin_amdgcn_raw_buffer_load_b128(rv, ok ? (int)((t * p.vs[2] + sc * 8) * 2) : (int)OOB, 0, 0);
+    pp = __builtin_amdgcn_raw_buffer_load_b128(rp, ok ? (int)((t * p.pos_stride + sc * 8) * 2) : (int)OOB, 0, 0);
+  };
+#ifdef SEA_STAMP
+  unsigned long long _tprev = __builtin_amdgcn_s_memtime();
+#endif
+  issue_loads(0);
+  // the result tile of a chunk leaves LDS as 16-byte row pieces at the START of the next chunk, i.e. before that
+  // chunk's prefetch loads are issued: a wait for those loads never has younger stores in front of it
+  auto flush_out = [&](int t0p, int rowsp) {
+#pragma unroll
+    for (int i = tid; i < C * (E / 8); i += NTH) {
+      const int row = i / (E / 8), ch = i - row * (E / 8);
+      const bu4 v = *reinterpret_cast<const bu4*>(sO + row * LDO + ch * 8);
+      __builtin_amdgcn_raw_buffer_store_b128(v, ro, row < rowsp ? ((t0p + row) * (3 * D) + ch * 8) * 2 : (int)OOB, 0, 0);
     }
   };
-  issue_loads(0);
   // swizzled chunk position inside a 256-byte row of the V image (conflict-free transposing reads)
   auto vchunk = [](int row, int ch) { return ch ^ (((row & 3) << 2) | ((row >> 2) & 3)); };
 
   for (int t0 = 0; t0 < p.T; t0 += C) {
     const int rows = min(C, p.T - t0);
     // ---- (a) staging ---------------------------------------------------------------------------------
-    if (sr < rows) *reinterpret_cast<uint4*>(ob + (int64_t)(t0 + sr) * (3 * D) + 2 * D + sc * 8) = pv;
-    *reinterpret_cast<uint4*>(sQ + (sc * C + sr) * 8) = pq;
-    *reinterpret_cast<uint4*>(sK + (sc * C + sr) * 8) = pk;
-    *reinterpret_cast<uint4*>(sV + sr * E + vchunk(sr, sc) * 8) = pp;
-    *reinterpret_cast<uint4*>(sV + sr * E + vchunk(sr, D / 8 + sc) * 8) = pv;
-    if (t0 + C < p.T) issue_loads(t0 + C);
+    if (SEA_EXP != 32 && SEA_EXP != 31) __builtin_amdgcn_raw_buffer_store_b128(pv, ro, sr < rows ? ((t0 + sr) * (3 * D) + 2 * D + sc * 8) * 2 : (int)OOB, 0, 0);
+    *reinterpret_cast<bu4*>(sQ + (sc * C + sr) * 8) = pq;
+    *reinterpret_cast<bu4*>(sK + (sc * C + sr) * 8) = pk;
+    *reinterpret_cast<bu4*>(sV + sr * E + vchunk(sr, sc) * 8) = pp;
+    *reinterpret_cast<bu4*>(sV + sr * E + vchunk(sr, D / 8 + sc) * 8) = pv;
+    if (t0 > 0 && SEA_EXP != 31) flush_out(t0 - C, C);      // (block-uniform)
+    if (SEA_EXP != 33) issue_loads(t0 + C);                                   // rows beyond T come back as zeros
     __syncthreads();
+    PSTAMP(0);   // (a) staging
 
     // ---- (b) feature maps, transposed: X^T[f][t] = sum_d W[f][d] x[t][d]; wave = (Q | K, row block) ----------
     {
@@ -441,11 +469,15 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
           if (f >= p.nb || row >= rows) val = 0.f;           // padded features / rows beyond T contribute nothing
           bf_split(val, hh[r], ll[r]);
         }
-        *reinterpret_cast<uint2*>(dh + row * LDP + fb * 16 + lg * 4) = pack4(hh);
-        *reinterpret_cast<uint2*>(dl + row * LDP + fb * 16 + lg * 4) = pack4(ll);
+        // feature 32kk + 16a + 4g + j is stored at position 32kk + 8g + 4a + j: the 8 features lane group g needs of
+        // a 32-wide k-step in (d) (4 of tile 2kk, 4 of tile 2kk+1) are then one 16-byte piece
+        const int pos = (fb >> 1) * 32 + lg * 8 + (fb & 1) * 4;
+        *reinterpret_cast<uint2*>(dh + row * LDP + pos) = pack4(hh);
+        *reinterpret_cast<uint2*>(dl + row * LDP + pos) = pack4(ll);
       }
     }
     __syncthreads();
+    PSTAMP(1);   // (b) feature maps
 
     // ---- (c) A^T tiles (lower triangle), denominator and k-sum partials ------------------------------------
     for (int tile = wv; tile < RB * (RB + 1) / 2; tile += NW) {
@@ -480,42 +512,60 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
       if (lg == 0) sDenP[trow * DSL + jb] = rs;              // one writer per (row, key block)
     }
     {
-      // carry part of the denominators: phi(q_t) . (ksum + eps), and the k-sum increment of this chunk
-      const int row = tid & (C - 1), part = tid / C;         // 8 parts x (FP/8) features
+      // carry part of the denominators: phi(q_t) . (ksum + eps) over the (permuted) feature positions
+      const int row = tid & (C - 1), part = tid / C;         // 8 parts x (FP/8) positions
       constexpr int PER = FP / (NTH / C);
-      float s = 0.f, ks_ = 0.f;
+      float s = 0.f;
 #pragma unroll
-      for (int j = 0; j < PER; ++j) {
-        const int f = part * PER + j;
-        const float q = bf_val(sQh[row * LDP + f]) + bf_val(sQl[row * LDP + f]);
-        s = fmaf(q, sKsum[f] + 1e-6f, s);
+      for (int g4 = 0; g4 < PER / 4; ++g4) {
+        const int f = part * PER + g4 * 4;
+        const uint2 qh = *reinterpret_cast<const uint2*>(sQh + row * LDP + f);
+        const uint2 ql = *reinterpret_cast<const uint2*>(sQl + row * LDP + f);
+        const float4 ks = *reinterpret_cast<const float4*>(sKsum + f);
+        s = fmaf(bf_val((unsigned short)(qh.x & 0xffff)) + bf_val((unsigned short)(ql.x & 0xffff)), ks.x + 1e-6f, s);
+        s = fmaf(bf_val((unsigned short)(qh.x >> 16)) + bf_val((unsigned short)(ql.x >> 16)), ks.y + 1e-6f, s);
+        s = fmaf(bf_val((unsigned short)(qh.y & 0xffff)) + bf_val((unsigned short)(ql.y & 0xffff)), ks.z + 1e-6f, s);
+        s = fmaf(bf_val((unsigned short)(qh.y >> 16)) + bf_val((unsigned short)(ql.y >> 16)), ks.w + 1e-6f, s);
       }
       sDenP[row * DSL + RB + part] = s;
-      // k-sum increment: thread (feature f2, part part2) adds its share of the chunk rows
-      constexpr int KPARTS = NTH / FP, RPP = (C + KPARTS - 1) / KPARTS;
-      const int f2 = tid % FP, part2 = tid / FP;
-      if (part2 < KPARTS) {
-        for (int j = 0; j < RPP; ++j) {
-          const int r2 = part2 * RPP + j;
-          if (r2 < C) ks_ += bf_val(sKh[r2 * LDP + f2]) + bf_val(sKl[r2 * LDP + f2]);
+      // k-sum increment: wave w owns rows 8w .. 8w+7; lane = (4-position group fc, row lane rr)
+      constexpr int FG = FP / 4, RRN = 64 / FG, RPL = (C / NW) / RRN;
+      const int fc = lane % FG, rr = lane / FG;
+      float k4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (rr < RRN) {
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+          const int r2 = wv * (C / NW) + rr * RPL + j;
+          const uint2 kh = *reinterpret_cast<const uint2*>(sKh + r2 * LDP + fc * 4);
+          const uint2 kl = *reinterpret_cast<const uint2*>(sKl + r2 * LDP + fc * 4);
+          k4[0] += bf_val((unsigned short)(kh.x & 0xffff)) + bf_val((unsigned short)(kl.x & 0xffff));
+          k4[1] += bf_val((unsigned short)(kh.x >> 16)) + bf_val((unsigned short)(kl.x >> 16));
+          k4[2] += bf_val((unsigned short)(kh.y & 0xffff)) + bf_val((unsigned short)(kl.y & 0xffff));
+          k4[3] += bf_val((unsigned short)(kh.y >> 16)) + bf_val((unsigned short)(kl.y >> 16));
         }
-        sKsP[part2 * FP + f2] = ks_;
       }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+#pragma unroll
+        for (int o = FG * (RRN / 2); o >= FG; o >>= 1) k4[j] += __shfl_down(k4[j], o);   // fixed order
+      }
+      if (lane < FG) *reinterpret_cast<float4*>(sKsP + wv * FP + fc * 4) = make_float4(k4[0], k4[1], k4[2], k4[3]);
     }
     __syncthreads();
     if (tid < C) {
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < DSL; ++i) s += sDenP[tid * DSL + i];
-      sDen[tid] = s;
+      sDen[tid] = 1.0f / s;                                  // the 16 column waves multiply by the reciprocal
     } else if (tid >= C && tid < C + FP) {
       const int f = tid - C;
       float s = sKsum[f];
 #pragma unroll
-      for (int i = 0; i < NTH / FP; ++i) s += sKsP[i * FP + f];   // fixed order: bitwise reproducible
+      for (int i = 0; i < NW; ++i) s += sKsP[i * FP + f];         // fixed order: bitwise reproducible
       sKsum[f] = s;
     }
     __syncthreads();
+    PSTAMP(2);   // (c) A + denominators + k-sum
 
     // ---- (d) O = A V + phi(Q) S over this wave's 16 columns; (e) S += phi(K)^T V ------------------------------
     {
@@ -559,10 +609,8 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
         const uint4 bh = cat8(pack4(h0), pack4(h1)), bl = cat8(pack4(l0), pack4(l1));
 #pragma unroll
         for (int ib = 0; ib < RB; ++ib) {
-          const unsigned short* qrh = sQh + (ib * 16 + li) * LDP + kk * 32 + lg * 4;
-          const unsigned short* qrl = sQl + (ib * 16 + li) * LDP + kk * 32 + lg * 4;
-          const uint4 ah = cat8(*reinterpret_cast<const uint2*>(qrh), *reinterpret_cast<const uint2*>(qrh + 16));
-          const uint4 al = cat8(*reinterpret_cast<const uint2*>(qrl), *reinterpret_cast<const uint2*>(qrl + 16));
+          const uint4 ah = *reinterpret_cast<const uint4*>(sQh + (ib * 16 + li) * LDP + kk * 32 + lg * 8);
+          const uint4 al = *reinterpret_cast<const uint4*>(sQl + (ib * 16 + li) * LDP + kk * 32 + lg * 8);
           o[ib] = SEA_MFMA_BF(ah, bh, o[ib]);
           o[ib] = SEA_MFMA_BF(ah, bl, o[ib]);
           o[ib] = SEA_MFMA_BF(al, bh, o[ib]);
@@ -574,7 +622,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = ib * 16 + lg * 4 + r;
-          if (row < rows) ob[(int64_t)(t0 + row) * (3 * D) + col] = from_f<T>(o[ib][r] / sDen[row]);
+          sO[row * LDO + col] = bf_bits(o[ib][r] * sDen[row]);
         }
       }
       // (e) S[f][e] += sum_s phi(k_s)[f] V[s][e]: A operand = phi(K)^T by transposing reads of the row-major images
@@ -585,7 +633,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 #pragma unroll
           for (int ks = 0; ks < C / 32; ++ks) {
             const int r0 = ks * 32 + lg * 8;
-            const int co = rb * 16 + 4 * pp_;
+            const int co = (rb >> 1) * 32 + 8 * pp_ + (rb & 1) * 4;      // positions of features 16rb + 4p .. +3
             const uint4 kh = cat8(lds_tr(sKh + (r0 + q) * LDP + co), lds_tr(sKh + (r0 + 4 + q) * LDP + co));
             const uint4 kl = cat8(lds_tr(sKl + (r0 + q) * LDP + co), lds_tr(sKl + (r0 + 4 + q) * LDP + co));
             S[rb] = SEA_MFMA_BF(kh, vf[ks], S[rb]);
@@ -595,6 +643,11 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
       }
     }
     __syncthreads();
+    PSTAMP(3);   // (d)+(e)
+  }
+  {
+    const int t0l = ((p.T - 1) / C) * C;
+    flush_out(t0l, p.T - t0l);
   }
 }
 
@@ -620,8 +673,8 @@ static int launch_perf(const PerfParams& p, hipStream_t s) {
 template <int NBT>
 static int launch_perf_bf16(const PerfParams& p, hipStream_t s) {
   constexpr int D = 64, C = 64, NTH = 512, E = 2 * D, NBP = NBT * 16, FP = ((NBT + 1) / 2) * 32, LDP = FP + 8, LDA = C + 8;
-  constexpr size_t lds = 2 * ((D / 8) * NBP * 8 + 2 * (D / 8) * C * 8 + C * E + 4 * C * LDP + 2 * C * LDA) +
-                         sizeof(float) * (FP + C + C * (C / 16 + NTH / C) + (NTH / FP) * FP);
+  constexpr size_t lds = 2 * ((D / 8) * NBP * 8 + 2 * (D / 8) * C * 8 + C * E + 4 * C * LDP + 2 * C * LDA + C * (E + 8)) +
+                         sizeof(float) * (FP + C + C * (C / 16 + NTH / C) + 8 * FP);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool configured = false;
   if (!configured) {
