@@ -242,11 +242,11 @@ __global__ __launch_bounds__(256) void sparse_attn_kernel(AttnParams p) {
 // softmax; nothing is merged across groups.  A wave therefore has 64/LPR independent
 // (offsets -> col -> K/V) load chains in flight instead of one, which is what the wave-per-row mapping lacks.
 // Workgroup = 4 waves = 256/LPR consecutive query rows of one (n, h).
-template <typename T, typename TO, int LPR, int U>
-__global__ __launch_bounds__(256) void sparse_attn_rows_kernel(AttnParams p) {
+template <typename T, typename TO, int LPR, int U, int NWB = 4>
+__global__ __launch_bounds__(NWB * 64) void sparse_attn_rows_kernel(AttnParams p) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr int RPW = 64 / LPR;       // rows per wave
-  constexpr int RPB = 4 * RPW;        // rows per workgroup
+  constexpr int RPB = NWB * RPW;      // rows per workgroup
   int pair, tb;
   if (!map_block(p.N * p.H, p.TB, &pair, &tb)) return;
   const int n = pair / p.H, h = pair - n * p.H;
@@ -491,6 +491,17 @@ static int launch_attn(AttnParams p, hipStream_t s) {
   const int esz = (int)sizeof(T);
   const bool small = p.T_src < (1 << 24) && p.ks[2] * esz < (1 << 24) && p.vs[2] * esz < (1 << 24) &&
                      (int64_t)p.T_src * p.ks[2] * esz < (1ll << 31) && (int64_t)p.T_src * p.vs[2] * esz < (1ll << 31);
+  static const int nwb_env = [] { const char* e = getenv("SEA_ATTN_WAVES"); return e ? atoi(e) : 4; }();
+  if (attn_variant() == 1 && lpr == 8 && small && nwb_env != 4) {   // experiment: larger workgroups (same-pair rows share a CU)
+    const int nwb = nwb_env >= 16 ? 16 : 8;
+    const int rpb = nwb * 8;
+    p.TB = (p.T_dst + rpb - 1) / rpb;
+    const int64_t blocks = (int64_t)8 * ((NH + 7) / 8) * p.TB;
+    dim3 grid((unsigned)blocks), block(nwb * 64);
+    if (nwb == 16) hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 8, 4, 16>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 8, 4, 8>), grid, block, 0, s, p);
+    return SEA_OK;
+  }
   if (attn_variant() == 1 && lpr <= 16 && small) {
     const int rpb = 4 * (64 / lpr);
     p.TB = (p.T_dst + rpb - 1) / rpb;
