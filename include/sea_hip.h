@@ -186,6 +186,19 @@ int sea_predictor_tail(const void* y, int dtype, int64_t N, int64_t C, int64_t H
                        const void* gamma, const void* beta, float eps,
                        void* probs, void* scores, sea_stream_t stream);
 
+/* Predictor tail + grouped top-k selection in one launch: sea_predictor_tail (MFMA variant, 16-bit
+ * channels-last / C8 input) followed by sea_topk_select on the probability map it produces, with the map's values
+ * handed over in registers -- the (N,H,T,T_m) map is still written (the module returns it) but never re-read.
+ * Bit-identical to the two separate calls.  Requires T_m = 256 (W4 = 64, up = 4), H % 4 == 0, H <= 64.
+ * Arguments as in sea_predictor_tail (conv_w16 mandatory, no FP32 weight copy) and sea_topk_select
+ * (keep / keep_stride_n / T_src / is_causal / max_k -> bits / row_nnz / head_off). */
+int sea_predictor_tail_select(const void* y, int dtype, int64_t N, int64_t C, int64_t H, int64_t T, int64_t W4,
+                              int64_t up, int64_t T_m, const int64_t* y_strides, const void* conv_b,
+                              const void* conv_w16, int64_t Cp, const void* gamma, const void* beta, float eps,
+                              void* probs, void* scores, const int32_t* keep, int64_t keep_stride_n,
+                              int64_t T_src, int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz,
+                              int32_t* head_off, sea_stream_t stream);
+
 /* Causal cumulative average out[n,h,t,:] = sum_{s<=t} v[n,h,s,:] / (t+1), fp32 accumulation.
  * Replaces `avg_v.cumsum(-2) / arange(1..T)` (attention.py:1220-1222).  out (N,H,T,D) contiguous. */
 int sea_cumavg(const void* v, int dtype, int64_t N, int64_t H, int64_t T, int64_t D, const int64_t* v_strides,

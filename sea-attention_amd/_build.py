@@ -7,7 +7,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libsea_hip.so")
 SOURCES = ["sea_topk.hip", "sea_attn.hip", "sea_csr_ops.hip", "sea_predictor.hip", "sea_performer.hip", "sea_conv.hip", "sea_mlp.hip"]
-HEADERS = [os.path.join(CSRC, "sea_common.hpp"), os.path.join(os.path.dirname(PKG_DIR), "include", "sea_hip.h")]
+HEADERS = [os.path.join(CSRC, "sea_common.hpp"), os.path.join(CSRC, "sea_tail.hpp"), os.path.join(os.path.dirname(PKG_DIR), "include", "sea_hip.h")]
 
 
 def _hipcc():

@@ -97,20 +97,58 @@ template <typename T> __device__ inline uint32_t pack2(float a, float b) {
 // ---- wave-level primitives -----------------------------------------------------------------
 __device__ inline int lane_id() { return threadIdx.x & 63; }
 
-template <typename T> __device__ inline T wave_sum(T v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+// All-lanes reductions over the 64 lanes without LDS traffic: four DPP steps inside each row of 16 lanes (quad_perm
+// xor 1 / xor 2, row_half_mirror, row_mirror), then the gfx950 row-swap instructions v_permlane16_swap /
+// v_permlane32_swap for the cross-row steps.  ~10 VALU instructions with a few cycles of latency each, against six
+// dependent ds_bpermute round trips (~100+ cycles each) for the __shfl_xor butterfly.  Every lane ends with the
+// same bits (each level combines the same two partial results, and + / max / min commute).
+template <int CTRL> __device__ inline uint32_t dpp_u32(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true);
+}
+template <typename T, typename Op> __device__ inline T wave_reduce32(T v, Op op) {
+  static_assert(sizeof(T) == 4, "32-bit types");
+  auto bits = [](T x) { return __builtin_bit_cast(uint32_t, x); };
+  auto val = [](uint32_t x) { return __builtin_bit_cast(T, x); };
+  v = op(v, val(dpp_u32<0xB1>(bits(v))));    // quad_perm [1,0,3,2]
+  v = op(v, val(dpp_u32<0x4E>(bits(v))));    // quad_perm [2,3,0,1]
+  v = op(v, val(dpp_u32<0x141>(bits(v))));   // row_half_mirror
+  v = op(v, val(dpp_u32<0x140>(bits(v))));   // row_mirror
+  {
+    const auto r = __builtin_amdgcn_permlane16_swap(bits(v), bits(v), false, false);
+    v = op(val(r[0]), val(r[1]));
+  }
+  {
+    const auto r = __builtin_amdgcn_permlane32_swap(bits(v), bits(v), false, false);
+    v = op(val(r[0]), val(r[1]));
+  }
   return v;
+}
+template <typename T> __device__ inline T wave_sum(T v) {
+  if constexpr (sizeof(T) == 4) {
+    return wave_reduce32(v, [](T a, T b) { return a + b; });
+  } else {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+  }
 }
 template <typename T> __device__ inline T wave_max(T v) {
+  if constexpr (sizeof(T) == 4) {
+    return wave_reduce32(v, [](T a, T b) { return b > a ? b : a; });
+  } else {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { T t = __shfl_xor(v, o); v = t > v ? t : v; }
-  return v;
+    for (int o = 32; o > 0; o >>= 1) { T t = __shfl_xor(v, o); v = t > v ? t : v; }
+    return v;
+  }
 }
 template <typename T> __device__ inline T wave_min(T v) {
+  if constexpr (sizeof(T) == 4) {
+    return wave_reduce32(v, [](T a, T b) { return b < a ? b : a; });
+  } else {
 #pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { T t = __shfl_xor(v, o); v = t < v ? t : v; }
-  return v;
+    for (int o = 32; o > 0; o >>= 1) { T t = __shfl_xor(v, o); v = t < v ? t : v; }
+    return v;
+  }
 }
 // inclusive scan over the 64 lanes
 template <typename T> __device__ inline T wave_incl_scan(T v) {

@@ -1,0 +1,153 @@
+// Device pieces of the predictor tail (MFMA variant) shared by predictor_tail_mfma_kernel (sea_predictor.hip) and the
+// fused tail + top-k selection kernel (sea_topk.hip).  See sea_predictor.hip for what the tail computes.
+#pragma once
+#include "sea_common.hpp"
+
+namespace sea {
+
+struct TailParams {
+  const void* y;     // (N, C, T, W4)
+  const void* w4;    // (C, Hpad) fp32: the live row of the (H, C, 1, 1) conv weight, transposed, heads padded to 8
+  const void* b4;    // (Hpad) fp32
+  const void* gamma; // (T_M)
+  const void* beta;  // (T_M)
+  void* probs;       // (N, H, T, T_M)
+  void* scores;      // optional (N, H, T, T_M)
+  float eps;
+  int N, C, H, T, W4, UP, T_M;
+  int64_t ys_n, ys_c, ys_t, ys_w;  // element strides of y (NCHW: ys_w == 1; channels-last / C8: ys_c == 1)
+  int64_t ys_c8;                   // stride between blocks of 8 channels (8*ys_c for plain 4-D layouts; W*8 for C8)
+  const void* w16;   // MFMA variant: (HP16, Cp) 16-bit row-major copy of the conv weight, zero padded
+  int Cp;            // channels padded to a multiple of 32
+};
+
+template <typename T, int E> __device__ inline void store_run(T* dst, const float* f, int j0, int T_M) {
+  if (E == 4 && sizeof(T) == 2 && j0 + 4 <= T_M) {
+    union { uint2 u; T h[4]; } pk;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pk.h[e] = from_f<T>(f[e]);
+    *reinterpret_cast<uint2*>(dst + j0) = pk.u;
+  } else if (E == 4 && sizeof(T) == 4 && j0 + 4 <= T_M) {
+    *reinterpret_cast<float4*>(reinterpret_cast<float*>(dst) + j0) = make_float4(f[0], f[1], f[2], f[3]);
+  } else {
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (j0 + e < T_M) dst[j0 + e] = from_f<T>(f[e]);
+  }
+}
+
+typedef __attribute__((ext_vector_type(4))) float tf4;
+typedef __attribute__((ext_vector_type(8))) __bf16 tbf8;
+typedef __attribute__((ext_vector_type(8))) _Float16 th8;
+template <typename T> __device__ inline tf4 tail_mfma(const uint4& a, const uint4& b, tf4 c);
+template <> __device__ inline tf4 tail_mfma<__hip_bfloat16>(const uint4& a, const uint4& b, tf4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(tbf8, a), __builtin_bit_cast(tbf8, b), c, 0, 0, 0);
+}
+template <> __device__ inline tf4 tail_mfma<__half>(const uint4& a, const uint4& b, tf4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(th8, a), __builtin_bit_cast(th8, b), c, 0, 0, 0);
+}
+
+
+// ---- z = y W^T + b: (W4 pixels x C) @ (C x H) on v_mfma_f32_16x16x32, A fragments straight from global -----------
+// z lands in LDS as [head][pixel] with [W4] = bias and [W4+1] = 0 per row (turn padded / unused taps of the area
+// resize into plain reads).  256 threads; the caller barriers before reading s_z.
+template <typename T>
+__device__ __forceinline__ void tail_z_tile(const TailParams& p, float* s_z, int n, int t) {
+  const int lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int HP = ((p.H + 15) / 16) * 16;
+  const int LDZ = p.W4 + 3;
+  const float* __restrict__ bF = reinterpret_cast<const float*>(p.b4);
+  const T* __restrict__ w16 = reinterpret_cast<const T*>(p.w16);
+  const T* yb = reinterpret_cast<const T*>(p.y) + n * p.ys_n + t * p.ys_t;
+  const int MT = (p.W4 + 15) / 16, NT = HP / 16, KC = p.Cp / 32;
+  for (int mt = wv; mt < MT; mt += 4) {
+    const int wpix = mt * 16 + li;
+    for (int nt = 0; nt < NT; ++nt) {
+      tf4 acc = tf4{0.f, 0.f, 0.f, 0.f};
+      for (int kc = 0; kc < KC; ++kc) {
+        const int ci = kc * 32 + 8 * lg;
+        uint4 a = make_uint4(0, 0, 0, 0);
+        if (ci < p.C && wpix < p.W4) a = *reinterpret_cast<const uint4*>(yb + (int64_t)wpix * p.ys_w + (ci >> 3) * p.ys_c8);
+        const uint4 b = *reinterpret_cast<const uint4*>(w16 + (nt * 16 + li) * p.Cp + ci);
+        acc = tail_mfma<T>(a, b, acc);
+      }
+      const int h = nt * 16 + li;                // C layout: col = li -> head, row = lg*4 + r -> pixel
+      const float bias = h < p.H ? bF[h] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int px = mt * 16 + lg * 4 + r;
+        if (px < p.W4) s_z[h * LDZ + px] = acc[r] + bias;
+      }
+    }
+  }
+  for (int h = threadIdx.x; h < HP; h += 256) { s_z[h * LDZ + p.W4] = h < p.H ? bF[h] : 0.f; s_z[h * LDZ + p.W4 + 1] = 0.f; }
+}
+
+// ---- per-lane constants of the area-resize / LayerNorm stage + one head's row -----------------------------------
+template <typename T, int E>
+struct TailRow {
+  float g[E], be[E], rcnt[E];
+  int src[E][3];   // index into the z row: pixel, W4 (bias: zero-padded border) or W4+1 (unused tap)
+
+  __device__ __forceinline__ void init(const TailParams& p, int lane) {
+    const int Wp = p.W4 * p.UP + 2;
+    const T* gam = reinterpret_cast<const T*>(p.gamma);
+    const T* bet = reinterpret_cast<const T*>(p.beta);
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      const int j = lane * E + e;
+      g[e] = 0.f; be[e] = 0.f; rcnt[e] = 0.f;
+      src[e][0] = src[e][1] = src[e][2] = p.W4 + 1;
+      if (j < p.T_M) {
+        g[e] = Elem<T>::to_f(gam[j]); be[e] = Elem<T>::to_f(bet[j]);
+        const int xs = (int)floorf((float)(j * Wp) / (float)p.T_M);
+        const int xe = (int)ceilf((float)((j + 1) * Wp) / (float)p.T_M);
+        rcnt[e] = 1.0f / (float)(xe - xs);
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          const int x = xs + k;
+          if (x < xe) src[e][k] = (x == 0 || x == Wp - 1) ? p.W4 : (x - 1) / p.UP;
+        }
+      }
+    }
+  }
+
+  // area resize -> LayerNorm -> (scores) -> softmax -> probs of head h (one wave); a[] returns the probabilities
+  __device__ __forceinline__ void head(const TailParams& p, const float* zr, int lane, int64_t obase, float (&a)[E]) const {
+    const float invT = 1.0f / (float)p.T_M;
+    float s1 = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      a[e] = (zr[src[e][0]] + zr[src[e][1]] + zr[src[e][2]]) * rcnt[e];
+      s1 += a[e];
+    }
+    const float mean = wave_sum(s1) * invT;
+    float s2 = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e)
+      if (lane * E + e < p.T_M) { const float d = a[e] - mean; s2 += d * d; }
+    const float rstd = rsqrtf(wave_sum(s2) * invT + p.eps);
+    float mx = -INFINITY;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      a[e] = (a[e] - mean) * rstd * g[e] + be[e];
+      if (lane * E + e < p.T_M) mx = fmaxf(mx, a[e]);
+    }
+    mx = wave_max(mx);
+    if (p.scores) store_run<T, E>(reinterpret_cast<T*>(p.scores) + obase, a, lane * E, p.T_M);
+    float se = 0.f;
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      a[e] = (lane * E + e < p.T_M) ? __expf(a[e] - mx) : 0.f;
+      se += a[e];
+    }
+    const float inv = 1.0f / wave_sum(se);
+#pragma unroll
+    for (int e = 0; e < E; ++e) a[e] *= inv;
+    store_run<T, E>(reinterpret_cast<T*>(p.probs) + obase, a, lane * E, p.T_M);
+  }
+};
+
+}  // namespace sea

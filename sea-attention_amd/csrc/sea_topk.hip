@@ -15,6 +15,7 @@
 //
 // Everything here is HBM-bound integer/compare work; LDS holds the score histogram only.
 #include "sea_common.hpp"
+#include "sea_tail.hpp"
 
 #ifndef SEA_EXP
 #define SEA_EXP 0
@@ -204,8 +205,12 @@ __device__ inline long long block_excl_scan64(long long v, long long* s_wave /*[
   return base + incl - v;
 }
 
+// Everything after the keys of the row are in registers: threshold search, bit mask, per-head entry counts.
+// Shared by topk_select_kernel (keys loaded from the probability map) and predictor_tail_select_kernel (keys
+// produced in registers by the predictor tail).  `base` = the row's probabilities in memory (slow path only).
 template <typename T, int EPT, bool FROM_MASK, bool FULL>
-__global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(TopkParams p) {
+__device__ __forceinline__ void select_body(const TopkParams& p, uint32_t (&key)[EPT], unsigned long long sel, int n, int t,
+                                            int row, const T* base) {
   constexpr int R = EPT / 4;  // chunk rounds
   __shared__ int s_hist[TK_MAX_BINS + 1];          // +1: dump bin for unused register slots
   __shared__ int s_head[1024];
@@ -219,42 +224,14 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(TopkParams p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
-  const int row = blockIdx.x;
-  const int n = row / p.T_dst, t = row - n * p.T_dst;
-  const T* base = reinterpret_cast<const T*>(p.src) + n * p.sn + t * p.st;
 #ifdef SEA_STAMP
   unsigned long long _tprev = __builtin_amdgcn_s_memtime();
 #endif
-
-  // ---- load the row: chunk c = j*256 + tid covers flat pixels 4c..4c+3 (head-major) ------------
-  uint32_t key[EPT];
-  unsigned long long sel = 0;  // bit (4*j + e): element e of round j is kept
-#pragma unroll
-  for (int j = 0; j < R; ++j) {
-    const int c = j * TK_THREADS + tid;
-    float f[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool valid = FULL || c < p.nchunks;
-    if (valid) {
-      const int f0 = c * 4;
-      const int h = f0 / p.T_m, b0 = f0 - h * p.T_m;
-      load4<T>(base + h * p.sh + b0, f);
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (FROM_MASK) {
-        if (valid && f[e] != 0.f) sel |= 1ull << (4 * j + e);
-        key[4 * j + e] = 0;
-      } else {
-        key[4 * j + e] = valid ? f2key(f[e]) : 0u;
-      }
-    }
-  }
   // LDS scratch is cleared while the loads are in flight
   for (int i = tid; i <= TK_MAX_BINS; i += TK_THREADS) s_hist[i] = 0;
   for (int i = tid; i < 512; i += TK_THREADS) s_selbits[i] = 0;
   for (int i = tid; i < p.H; i += TK_THREADS) s_head[i] = 0;
   if (tid == 0) s_ncand = 0;
-  STAMP(0);   // row loaded, keys built
 
   if (!FROM_MASK) {
 #if SEA_EXP == 1
@@ -371,42 +348,52 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(TopkParams p) {
   // ---- outputs ----------------------------------------------------------------------------------
   const int w_t = row_width(t, p.T_dst, p.T_src, p.is_causal);
   const float scale = interp_scale(w_t, p.T_m);
+  // pixel bounds of this row (shared by all heads) in the candidate array, which the selection no longer needs
+  int* s_bnd = reinterpret_cast<int*>(s_ckey);
+  const bool table = p.T_m < TK_CAND_CAP;
+  if (table) {
+    for (int m = tid; m <= p.T_m; m += TK_THREADS) s_bnd[m] = (int)interp_bound(m, scale);
+    __syncthreads();
+  }
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     const int c = j * TK_THREADS + tid;
     const bool valid = FULL || c < p.nchunks;
     const uint32_t nib = (uint32_t)(sel >> (4 * j)) & 0xFu;
-    // bit mask: 8 consecutive lanes own one 32-bit word
+    // bit mask: 8 consecutive lanes own one 32-bit word (OR over the 8 lanes by DPP: xor 1, xor 2, half-row mirror)
     uint32_t word = nib << (4 * (lane & 7));
-    word |= __shfl_xor(word, 1);
-    word |= __shfl_xor(word, 2);
-    word |= __shfl_xor(word, 4);
+    word |= dpp_u32<0xB1>(word);
+    word |= dpp_u32<0x4E>(word);
+    word |= dpp_u32<0x141>(word);
     if ((lane & 7) == 0 && (c >> 3) < p.W) p.bits[(int64_t)row * p.W + (c >> 3)] = word;
-    if (p.mask_out != nullptr && valid) {
+    int h = 0, b0 = 0;
+    if ((p.mask_out != nullptr && valid) || nib) {
       const int f0 = c * 4;
-      const int h = f0 / p.T_m, b0 = f0 - h * p.T_m;
+      h = f0 / p.T_m; b0 = f0 - h * p.T_m;
+    }
+    if (p.mask_out != nullptr && valid) {
       float4 m;
       m.x = (nib & 1u) ? 1.f : 0.f; m.y = (nib & 2u) ? 1.f : 0.f;
       m.z = (nib & 4u) ? 1.f : 0.f; m.w = (nib & 8u) ? 1.f : 0.f;
       *reinterpret_cast<float4*>(p.mask_out + (((int64_t)n * p.H + h) * p.T_dst + t) * p.T_m + b0) = m;
     }
-  }
-  // entries each kept pixel will emit: min(v_end - v_start, max_k), accumulated per head.  Only kept pixels
-  // are visited (a row keeps ~K_t << H*T_m of them once t is large).
+    // entries each kept pixel will emit: min(v_end - v_start, max_k); the 4 pixels of a chunk share a head
+    // (T_m % 4 == 0), so one LDS atomic per chunk that keeps anything
 #if SEA_EXP != 2
-  {
-    unsigned long long m = sel;
-    while (m) {
-      const int i = __ffsll((long long)m) - 1;
-      m &= m - 1;
-      const int f = ((i >> 2) * TK_THREADS + tid) * 4 + (i & 3);
-      const int h = f / p.T_m, b = f - h * p.T_m;
-      int w = (int)(interp_bound(b + 1, scale) - interp_bound(b, scale));
-      w = w < p.max_k ? w : p.max_k;
-      if (w > 0) atomicAdd(&s_head[h], w);
+    if (nib) {
+      int wsum = 0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (nib & (1u << e)) {
+          const int b = b0 + e;
+          int w = table ? s_bnd[b + 1] - s_bnd[b] : (int)(interp_bound(b + 1, scale) - interp_bound(b, scale));
+          wsum += w < p.max_k ? w : p.max_k;
+        }
+      }
+      if (wsum > 0) atomicAdd(&s_head[h], wsum);
     }
-  }
 #endif
+  }
   __syncthreads();
   STAMP(4);   // bit mask + widths + head counts
   // exclusive scan over heads (first wave, 64 heads per step)
@@ -422,6 +409,77 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(TopkParams p) {
     }
     if (lane == 0) { ho[p.H] = carry; p.row_nnz[row] = carry; }
   }
+}
+
+template <typename T, int EPT, bool FROM_MASK, bool FULL>
+__global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(TopkParams p) {
+  constexpr int R = EPT / 4;  // chunk rounds
+  const int tid = threadIdx.x;
+  const int row = blockIdx.x;
+  const int n = row / p.T_dst, t = row - n * p.T_dst;
+  const T* base = reinterpret_cast<const T*>(p.src) + n * p.sn + t * p.st;
+#ifdef SEA_STAMP
+  unsigned long long _tprev = __builtin_amdgcn_s_memtime();
+#endif
+
+  // ---- load the row: chunk c = j*256 + tid covers flat pixels 4c..4c+3 (head-major) ------------
+  uint32_t key[EPT];
+  unsigned long long sel = 0;  // bit (4*j + e): element e of round j is kept
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int c = j * TK_THREADS + tid;
+    float f[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool valid = FULL || c < p.nchunks;
+    if (valid) {
+      const int f0 = c * 4;
+      const int h = f0 / p.T_m, b0 = f0 - h * p.T_m;
+      load4<T>(base + h * p.sh + b0, f);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (FROM_MASK) {
+        if (valid && f[e] != 0.f) sel |= 1ull << (4 * j + e);
+        key[4 * j + e] = 0;
+      } else {
+        key[4 * j + e] = valid ? f2key(f[e]) : 0u;
+      }
+    }
+  }
+  STAMP(0);   // row loaded, keys built
+  select_body<T, EPT, FROM_MASK, FULL>(p, key, sel, n, t, row, base);
+}
+
+// ---- predictor tail + grouped top-k in one launch ("emit probs in the top-k kernel's layout") ------------
+// With T_m = 256 the two kernels already agree on who holds what: wave w of the 256-thread workgroup of row (n, t)
+// produces the probabilities of heads 4j + w (j = 0, 1, ...), lane l those of pixels 4l .. 4l+3 -- exactly flat chunk
+// c = 256j + tid of the selection kernel.  So the tail's softmax output, rounded to the map's dtype, is stored for the
+// caller (the module returns the map) AND becomes the selection key in registers: the selection never re-reads the
+// (N,H,T,T_m) map from memory.  Results are bit-identical to the two-launch path (same arithmetic, same rounding).
+template <typename T, int EPT, bool FULL>
+__global__ __launch_bounds__(TK_THREADS) void predictor_tail_select_kernel(TailParams tp, TopkParams p) {
+  constexpr int R = EPT / 4, E = 4;
+  extern __shared__ __attribute__((aligned(16))) float s_z[];     // HP x (W4 + 3)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row = blockIdx.x;
+  const int n = row / tp.T, t = row - n * tp.T;
+  const int LDZ = tp.W4 + 3;
+  tail_z_tile<T>(tp, s_z, n, t);
+  TailRow<T, E> tr;
+  tr.init(tp, lane);
+  __syncthreads();
+  uint32_t key[EPT];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int h = 4 * j + wv;                                      // wave-uniform
+    float a[E] = {0.f, 0.f, 0.f, 0.f};
+    if (FULL || h < tp.H) tr.head(tp, s_z + h * LDZ, lane, (((int64_t)n * tp.H + h) * tp.T + t) * tp.T_M, a);
+#pragma unroll
+    for (int e = 0; e < E; ++e) key[4 * j + e] = (FULL || h < tp.H) ? f2key(Elem<T>::to_f(from_f<T>(a[e]))) : 0u;
+  }
+  const T* base = reinterpret_cast<const T*>(p.src) + n * p.sn + t * p.st;   // = the map just written (slow path re-reads it)
+  select_body<T, EPT, false, FULL>(p, key, 0ull, n, t, row, base);
 }
 
 // ---- crow = exclusive scan of row_nnz ------------------------------------------------------------
@@ -689,6 +747,64 @@ extern "C" int sea_mask_to_bits(const void* mask, int dtype, int64_t N, int64_t 
                                 int max_k, uint32_t* bits, int32_t* row_nnz, int32_t* head_off, sea_stream_t stream) {
   return select_common<true>("sea_mask_to_bits", mask, dtype, N, H, T_dst, T_m, stride_n, stride_h, stride_t, nullptr, 0,
                              T_src, is_causal, max_k, bits, nullptr, row_nnz, head_off, (hipStream_t)stream);
+}
+
+template <typename T>
+static int launch_tail_select(const TailParams& tp, const TopkParams& p, int64_t rows, hipStream_t s) {
+  const int ept = ((p.nchunks + TK_THREADS - 1) / TK_THREADS) * 4;
+  const size_t lds = (size_t)(((tp.H + 15) / 16) * 16) * (tp.W4 + 3) * sizeof(float);
+  dim3 grid((unsigned)rows), block(TK_THREADS);
+#define SEA_TSEL(EE)                                                                                              \
+  do {                                                                                                            \
+    const bool full = p.nchunks == ((EE) / 4) * TK_THREADS;                                                       \
+    if (full) hipLaunchKernelGGL((predictor_tail_select_kernel<T, EE, true>), grid, block, lds, s, tp, p);        \
+    else hipLaunchKernelGGL((predictor_tail_select_kernel<T, EE, false>), grid, block, lds, s, tp, p);            \
+  } while (0)
+  if (ept <= 4) SEA_TSEL(4);
+  else if (ept <= 8) SEA_TSEL(8);
+  else if (ept <= 16) SEA_TSEL(16);
+  else if (ept <= 32) SEA_TSEL(32);
+  else if (ept <= 40) SEA_TSEL(40);
+  else SEA_TSEL(64);
+#undef SEA_TSEL
+  return SEA_OK;
+}
+
+extern "C" int sea_predictor_tail_select(const void* y, int dtype, int64_t N, int64_t C, int64_t H, int64_t T, int64_t W4,
+                                         int64_t up, int64_t T_m, const int64_t* y_strides, const void* conv_b,
+                                         const void* conv_w16, int64_t Cp, const void* gamma, const void* beta, float eps,
+                                         void* probs, void* scores, const int32_t* keep, int64_t keep_stride_n,
+                                         int64_t T_src, int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz,
+                                         int32_t* head_off, sea_stream_t stream) {
+  const char* nm = "sea_predictor_tail_select";
+  SEA_REQUIRE(y && y_strides && conv_b && conv_w16 && gamma && beta && probs && keep && bits && row_nnz && head_off, SEA_EINVAL,
+              "%s: null pointer", nm);
+  SEA_REQUIRE(dtype == SEA_F16 || dtype == SEA_BF16, SEA_EUNSUPPORTED, "%s: 16-bit data only (dtype %d)", nm, dtype);
+  SEA_REQUIRE(N > 0 && C > 0 && H > 0 && T > 0 && T_src >= T && max_k > 0, SEA_EINVAL, "%s: bad shape", nm);
+  SEA_REQUIRE(T_m == 256 && W4 == 64 && up == 4 && H % 4 == 0 && H <= 64, SEA_EUNSUPPORTED,
+              "%s: needs T_m = 256 (W4 = 64, up = 4), H %% 4 == 0, H <= 64", nm);
+  SEA_REQUIRE(y_strides[1] == 1 && C % 8 == 0 && y_strides[0] % 8 == 0 && y_strides[2] % 8 == 0 && y_strides[3] % 8 == 0 &&
+                  y_strides[4] % 8 == 0 && Cp % 32 == 0 && Cp >= C &&
+                  (((uintptr_t)y | (uintptr_t)conv_w16 | (uintptr_t)probs | (uintptr_t)scores) & 15) == 0,
+              SEA_EUNSUPPORTED, "%s: y must be channels-last / C8 with 16-byte aligned vectors", nm);
+  SEA_REQUIRE(N * T < (1ll << 31), SEA_EUNSUPPORTED, "%s: too many rows", nm);
+  TailParams tp;
+  tp.y = y; tp.w4 = nullptr; tp.b4 = conv_b; tp.gamma = gamma; tp.beta = beta; tp.probs = probs; tp.scores = scores; tp.eps = eps;
+  tp.N = (int)N; tp.C = (int)C; tp.H = (int)H; tp.T = (int)T; tp.W4 = (int)W4; tp.UP = (int)up; tp.T_M = (int)T_m;
+  tp.ys_n = y_strides[0]; tp.ys_c = y_strides[1]; tp.ys_t = y_strides[2]; tp.ys_w = y_strides[3]; tp.ys_c8 = y_strides[4];
+  tp.w16 = conv_w16; tp.Cp = (int)Cp;
+  TopkParams p;
+  p.src = probs; p.sn = H * T * T_m; p.sh = T * T_m; p.st = T_m;          // the (N,H,T,T_m) map this kernel writes
+  p.H = (int)H; p.T_dst = (int)T; p.T_m = (int)T_m; p.T_src = (int)T_src;
+  p.is_causal = is_causal; p.max_k = max_k;
+  p.M = (int)(H * T_m); p.nchunks = p.M / 4; p.W = (p.M + 31) / 32; p.G = group_lanes((int)T_m);
+  p.keep = keep; p.keep_stride_n = keep_stride_n;
+  p.bits = bits; p.mask_out = nullptr; p.row_nnz = row_nnz; p.head_off = head_off;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == SEA_F16) launch_tail_select<__half>(tp, p, N * T, s);
+  else launch_tail_select<__hip_bfloat16>(tp, p, N * T, s);
+  SEA_CHECK_LAUNCH(nm);
+  return SEA_OK;
 }
 
 extern "C" int sea_csr_row_scan(const int32_t* row_nnz, int64_t N, int64_t T_dst, void* crow, int idx_bytes,

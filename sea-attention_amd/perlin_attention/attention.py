@@ -122,6 +122,7 @@ class PerlinAttention(nn.Module):
         # debugging / parity: run the estimator's LayerNorm / conv tail through the torch modules even on GPU
         self.force_torch_estimator = False
         self._fused_gates = None            # (row_scale, average_scale) when the fused predictor MLP produced them
+        self._fused_selection = None        # (bits, row_nnz, head_off) when the tail kernel also ran the top-k selection
 
         d, H = self.attention_head_size, self.num_attention_heads
         pc = self.pconfig
@@ -297,6 +298,7 @@ class PerlinAttention(nn.Module):
                 bench.register_temp_buffer('performer_value', performer_value)
         fused_mlp = self._fused_mlp_ok(performer_value)
         self._fused_gates = None
+        self._fused_selection = None
         if fused_mlp:
             with timer("predictor"):
                 want_scores = get_bench().activate_temp_buffers or (not self.benchmarking)
@@ -317,10 +319,23 @@ class PerlinAttention(nn.Module):
                                 x = ops.causal_conv_c8(x, conv.weight, conv.bias, conv.kernel_size, conv.dilation,
                                                        conv.padding[1], relu=True)
                         conv4 = body[-1].module
+                        T_M_ = self.pconfig.attention_predictor_length
+                        Hh = self.num_attention_heads
                         with timer("cnn.tail"):
-                            estimated_attention_probs, estimated_attention_score = ops.predictor_tail(
-                                x, conv4.weight[:, :, 0, 0], conv4.bias, ln2.weight, ln2.bias, up=4,
-                                T_m=self.pconfig.attention_predictor_length, eps=ln2.eps, want_scores=want_scores)
+                            if (self.benchmarking and not_padded and not get_bench().activate_temp_buffers
+                                    and ops.predictor_tail_select_supported(x, Hh, T_M_)):
+                                # sparse mode, unpadded batch: the tail hands the map to the top-k selection in
+                                # registers (one launch; the map is still written, it is part of the module's output)
+                                keep, _z = self._keep_table(Hh, q.shape[-2], T_SRC, T_M_, q.device)
+                                estimated_attention_probs, estimated_attention_score, sel = ops.predictor_tail_select(
+                                    x, conv4.weight[:, :, 0, 0], conv4.bias, ln2.weight, ln2.bias, up=4, T_m=T_M_,
+                                    keep=keep, k=int(self.pconfig.k), T_src=T_SRC, is_causal=True, eps=ln2.eps,
+                                    want_scores=want_scores)
+                                self._fused_selection = (estimated_attention_probs, sel)
+                            else:
+                                estimated_attention_probs, estimated_attention_score = ops.predictor_tail(
+                                    x, conv4.weight[:, :, 0, 0], conv4.bias, ln2.weight, ln2.bias, up=4,
+                                    T_m=T_M_, eps=ln2.eps, want_scores=want_scores)
                 bench.register_temp_buffer('t_attention_predictor', t_attention_predictor)
             bench.register_temp_buffer('estimated_attention_score', estimated_attention_score)
             bench.register_temp_buffer('estimated_attention_probs', estimated_attention_probs)
@@ -532,8 +547,14 @@ class PerlinAttention(nn.Module):
             if not not_padded:
                 # padded query rows keep nothing (the reference zeroes those mask rows, :927-931)
                 keep = (keep.view(1, T) * (dst_attention_mask.view(N, T) > -1).to(torch.int32)).contiguous()
-            csr, mask_m = ops.topk_to_csr(probs, keep, int(self.pconfig.k), target_width=T_SRC, is_causal=True,
-                                          z_cap=z_cap, want_mask=probing)
+            fs = self._fused_selection
+            if fs is not None and fs[0] is probs and not_padded and not probing:
+                # the selection already ran inside the predictor-tail launch on this very map: scan + emit only
+                csr, mask_m = ops.csr_from_selection(*fs[1], H, T_M, T_SRC, int(self.pconfig.k), True, z_cap), None
+            else:
+                csr, mask_m = ops.topk_to_csr(probs, keep, int(self.pconfig.k), target_width=T_SRC, is_causal=True,
+                                              z_cap=z_cap, want_mask=probing)
+            self._fused_selection = None
         if probing:
             bench.register_temp_buffer('partial_attention_mask_before_interp', mask_m)
             bench.register_temp_buffer('partial_attention_mask', None,

@@ -129,6 +129,17 @@ def topk_to_csr(probs: torch.Tensor, keep: torch.Tensor, k: int, target_width: O
         probs.stride(0), probs.stride(1), probs.stride(2),
         _p(keep), keep_stride_n, T_src, int(is_causal), int(k),
         _p(bits), _p(mask), _p(row_nnz), _p(head_off), st), "sea_topk_select")
+    return csr_from_selection(bits, row_nnz, head_off, H, T_m, T_src, int(k), is_causal, z_cap, keep), mask
+
+
+def csr_from_selection(bits: torch.Tensor, row_nnz: torch.Tensor, head_off: torch.Tensor, H: int, T_m: int, T_src: int,
+                       k: int, is_causal: bool = True, z_cap: Optional[int] = None, keep: Optional[torch.Tensor] = None):
+    """Row scan + emit: the (bits, row_nnz, head_off) of a selection launch (sea_topk_select or the fused
+    sea_predictor_tail_select) -> FlatCSR.  Two launches, no host sync."""
+    lib = _lib.load()
+    N, T_dst = row_nnz.shape
+    dev = bits.device
+    st = _lib.stream_ptr()
     crow = torch.empty((N, T_dst + 1), dtype=torch.int32, device=dev)
     _lib.check(lib.sea_csr_row_scan(_p(row_nnz), N, T_dst, _p(crow), 4, st), "sea_csr_row_scan")
     if z_cap is None:
@@ -137,7 +148,7 @@ def topk_to_csr(probs: torch.Tensor, keep: torch.Tensor, k: int, target_width: O
     _lib.check(lib.sea_csr_emit(
         _p(bits), _p(crow), _p(head_off), N, H, T_dst, T_m, T_src, int(is_causal), int(k),
         _p(col), 4, col.stride(0), z_cap, None, st), "sea_csr_emit")
-    return FlatCSR(crow, col, head_off, H, T_src, bits=bits, row_nnz=row_nnz), mask
+    return FlatCSR(crow, col, head_off, H, T_src, bits=bits, row_nnz=row_nnz)
 
 
 def topk_mask(probs: torch.Tensor, keep: torch.Tensor, k: int, target_width=None, is_causal=True) -> torch.Tensor:

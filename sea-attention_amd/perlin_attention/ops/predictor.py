@@ -93,14 +93,66 @@ def predictor_tail(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.Tensor, 
     return probs, scores
 
 
-def cumavg(v: torch.Tensor) -> torch.Tensor:
-    """Causal cumulative average over the time axis of (N,H,T,D), fp32 accumulation, dtype preserved."""
+def predictor_tail_select_supported(y: torch.Tensor, H: int, T_m: int) -> bool:
+    """Shapes csrc/sea_topk.hip: predictor_tail_select_kernel takes (see sea_predictor_tail_select in sea_hip.h)."""
+    return (y.dtype in (torch.float16, torch.bfloat16) and T_m == 256 and H % 4 == 0 and H <= 64
+            and (y.dim() == 5 or y.stride(1) == 1))
+
+
+def predictor_tail_select(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor,
+                          up: int, T_m: int, keep: torch.Tensor, k: int, T_src: int, is_causal: bool = True,
+                          eps: float = 1e-5, want_scores: bool = False):
+    """predictor_tail + grouped top-k selection in one launch.  Returns (probs, scores, (bits, row_nnz, head_off));
+    feed the triple to flat_csr.csr_from_selection.  Bit-identical to predictor_tail followed by topk_to_csr."""
+    lib = _lib.load()
+    _lib.require_gpu(y, conv_w, conv_b, ln_w, ln_b, keep)
+    if y.dim() == 5:
+        N, T, C8, W4, _e = y.shape
+        assert _e == 8 and y.is_contiguous()
+        C = C8 * 8
+    else:
+        N, C, T, W4 = y.shape
+    H = conv_w.shape[0]
+    assert conv_w.shape == (H, C) and W4 * up == T_m and predictor_tail_select_supported(y, H, T_m)
+    assert keep.dtype == torch.int32 and keep.is_contiguous() and keep.shape in ((T,), (N, T))
+    dt = y.dtype
+    Hpad = (H + 7) // 8 * 8
+
+    def build():   # same cache entry layout as predictor_tail
+        cw = torch.zeros((C, Hpad), dtype=torch.float32, device=y.device)
+        cw[:, :H] = conv_w.to(dt).float().t()
+        cb = torch.zeros((Hpad,), dtype=torch.float32, device=y.device)
+        cb[:H] = conv_b.to(dt).float()
+        Cp, HP = (C + 31) // 32 * 32, (H + 15) // 16 * 16
+        w16 = torch.zeros((HP, Cp), dtype=dt, device=y.device)
+        w16[:H, :C] = conv_w.to(dt)
+        return cw, cb, ln_w.to(dt).contiguous(), ln_b.to(dt).contiguous(), w16, Cp
+    _cw, cb, g, b, w16, Cp = _cached("tail", (conv_w, conv_b, ln_w, ln_b), dt, build)
+    dev = y.device
+    probs = torch.empty((N, H, T, T_m), dtype=dt, device=dev)
+    scores = torch.empty_like(probs) if want_scores else None
+    W = (H * T_m + 31) // 32
+    bits = torch.empty((N, T, W), dtype=torch.int32, device=dev)
+    row_nnz = torch.empty((N, T), dtype=torch.int32, device=dev)
+    head_off = torch.empty((N, T, H + 1), dtype=torch.int32, device=dev)
+    _lib.check(lib.sea_predictor_tail_select(
+        _p(y), _lib.dtype_code(dt), N, C, H, T, W4, up, T_m, _lib.strides5_blocked(y), _p(cb), _p(w16), Cp, _p(g), _p(b),
+        float(eps), _p(probs), _p(scores), _p(keep), T if keep.ndim == 2 else 0, T_src, int(is_causal), int(k),
+        _p(bits), _p(row_nnz), _p(head_off), _lib.stream_ptr()), "sea_predictor_tail_select")
+    return probs, scores, (bits, row_nnz, head_off)
+
+
+def cumavg(v: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Causal cumulative average over the time axis of (N,H,T,D), fp32 accumulation, dtype preserved.
+    `out`: optional preallocated contiguous (N,H,T,D) result (lets a caller launch this on a side stream)."""
     lib = _lib.load()
     _lib.require_gpu(v)
     N, H, T, D = v.shape
     if v.stride(-1) != 1:
         v = v.contiguous()
-    out = torch.empty((N, H, T, D), dtype=v.dtype, device=v.device)
+    if out is None:
+        out = torch.empty((N, H, T, D), dtype=v.dtype, device=v.device)
+    assert out.shape == (N, H, T, D) and out.dtype == v.dtype and out.is_contiguous()
     _lib.check(lib.sea_cumavg(_p(v), _lib.dtype_code(v.dtype), N, H, T, D, _lib.strides3(v), _p(out),
                               _lib.stream_ptr()), "sea_cumavg")
     return out

@@ -312,3 +312,32 @@ def test_predictor_mlp(ops, dtype, N, H, T, d, T_M):
     torch.testing.assert_close(av.cpu(), gate[..., 1], atol=atol / 2, rtol=rtol)
     x2, tp2, _, _ = ops.predictor_mlp(x.to(DEV), enc_lin, enc_ln, dec_lin, ln1, sc, want_tpred=False)
     assert tp2 is None and torch.equal(x2, x_c8)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,T,k", [(2, 32, 300, 64), (1, 12, 257, 16), (1, 4, 64, 8), (1, 40, 100, 64), (1, 64, 40, 32)])
+def test_predictor_tail_select_bit_identical(ops, dtype, N, H, T, k):
+    """One-launch tail + top-k selection == predictor_tail followed by topk_to_csr, bit for bit (map, CSR, offsets)."""
+    T_M, C, W4 = 256, 2 * H, 64
+    g = torch.Generator().manual_seed(9)
+    y = ops.to_c8(torch.relu(torch.randn((N, C, T, W4), generator=g)).to(dtype).to(DEV))
+    cw = (torch.randn((H, C), generator=g) * C ** -0.5).to(dtype).to(DEV)
+    cb = (torch.randn(H, generator=g) * 0.1).to(dtype).to(DEV)
+    lw = (torch.rand(T_M, generator=g) + 0.5).to(dtype).to(DEV)
+    lb = (torch.randn(T_M, generator=g) * 0.1).to(dtype).to(DEV)
+    keep = ops.keep_table_causal(H, T, T_M, k, device=DEV)
+    p0, s0 = ops.predictor_tail(y, cw, cb, lw, lb, up=4, T_m=T_M, want_scores=True)
+    c0, _ = ops.topk_to_csr(p0, keep, k, target_width=T)
+    p1, s1, sel = ops.predictor_tail_select(y, cw, cb, lw, lb, up=4, T_m=T_M, keep=keep, k=k, T_src=T, want_scores=True)
+    c1 = ops.csr_from_selection(*sel, H, T_M, T, k, True, None, keep)
+    assert torch.equal(p0, p1) and torch.equal(s0, s1)
+    assert torch.equal(c0.bits, c1.bits) and torch.equal(c0.crow, c1.crow) and torch.equal(c0.head_off, c1.head_off)
+    for i in range(N):
+        Z = int(c0.crow[i, -1])
+        assert torch.equal(c0.col[i, :Z], c1.col[i, :Z])
+    # all-equal map (massive ties): the selection's slow path re-reads the map the same launch has just written
+    y0 = torch.zeros_like(y)
+    p2, _, sel2 = ops.predictor_tail_select(y0, cw * 0, cb * 0, lw, lb * 0, up=4, T_m=T_M, keep=keep, k=k, T_src=T)
+    c2 = ops.csr_from_selection(*sel2, H, T_M, T, k, True, None, keep)
+    c3, _ = ops.topk_to_csr(ops.predictor_tail(y0, cw * 0, cb * 0, lw, lb * 0, up=4, T_m=T_M)[0], keep, k, target_width=T)
+    assert torch.equal(c2.bits, c3.bits) and torch.equal(c2.crow, c3.crow)
