@@ -348,52 +348,42 @@ __device__ __forceinline__ void select_body(const TopkParams& p, uint32_t (&key)
   // ---- outputs ----------------------------------------------------------------------------------
   const int w_t = row_width(t, p.T_dst, p.T_src, p.is_causal);
   const float scale = interp_scale(w_t, p.T_m);
-  // pixel bounds of this row (shared by all heads) in the candidate array, which the selection no longer needs
-  int* s_bnd = reinterpret_cast<int*>(s_ckey);
-  const bool table = p.T_m < TK_CAND_CAP;
-  if (table) {
-    for (int m = tid; m <= p.T_m; m += TK_THREADS) s_bnd[m] = (int)interp_bound(m, scale);
-    __syncthreads();
-  }
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     const int c = j * TK_THREADS + tid;
     const bool valid = FULL || c < p.nchunks;
     const uint32_t nib = (uint32_t)(sel >> (4 * j)) & 0xFu;
-    // bit mask: 8 consecutive lanes own one 32-bit word (OR over the 8 lanes by DPP: xor 1, xor 2, half-row mirror)
+    // bit mask: 8 consecutive lanes own one 32-bit word
     uint32_t word = nib << (4 * (lane & 7));
-    word |= dpp_u32<0xB1>(word);
+    word |= dpp_u32<0xB1>(word);     // OR over the 8 lanes by DPP: xor 1, xor 2, half-row mirror
     word |= dpp_u32<0x4E>(word);
     word |= dpp_u32<0x141>(word);
     if ((lane & 7) == 0 && (c >> 3) < p.W) p.bits[(int64_t)row * p.W + (c >> 3)] = word;
-    int h = 0, b0 = 0;
-    if ((p.mask_out != nullptr && valid) || nib) {
-      const int f0 = c * 4;
-      h = f0 / p.T_m; b0 = f0 - h * p.T_m;
-    }
     if (p.mask_out != nullptr && valid) {
+      const int f0 = c * 4;
+      const int h = f0 / p.T_m, b0 = f0 - h * p.T_m;
       float4 m;
       m.x = (nib & 1u) ? 1.f : 0.f; m.y = (nib & 2u) ? 1.f : 0.f;
       m.z = (nib & 4u) ? 1.f : 0.f; m.w = (nib & 8u) ? 1.f : 0.f;
       *reinterpret_cast<float4*>(p.mask_out + (((int64_t)n * p.H + h) * p.T_dst + t) * p.T_m + b0) = m;
     }
-    // entries each kept pixel will emit: min(v_end - v_start, max_k); the 4 pixels of a chunk share a head
-    // (T_m % 4 == 0), so one LDS atomic per chunk that keeps anything
-#if SEA_EXP != 2
-    if (nib) {
-      int wsum = 0;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (nib & (1u << e)) {
-          const int b = b0 + e;
-          int w = table ? s_bnd[b + 1] - s_bnd[b] : (int)(interp_bound(b + 1, scale) - interp_bound(b, scale));
-          wsum += w < p.max_k ? w : p.max_k;
-        }
-      }
-      if (wsum > 0) atomicAdd(&s_head[h], wsum);
-    }
-#endif
   }
+  // entries each kept pixel will emit: min(v_end - v_start, max_k), accumulated per head.  Only kept pixels
+  // are visited (a row keeps ~K_t << H*T_m of them once t is large).
+#if SEA_EXP != 2
+  {
+    unsigned long long m = sel;
+    while (m) {
+      const int i = __ffsll((long long)m) - 1;
+      m &= m - 1;
+      const int f = ((i >> 2) * TK_THREADS + tid) * 4 + (i & 3);
+      const int h = f / p.T_m, b = f - h * p.T_m;
+      int w = (int)(interp_bound(b + 1, scale) - interp_bound(b, scale));
+      w = w < p.max_k ? w : p.max_k;
+      if (w > 0) atomicAdd(&s_head[h], w);
+    }
+  }
+#endif
   __syncthreads();
   STAMP(4);   // bit mask + widths + head counts
   // exclusive scan over heads (first wave, 64 heads per step)
