@@ -2,6 +2,7 @@
 // fused tail + top-k selection kernel (sea_topk.hip).  See sea_predictor.hip for what the tail computes.
 #pragma once
 #include "sea_common.hpp"
+#include <type_traits>
 
 namespace sea {
 
@@ -62,6 +63,45 @@ __device__ __forceinline__ void tail_z_tile(const TailParams& p, float* s_z, int
   const T* __restrict__ w16 = reinterpret_cast<const T*>(p.w16);
   const T* yb = reinterpret_cast<const T*>(p.y) + n * p.ys_n + t * p.ys_t;
   const int MT = (p.W4 + 15) / 16, NT = HP / 16, KC = p.Cp / 32;
+  // All fragments of a tile are requested before the first MFMA (ONE exposed memory round trip per tile, not one per
+  // MFMA: this phase is pure latency -- 8 KB of y and 4 KB of L2-resident weights per row).  Guards instead of
+  // compile-time trip counts for the common shapes so that the loops unroll; other shapes loop below.
+  auto tile_fixed = [&](auto ntc, auto kcc) {
+    constexpr int CNT = decltype(ntc)::value, CKC = decltype(kcc)::value;
+    for (int mt = wv; mt < MT; mt += 4) {
+      const int wpix = mt * 16 + li;
+      uint4 a[CKC], b[CNT][CKC];
+#pragma unroll
+      for (int kc = 0; kc < CKC; ++kc) {
+        const int ci = kc * 32 + 8 * lg;
+        a[kc] = make_uint4(0, 0, 0, 0);
+        if (ci < p.C && wpix < p.W4) a[kc] = *reinterpret_cast<const uint4*>(yb + (int64_t)wpix * p.ys_w + (ci >> 3) * p.ys_c8);
+      }
+#pragma unroll
+      for (int nt = 0; nt < CNT; ++nt)
+#pragma unroll
+        for (int kc = 0; kc < CKC; ++kc)
+          b[nt][kc] = *reinterpret_cast<const uint4*>(w16 + (nt * 16 + li) * p.Cp + kc * 32 + 8 * lg);
+#pragma unroll
+      for (int nt = 0; nt < CNT; ++nt) {
+        tf4 acc = tf4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kc = 0; kc < CKC; ++kc) acc = tail_mfma<T>(a[kc], b[nt][kc], acc);
+        const int h = nt * 16 + li;                // C layout: col = li -> head, row = lg*4 + r -> pixel
+        const float bias = h < p.H ? bF[h] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int px = mt * 16 + lg * 4 + r;
+          if (px < p.W4) s_z[h * LDZ + px] = acc[r] + bias;
+        }
+      }
+    }
+  };
+  if (NT == 2 && KC == 2) {                        // H in 17..32, C <= 64 (OPT-1.3B ... 6.7B)
+    tile_fixed(std::integral_constant<int, 2>{}, std::integral_constant<int, 2>{});
+  } else if (NT == 1 && KC == 1) {                 // H <= 16, C <= 32 (OPT-125m / 350m)
+    tile_fixed(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{});
+  } else {
   for (int mt = wv; mt < MT; mt += 4) {
     const int wpix = mt * 16 + li;
     for (int nt = 0; nt < NT; ++nt) {
@@ -81,6 +121,7 @@ __device__ __forceinline__ void tail_z_tile(const TailParams& p, float* s_z, int
         if (px < p.W4) s_z[h * LDZ + px] = acc[r] + bias;
       }
     }
+  }
   }
   for (int h = threadIdx.x; h < HP; h += 256) { s_z[h * LDZ + p.W4] = h < p.H ? bF[h] : 0.f; s_z[h * LDZ + p.W4 + 1] = 0.f; }
 }

@@ -455,10 +455,14 @@ __global__ __launch_bounds__(TK_THREADS) void predictor_tail_select_kernel(TailP
   const int row = blockIdx.x;
   const int n = row / tp.T, t = row - n * tp.T;
   const int LDZ = tp.W4 + 3;
+#ifdef SEA_STAMP
+  unsigned long long _tprev = __builtin_amdgcn_s_memtime();
+#endif
   tail_z_tile<T>(tp, s_z, n, t);
   TailRow<T, E> tr;
   tr.init(tp, lane);
   __syncthreads();
+  STAMP(8);   // z tile (MFMA) + per-lane constants
   uint32_t key[EPT];
 #pragma unroll
   for (int j = 0; j < R; ++j) {
@@ -468,6 +472,7 @@ __global__ __launch_bounds__(TK_THREADS) void predictor_tail_select_kernel(TailP
 #pragma unroll
     for (int e = 0; e < E; ++e) key[4 * j + e] = (FULL || h < tp.H) ? f2key(Elem<T>::to_f(from_f<T>(a[e]))) : 0u;
   }
+  STAMP(9);   // 8 heads per wave: resize + LayerNorm + softmax + store
   const T* base = reinterpret_cast<const T*>(p.src) + n * p.sn + t * p.st;   // = the map just written (slow path re-reads it)
   select_body<T, EPT, false, FULL>(p, key, 0ull, n, t, row, base);
 }

@@ -46,3 +46,46 @@ def all_gather_context(local: torch.Tensor, n_items: int, group=None) -> torch.T
     bufs: List[torch.Tensor] = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(bufs, padded, group=group)
     return torch.cat([b[:c] for b, c in zip(bufs, counts)], dim=0)
+
+
+class ContextGatherer:
+    """Pipelined all-gather of the per-rank context shards: the collective of step i runs on the process group's
+    own stream (RCCL over xGMI) while step i+1 computes.
+
+    `depth` (default 2) slots of (local shard buffer, gathered buffer).  Protocol per step:
+        slot = g.next_slot()            # the launch stream now waits for whatever last used this slot
+        ... producer writes g.local[slot]  (e.g. the attention kernel's `out=`) ...
+        full = g.launch(slot)           # asynchronous all-gather of g.local[slot] into g.out[slot]
+    and `g.finish()` before the results are read / the timed region ends.  With world size 1 it degenerates to
+    returning the local buffer.  Equal shards only (the ragged case uses `all_gather_context`)."""
+
+    def __init__(self, local_shape, n_items: int, dtype, device, group=None, depth: int = 2):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        assert n_items % self.world == 0 and local_shape[0] * self.world == n_items, "equal shards only"
+        self.depth = depth
+        self.local = [torch.empty(tuple(local_shape), dtype=dtype, device=device) for _ in range(depth)]
+        self.out = ([torch.empty((n_items,) + tuple(local_shape[1:]), dtype=dtype, device=device) for _ in range(depth)]
+                    if self.world > 1 else self.local)
+        self._work = [None] * depth
+        self._i = 0
+
+    def next_slot(self) -> int:
+        slot = self._i % self.depth
+        self._i += 1
+        w = self._work[slot]
+        if w is not None:                 # the collective that read local[slot] / wrote out[slot] `depth` steps ago
+            w.wait()                      # nccl: a stream-level dependency, the host does not block
+            self._work[slot] = None
+        return slot
+
+    def launch(self, slot: int) -> torch.Tensor:
+        if self.world > 1:
+            self._work[slot] = dist.all_gather_into_tensor(self.out[slot], self.local[slot], group=self.group, async_op=True)
+        return self.out[slot]
+
+    def finish(self) -> None:
+        for s, w in enumerate(self._work):
+            if w is not None:
+                w.wait()
+                self._work[s] = None
