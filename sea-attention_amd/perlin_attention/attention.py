@@ -434,7 +434,8 @@ class PerlinAttention(nn.Module):
         if not self.pconfig.causal:
             raise NotImplementedError("non-causal (BERT) SEA is outside this build's scope (SURVEY.md 2.1 #12)")
         if self.pconfig.use_cache or last_state is not None:
-            raise NotImplementedError("kv-cache decoding state (attention_state.py) is a next-tier item (SURVEY.md 8f-3)")
+            return self._forward_cached(q, k, v, q_for_atten, k_for_atten, v_for_atten, q_for_score, k_for_score,
+                                        attention_mask, last_state)
 
         if context_layer_truth is not None:
             if callable(context_layer_truth):
@@ -530,6 +531,114 @@ class PerlinAttention(nn.Module):
                 key_for_score=k_for_score,
                 state=None,
             )
+
+    # ------------------------------------------------------------------------------------------------
+    def _forward_cached(self, q, k, v, q_for_atten, k_for_atten, v_for_atten, q_for_score, k_for_score,
+                        attention_mask, last_state):
+        """KV-cache decoding (reference: the `use_cache` branches of attention.py:391-439,527-572,
+        630-646,1229-1235 + attention_state.py).  q / q_for_* bring the T_DST NEW rows, k / v the whole T_SRC prefix;
+        `attention_mask` is the (N,1,T_DST,T_SRC) tail of the causal mask.  Returns the rows a stateless forward over
+        T_SRC tokens would produce for the last T_DST positions, plus the new state.  The estimator (a handful of
+        rows per call) runs on the torch modules; steps H..L run on the HIP kernels with T_dst < T_src."""
+        from .attention_state import PerlinAttentionState, PerformerState, CnnWindowState, CumAvgState
+        if not self.pconfig.causal:
+            raise NotImplementedError("kv-cache decoding is defined for the causal configuration only")
+        if torch.is_grad_enabled() and any(t.requires_grad for t in (q, k, v)):
+            raise NotImplementedError("kv-cache decoding is an inference path (no autograd)")
+        N, H, T_DST, HID = q.shape
+        T_SRC = k.shape[-2]
+        assert attention_mask.shape == (N, 1, T_DST, T_SRC) and v.shape[-2] == T_SRC and T_DST <= T_SRC
+        state = last_state.clone() if last_state is not None else PerlinAttentionState(self)
+        seen = state.seq_len
+        assert seen + T_DST == T_SRC, f"state has seen {seen} tokens, call brings {T_DST} new of {T_SRC}"
+        bench = get_bench()
+        T_M = self.pconfig.attention_predictor_length
+        LB = CnnWindowState.LOOKBACK
+        if last_state is None and T_DST > 4 * LB and q.is_cuda and self.benchmarking:
+            # ---- prefill: the rows come from the stateless fast path (HIP estimator + kernels, one pass); the state a
+            # later call needs is rebuilt from sums over the prefix plus a cached-mode pass over the last LOOKBACK rows
+            self.pconfig.use_cache = False
+            try:
+                out = self.forward(q, k, v, q_for_atten, k_for_atten, v_for_atten, q_for_score, k_for_score,
+                                   attention_mask, None, None, None)
+            finally:
+                self.pconfig.use_cache = True
+            with torch.no_grad():
+                cut = T_SRC - LB
+                pos = self.v_eye_learned_causal[:, :, :cut, :]
+                ka, va = k_for_atten[..., :cut, :].float(), v_for_atten[..., :cut, :].float()
+                kp = self.performer.feature_map(ka).double()
+                ps = PerformerState()
+                ps.S = torch.matmul(kp.transpose(-1, -2), torch.cat([pos.expand(va.shape).float(), va], dim=-1).double())
+                ps.ksum = kp.sum(-2)
+                ps.seq_index = cut
+                cav = CumAvgState()
+                cav.cumsum, cav.prev_len = v[..., :cut, :].float().sum(-2, keepdim=True), cut
+                state.states[PerlinAttentionState.PERFORMER] = ps
+                state.states[PerlinAttentionState.CUMAVG] = cav
+                tail = self._forward_cached(q[..., cut:, :], k, v, q_for_atten[..., cut:, :], k_for_atten, v_for_atten,
+                                            q_for_score[..., cut:, :], k_for_score, attention_mask[:, :, cut:, :], state)
+            return PerlinAttentionOutput(*out[:-1], state=tail.state)
+        with timer("perlin"), torch.no_grad():
+            # ---- A-C: value augmentation + causal Performer on the new rows, running sums carried ------------------
+            with timer("performer"):
+                sl = slice(T_SRC - T_DST, T_SRC)
+                pos = self.v_eye_learned_causal[:, :, sl, :]
+                qa = q_for_atten.float()
+                ka, va = k_for_atten[..., sl, :].float(), v_for_atten[..., sl, :].float()
+                vaug = torch.cat([pos.expand(va.shape).float(), va], dim=-1)
+                ps = state.get(PerlinAttentionState.PERFORMER, PerformerState)
+                outs = []
+                for c0 in range(0, T_DST, 256):                      # bounded (chunk x chunk) score tiles (prefill)
+                    c1 = min(T_DST, c0 + 256)
+                    ps, o = ps.step(self.performer.feature_map(qa[..., c0:c1, :]),
+                                    self.performer.feature_map(ka[..., c0:c1, :]), vaug[..., c0:c1, :])
+                    outs.append(o)
+                state.states[PerlinAttentionState.PERFORMER] = ps
+                performer_context_layer = torch.cat(outs, dim=-2).to(q_for_atten.dtype)
+                v_new = v[..., sl, :]
+                performer_value = torch.cat([performer_context_layer, v_new], dim=-1)
+            # ---- D-G: predictor MLP, windowed CNN, softmax ---------------------------------------------------------
+            with timer("predictor"):
+                t_attention_predictor = self.attention_predictor_enc(performer_value)
+                x = self.attention_predictor_dec_row(t_attention_predictor)
+                cs = state.get(PerlinAttentionState.CNN, CnnWindowState)
+                cs, estimated_attention_score = cs.step(self.attention_predictor_cnn, x)
+                state.states[PerlinAttentionState.CNN] = cs
+                estimated_attention_probs = torch.softmax(estimated_attention_score.float(), dim=-1) \
+                    .to(estimated_attention_score.dtype).contiguous()
+            # ---- H-I: grouped top-k of the new rows (their absolute widths), interpolation to flat CSR -------------
+            with timer("interp"):
+                # K_t of the new rows only (absolute positions T_SRC-T_DST+1 .. T_SRC), same fp32 expression as
+                # ops.keep_table_causal (attention.py:849-866)
+                ctl = torch.arange(T_SRC - T_DST + 1, T_SRC + 1, dtype=torch.long)
+                per = H * (self.pconfig.k * self.pconfig.k_oversample * T_M / ctl)
+                keep_cpu = torch.clamp_max(torch.clamp_min(torch.round(per), 1), H * T_M).to(torch.int32)
+                z_cap = ops.z_capacity(keep_cpu, H, T_DST, T_SRC, T_M, int(self.pconfig.k), True)
+                csr, _ = ops.topk_to_csr(estimated_attention_probs, keep_cpu.to(q.device), int(self.pconfig.k),
+                                         target_width=T_SRC, is_causal=True, z_cap=z_cap)
+            # ---- J-L: gates, cumulative average (carried), fused sparse attention ----------------------------------
+            with timer("attention"):
+                sig = torch.sigmoid(self.attention_predictor_dec_scaler(t_attention_predictor).float())
+                row_scale = sig[..., 0].contiguous() if self.pconfig.partial_attention_scaler else None
+                average_scale = sig[..., 1].contiguous()
+                cav = state.get(PerlinAttentionState.CUMAVG, CumAvgState)
+                cav, average_context_layer = cav.step(v_new)
+                state.states[PerlinAttentionState.CUMAVG] = cav
+                qs = q_for_score if q_for_score.stride(-1) == 1 else q_for_score.contiguous()
+                ks = k_for_score if k_for_score.stride(-1) == 1 else k_for_score.contiguous()
+                vs = v if v.stride(-1) == 1 else v.contiguous()
+                ks, vs = ks.to(qs.dtype), vs.to(qs.dtype)
+                out_dtype = self.context_layer_dtype or torch.float32
+                ctx = torch.empty((N, T_DST, H * HID), dtype=out_dtype, device=q.device)
+                ops.sparse_attention(qs, ks, vs, csr, row_scale=row_scale, avg=average_context_layer.to(qs.dtype).contiguous(),
+                                     mix=average_scale, out=ctx.view(N, T_DST, H, HID).permute(0, 2, 1, 3))
+        bench.register_temp_buffer('estimated_attention_probs', estimated_attention_probs)
+        mask_out = csr.to_sparse_csr() if self.materialize_csr else csr
+        return PerlinAttentionOutput(
+            loss=0, context_layer=ctx, partial_attention_probs=mask_out, partial_attention_mask=mask_out,
+            estimated_attention_probs_m=estimated_attention_probs, estimated_attention_probs=estimated_attention_probs,
+            dense_attention_probs=None, key_for_score=k_for_score, state=state)
 
     # ------------------------------------------------------------------------------------------------
     def _forward_sparse(self, q, v, q_for_score, k_for_score, t_attention_predictor, probs, dst_attention_mask,

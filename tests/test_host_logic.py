@@ -250,3 +250,38 @@ def test_weight_prep_cache_is_keyed_on_tensor_identity():
         w.mul_(2)                              # in-place update bumps the version: rebuilt
     c = prep(w[:, :, 0, 0])
     assert len(builds) == n0 + 2 and torch.equal(c, w[:, :, 0, 0])
+
+
+def test_decoding_sub_states_match_one_shot_computation():
+    """attention_state.py on CPU: feeding the rows in chunks through the carried states equals the one-shot formulas
+    (causal linear attention, causal CNN, cumulative average)."""
+    from sea_attention_amd.perlin_attention.attention_state import PerformerState, CnnWindowState, CumAvgState
+    from sea_attention_amd.perlin_attention.performer import causal_linear_attention
+    from sea_attention_amd.perlin_attention.modules import CausalConv2d
+    g = torch.Generator().manual_seed(0)
+    N, H, T, nb, e = 2, 3, 37, 11, 6
+    qp, kp = torch.rand((N, H, T, nb), generator=g) + 1e-3, torch.rand((N, H, T, nb), generator=g) + 1e-3
+    v = torch.randn((N, H, T, e), generator=g)
+    ref = causal_linear_attention(qp.double(), kp.double(), v.double(), chunk=T).float()
+    st, outs, pos = PerformerState(), [], 0
+    for step in (5, 1, 1, 17, 13):
+        st, o = st.step(qp[..., pos:pos + step, :], kp[..., pos:pos + step, :], v[..., pos:pos + step, :])
+        outs.append(o); pos += step
+    assert st.seq_index == T
+    torch.testing.assert_close(torch.cat(outs, -2), ref, atol=1e-5, rtol=1e-5)
+    # cumulative average
+    cs, outs, pos = CumAvgState(), [], 0
+    for step in (9, 1, 27):
+        cs, o = cs.step(v[..., pos:pos + step, :]); outs.append(o); pos += step
+    torch.testing.assert_close(torch.cat(outs, -2), v.cumsum(-2) / torch.arange(1, T + 1).view(1, 1, -1, 1), atol=1e-5, rtol=1e-5)
+    # two dilated causal convs look back 8 rows: the windowed state equals the full pass
+    cnn = torch.nn.Sequential(CausalConv2d(4, 4, 3, padding=2, dilation=2, causal=True), torch.nn.ReLU(),
+                              CausalConv2d(4, 4, 3, padding=2, dilation=2, causal=True))
+    x = torch.randn((1, 4, 30, 8), generator=g)
+    with torch.no_grad():
+        full = cnn(x)
+        ws, outs, pos = CnnWindowState(), [], 0
+        for step in (12, 1, 1, 16):
+            ws, o = ws.step(cnn, x[..., pos:pos + step, :]); outs.append(o); pos += step
+    torch.testing.assert_close(torch.cat(outs, -2), full, atol=1e-5, rtol=1e-5)
+    assert ws.rows.shape[-2] == CnnWindowState.LOOKBACK

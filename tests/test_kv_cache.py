@@ -1,0 +1,101 @@
+"""-m gpu: kv-cache decoding.  Protocol of the reference's test_perlin_opt_cache.py: decoding with the
+carried state must reproduce the rows of the stateless forward over the whole sequence.  Here: prefill T0 tokens with
+`use_cache`, then feed the rest in chunks (1 token and several tokens per call), compare every produced row with the
+stateless sparse-mode forward (same layer, torch estimator on both sides so that only the state logic differs)."""
+import pytest
+import torch
+
+import sea_attention_amd as S
+from sea_attention_amd.perlin_attention import PerlinAttentionConfig, PerlinSelfAttention
+from sea_attention_amd.perlin_attention.attention_state import PerlinAttentionState, CnnWindowState
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class Cfg:
+    def __init__(self, hidden, heads, max_pos):
+        self.hidden_size, self.num_attention_heads, self.max_position_embeddings = hidden, heads, max_pos
+
+
+def _mask(N, T_dst, T_src, dtype):
+    fp_min = torch.finfo(torch.float32 if dtype == torch.float32 else torch.float16).min / 2
+    rows = torch.arange(T_src - T_dst, T_src, device=DEV).view(T_dst, 1)
+    m = ((torch.arange(T_src, device=DEV).view(1, T_src) > rows) * fp_min).view(1, 1, T_dst, T_src)
+    return m.expand(N, 1, T_dst, T_src).contiguous().to(dtype)
+
+
+def _layer(H, d, T_M, k, T, dtype, use_cache):
+    S.seed(42)
+    pc = PerlinAttentionConfig(k=k, attention_predictor_length=T_M, performer_nb_factor=8, causal=True, k_flatten=True,
+                               k_flatten_dim='causal_batch', context_output_method='mix', use_cache=use_cache)
+    layer = PerlinSelfAttention(Cfg(H * d, H, T), pc).to(DEV).to(dtype).eval()
+    for m in layer.modules():
+        if hasattr(m, 'benchmarking'):
+            m.benchmarking = True
+    layer.attention.force_torch_estimator = True
+    return layer
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
+@pytest.mark.parametrize("N,H,T,d,T_M,k,T0,chunks", [(2, 4, 96, 32, 32, 8, 64, (1, 1, 6, 8, 16)),
+                                                     (1, 8, 300, 64, 64, 16, 257, (1, 10, 32)),
+                                                     (1, 4, 40, 32, 32, 8, 1, (1, 2, 36))])
+def test_cached_decoding_matches_stateless(dtype, tol, N, H, T, d, T_M, k, T0, chunks):
+    assert T0 + sum(chunks) == T
+    full = _layer(H, d, T_M, k, T, dtype, use_cache=False)
+    cached = _layer(H, d, T_M, k, T, dtype, use_cache=True)
+    cached.load_state_dict(full.state_dict())
+    S.seed(7)
+    x = torch.randn((N, H, T, d), device=DEV).to(dtype)
+    q = (x.float() * d ** -0.5).to(dtype)
+    with torch.no_grad():
+        ref = full(None, None, None, query_layer=q, key_layer=x, value_layer=x, attention_mask=_mask(N, T, T, dtype)).context_layer.float()
+        state, got, pos = None, [], 0
+        for step in (T0,) + tuple(chunks):
+            hi = pos + step
+            out = cached(None, None, None, query_layer=q[:, :, pos:hi], key_layer=x[:, :, :hi], value_layer=x[:, :, :hi],
+                         attention_mask=_mask(N, step, hi, dtype), last_state=state)
+            assert isinstance(out.state, PerlinAttentionState) and out.state.seq_len == hi
+            assert out.context_layer.shape == (N, step, H * d)
+            state = out.state
+            got.append(out.context_layer.float())
+            pos = hi
+    got = torch.cat(got, dim=1)
+    # fp32: every row agrees.  bf16: the estimator's outputs are rounded to 8 significant bits, so the float64 state and
+    # the one-pass fp32 sums land on neighbouring bf16 values now and then, a near-tied top-k choice flips and that
+    # row attends to a slightly different key set -- judged by the relative error of the whole context instead
+    err = (got - ref).abs().amax(-1)                      # (N, T) worst element per row
+    scale = ref.abs().amax(-1).clamp_min(1.0)
+    bad = (err > tol * scale).float().mean().item()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    if dtype == torch.float32:
+        assert bad == 0.0 and rel < 1e-4, (bad, rel, err.max().item())
+    else:
+        assert rel < 0.2 and bad < 0.35, (bad, rel, err.max().item())
+
+
+def test_state_is_copy_on_write_and_cnn_window_is_enough():
+    N, H, T, d, T_M, k = 1, 4, 48, 32, 32, 8
+    cached = _layer(H, d, T_M, k, T, torch.float32, use_cache=True)
+    S.seed(3)
+    x = torch.randn((N, H, T, d), device=DEV)
+    q = x * d ** -0.5
+    with torch.no_grad():
+        o0 = cached(None, None, None, query_layer=q[:, :, :40], key_layer=x[:, :, :40], value_layer=x[:, :, :40],
+                    attention_mask=_mask(N, 40, 40, torch.float32))
+        s0 = o0.state
+        a = cached(None, None, None, query_layer=q[:, :, 40:44], key_layer=x[:, :, :44], value_layer=x[:, :, :44],
+                   attention_mask=_mask(N, 4, 44, torch.float32), last_state=s0)
+        b = cached(None, None, None, query_layer=q[:, :, 40:44], key_layer=x[:, :, :44], value_layer=x[:, :, :44],
+                   attention_mask=_mask(N, 4, 44, torch.float32), last_state=s0)       # branch again from s0
+    assert s0.seq_len == 40 and a.state.seq_len == 44 and b.state.seq_len == 44
+    assert torch.equal(a.context_layer, b.context_layer)
+    assert a.state.states[PerlinAttentionState.CNN].rows.shape[-2] == CnnWindowState.LOOKBACK
+
+
+def test_cached_call_checks_its_bookkeeping():
+    cached = _layer(4, 32, 32, 8, 64, torch.float32, use_cache=True)
+    x = torch.randn((1, 4, 20, 32), device=DEV)
+    with torch.no_grad(), pytest.raises(AssertionError):    # 4 new rows on top of an EMPTY state cannot cover 20 keys
+        cached(None, None, None, query_layer=x[:, :, -4:], key_layer=x, value_layer=x, attention_mask=_mask(1, 4, 20, torch.float32))
