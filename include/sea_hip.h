@@ -248,11 +248,13 @@ int sea_predictor_mlp(const void* x, int dtype, int64_t N, int64_t H, int64_t T,
  * Replaces performer_pytorch.FastAttention(causal, generalized) as called at attention.py:556-572 plus the
  * concatenations at :506-510 and :577-590.  q,k,v (N,H,T,D) of `dtype` (element strides [n,h,t]), pos (>=T, D)
  * with row stride pos_stride, proj (nb, D) FP32.  out (N,H,T,3D) contiguous of `dtype` = [ctx_pos | ctx_v | v].
- * Supported: D in {64,80,128}, nb <= 80 (48 for D=80 with 64-row chunks). */
+ * Supported: D in {64,80,128}, nb <= 80 (48 for D=80 with 64-row chunks).
+ * bf16 data with D = 64 runs on bf16 MFMA with split (hi+lo) operands; that kernel can also emit
+ * avg_out (N,H,T,D) = cumsum_t(v)/(t+1), the input of the mix step (attention.py:1220-1222) -- pass NULL otherwise. */
 int sea_performer_causal(const void* q, const void* k, const void* v, const void* pos, int dtype,
                          const float* proj, int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb,
                          const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
-                         int64_t pos_stride, void* out, sea_stream_t stream);
+                         int64_t pos_stride, void* out, void* avg_out, sea_stream_t stream);
 
 /* Algorithmic bytes of one sea_sparse_attention launch:
  * Z*(2*D*s + 4) + N*H*T_dst*(2*D*s + 4).  Host-side helper, no device work. */

@@ -44,7 +44,7 @@ _SIGNATURES = {
                            ctypes.c_float, ptr, ptr, ptr, ptr, ptr], c_int),
     "sea_split_layernorm_c8": ([ptr, c_int, i64, i64, i64, i64, i64, ptr, ptr, ctypes.c_float, ptr, ptr], c_int),
     "sea_causal_conv_c8": ([ptr, c_int, i64, i64, i64, i64, i64, ptr, i64, ptr, c_int, c_int, c_int, c_int, ptr, ptr], c_int),
-    "sea_performer_causal": ([ptr, ptr, ptr, ptr, c_int, ptr, i64, i64, i64, i64, i64, _i64p, _i64p, _i64p, i64, ptr, ptr], c_int),
+    "sea_performer_causal": ([ptr, ptr, ptr, ptr, c_int, ptr, i64, i64, i64, i64, i64, _i64p, _i64p, _i64p, i64, ptr, ptr, ptr], c_int),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

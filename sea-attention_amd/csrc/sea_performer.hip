@@ -40,6 +40,7 @@ struct PerfParams {
   const void* pos;         // (>=T, D) learned causal value embedding
   const float* W;          // (nb, D) fp32
   void* out;               // (N,H,T,3D)
+  void* avg;               // optional (N,H,T,D): cumulative average of v (bf16 kernel only)
   int64_t qs[3], ks[3], vs[3];
   int64_t pos_stride;
   int N, H, T, nb;
@@ -357,10 +358,13 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   unsigned short* sAl = sAh + C * LDA;
   constexpr int LDO = E + 8;
   unsigned short* sO = sAl + C * LDA;                               // [C][LDO]  the chunk's result rows, flushed one chunk later
-  float* sKsum = reinterpret_cast<float*>(sO + C * LDO);            // [FP]
+  constexpr int LDG = D + 8;
+  unsigned short* sAvg = sO + C * LDO;                              // [C][LDG]  cumulative-average rows (optional output)
+  float* sKsum = reinterpret_cast<float*>(sAvg + C * LDG);          // [FP]
   float* sDen = sKsum + FP;                                         // [C]
   float* sDenP = sDen + C;                                          // [C][DSL]
   float* sKsP = sDenP + C * DSL;                                    // [NW][FP]   per-wave k-sum increments
+  float* sRinv = sKsP + NW * FP;                                    // [C]        1 / (absolute row index + 1)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -401,6 +405,9 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   const __amdgpu_buffer_rsrc_t rq = mk(qb, p.qs[2]), rk = mk(kb, p.ks[2]), rv = mk(vb, p.vs[2]), rp = mk(pb, p.pos_stride);
   const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((int64_t)p.T * 3 * D * 2), 0x00020000);
   typedef __attribute__((ext_vector_type(4))) unsigned int bu4;
+  const bool want_avg = p.avg != nullptr;                  // block-uniform
+  T* gb = reinterpret_cast<T*>(p.avg) + (want_avg ? (int64_t)nh * p.T * D : 0);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(gb, 0, want_avg ? (int)((int64_t)p.T * D * 2) : 0, 0x00020000);
   bu4 pq, pk, pv, pp;
   auto issue_loads = [&](int t0n) {
     const int t = t0n + sr;
@@ -423,9 +430,32 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
       const bu4 v = *reinterpret_cast<const bu4*>(sO + row * LDO + ch * 8);
       __builtin_amdgcn_raw_buffer_store_b128(v, ro, row < rowsp ? ((t0p + row) * (3 * D) + ch * 8) * 2 : (int)OOB, 0, 0);
     }
+    if (want_avg) {                                        // C * D / 8 = 512 pieces: one per thread
+      const int row = tid / (D / 8), ch = tid - row * (D / 8);
+      const bu4 v = *reinterpret_cast<const bu4*>(sAvg + row * LDG + ch * 8);
+      __builtin_amdgcn_raw_buffer_store_b128(v, rg, row < rowsp ? ((t0p + row) * D + ch * 8) * 2 : (int)OOB, 0, 0);
+    }
   };
   // swizzled chunk position inside a 256-byte row of the V image (conflict-free transposing reads)
   auto vchunk = [](int row, int ch) { return ch ^ (((row & 3) << 2) | ((row >> 2) & 3)); };
+
+  // cumulative average of v (step K's input) on the waves that own the v columns: prefix sum over the chunk rows =
+  // tril(ones) . V on the matrix cores (1.0 and v are exact in bf16, fp32 accumulation) + the running column sum
+  float csum = 0.f;
+  auto tril_frag = [&](int ib, int ks) {
+    unsigned short o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (ks * 32 + lg * 8 + j <= ib * 16 + li) ? (unsigned short)0x3F80 : (unsigned short)0;
+    const unsigned short (&o0)[4] = *reinterpret_cast<const unsigned short (*)[4]>(&o[0]);
+    const unsigned short (&o1)[4] = *reinterpret_cast<const unsigned short (*)[4]>(&o[4]);
+    return cat8(pack4(o0), pack4(o1));
+  };
+
+  uint4 tril[RB][C / 32];                                  // loop-invariant A operands of the prefix-sum product
+#pragma unroll
+  for (int ib = 0; ib < RB; ++ib)
+#pragma unroll
+    for (int ks = 0; ks < C / 32; ++ks) tril[ib][ks] = tril_frag(ib, ks);
 
   for (int t0 = 0; t0 < p.T; t0 += C) {
     const int rows = min(C, p.T - t0);
@@ -557,6 +587,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 #pragma unroll
       for (int i = 0; i < DSL; ++i) s += sDenP[tid * DSL + i];
       sDen[tid] = 1.0f / s;                                  // the 16 column waves multiply by the reciprocal
+      sRinv[tid] = 1.0f / (float)(t0 + tid + 1);
     } else if (tid >= C && tid < C + FP) {
       const int f = tid - C;
       float s = sKsum[f];
@@ -625,6 +656,24 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
           sO[row * LDO + col] = bf_bits(o[ib][r] * sDen[row]);
         }
       }
+      if (want_avg && jb >= EB / 2) {                      // wave-uniform: this wave's 16 columns are v features
+        f4 cum[RB];
+#pragma unroll
+        for (int ib = 0; ib < RB; ++ib) {
+          cum[ib] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks <= ib / 2; ++ks) cum[ib] = SEA_MFMA_BF(tril[ib][ks], vf[ks], cum[ib]);
+        }
+        const int gcol = col - D;
+#pragma unroll
+        for (int ib = 0; ib < RB; ++ib)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = ib * 16 + lg * 4 + r;
+            sAvg[row * LDG + gcol] = bf_bits((cum[ib][r] + csum) * sRinv[row]);
+          }
+        csum += __shfl(cum[RB - 1][3], 48 + li);           // column total of the chunk = its last row's prefix
+      }
       // (e) S[f][e] += sum_s phi(k_s)[f] V[s][e]: A operand = phi(K)^T by transposing reads of the row-major images
       {
         const int q = li >> 2, pp_ = li & 3;
@@ -673,8 +722,8 @@ static int launch_perf(const PerfParams& p, hipStream_t s) {
 template <int NBT>
 static int launch_perf_bf16(const PerfParams& p, hipStream_t s) {
   constexpr int D = 64, C = 64, NTH = 512, E = 2 * D, NBP = NBT * 16, FP = ((NBT + 1) / 2) * 32, LDP = FP + 8, LDA = C + 8;
-  constexpr size_t lds = 2 * ((D / 8) * NBP * 8 + 2 * (D / 8) * C * 8 + C * E + 4 * C * LDP + 2 * C * LDA + C * (E + 8)) +
-                         sizeof(float) * (FP + C + C * (C / 16 + NTH / C) + 8 * FP);
+  constexpr size_t lds = 2 * ((D / 8) * NBP * 8 + 2 * (D / 8) * C * 8 + C * E + 4 * C * LDP + 2 * C * LDA + C * (E + 8) + C * (D + 8)) +
+                         sizeof(float) * (FP + C + C * (C / 16 + NTH / C) + 8 * FP + C);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool configured = false;
   if (!configured) {
@@ -719,7 +768,7 @@ extern "C" int sea_debug_perf_stamps(unsigned long long* host8) {
 extern "C" int sea_performer_causal(const void* q, const void* k, const void* v, const void* pos, int dtype,
                                     const float* proj, int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb,
                                     const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
-                                    int64_t pos_stride, void* out, sea_stream_t stream) {
+                                    int64_t pos_stride, void* out, void* avg_out, sea_stream_t stream) {
   const char* nm = "sea_performer_causal";
   SEA_REQUIRE(q && k && v && pos && proj && out && q_strides && k_strides && v_strides, SEA_EINVAL, "%s: null pointer", nm);
   SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_F16 || dtype == SEA_BF16, SEA_EINVAL, "%s: bad dtype %d", nm, dtype);
@@ -730,7 +779,9 @@ extern "C" int sea_performer_causal(const void* q, const void* k, const void* v,
                   ok3(k_strides) && ok3(v_strides) && pos_stride % vec == 0,
               SEA_EUNSUPPORTED, "%s: rows must be 16-byte aligned", nm);
   PerfParams p;
-  p.q = q; p.k = k; p.v = v; p.pos = pos; p.W = proj; p.out = out;
+  p.q = q; p.k = k; p.v = v; p.pos = pos; p.W = proj; p.out = out; p.avg = avg_out;
+  SEA_REQUIRE(avg_out == nullptr || (dtype == SEA_BF16 && D == 64 && nb <= 80 && !perf_force_fp32() && ((uintptr_t)avg_out & 15) == 0),
+              SEA_EUNSUPPORTED, "%s: avg_out needs the bf16 kernel (bf16 data, D = 64)", nm);
   for (int i = 0; i < 3; ++i) { p.qs[i] = q_strides[i]; p.ks[i] = k_strides[i]; p.vs[i] = v_strides[i]; }
   p.pos_stride = pos_stride;
   p.N = (int)N; p.H = (int)H; p.T = (int)T; p.nb = (int)nb;

@@ -123,6 +123,7 @@ class PerlinAttention(nn.Module):
         self.force_torch_estimator = False
         self._fused_gates = None            # (row_scale, average_scale) when the fused predictor MLP produced them
         self._fused_selection = None        # (bits, row_nnz, head_off) when the tail kernel also ran the top-k selection
+        self._avg_ahead = None              # cumulative average of v when the Performer launch produced it
 
         d, H = self.attention_head_size, self.num_attention_heads
         pc = self.pconfig
@@ -265,6 +266,7 @@ class PerlinAttention(nn.Module):
     def _estimate(self, q, k, v, q_for_atten, k_for_atten, v_for_atten, dst_attention_mask, not_padded, T_SRC):
         """Steps A..G: value augmentation, Performer, predictor MLP + CNN, softmax over T_M."""
         bench = get_bench()
+        self._avg_ahead = None
         hip_perf = (self._hip_estimator_ok(q) and not_padded and q_for_atten.shape == v_for_atten.shape
                     and ops.performer_supported(q.shape[-1], self.performer_nb_features)
                     and T_SRC == q.shape[-2] and q_for_atten.dtype == k_for_atten.dtype == v_for_atten.dtype)
@@ -272,8 +274,13 @@ class PerlinAttention(nn.Module):
             # value augmentation + Performer + concat with v: one fp32-MFMA kernel (csrc/sea_performer.hip)
             with timer("performer"):
                 pos = self.v_eye_learned_causal[0, 0, :T_SRC, :]
+                # sparse mode: the same launch also emits the cumulative average of v that step K mixes in
+                # (only when the estimator's value tensor IS the layer's value tensor, i.e. no separate LoRA branch)
+                avg_too = (self.benchmarking and v_for_atten is v and ops.performer_avg_supported(q_for_atten, self.performer_nb_features))
                 performer_value = ops.performer_value(q_for_atten, k_for_atten, v_for_atten, pos,
-                                                      self.performer.projection_matrix)
+                                                      self.performer.projection_matrix, want_avg=avg_too)
+                if avg_too:
+                    performer_value, self._avg_ahead = performer_value
                 D_ = q.shape[-1]
                 bench.register_temp_buffer('v_for_atten', None, lazy=lambda: torch.cat(
                     [pos.expand(v_for_atten.shape).to(v_for_atten.dtype), v_for_atten], dim=-1))
@@ -686,8 +693,11 @@ class PerlinAttention(nn.Module):
                     row_scale = sig[..., 0].contiguous() if self.pconfig.partial_attention_scaler else None
                     average_scale = sig[..., 1].contiguous()
             with timer("attention.avg_pool"):
-                avg_v = v if not_padded else v * (dst_attention_mask > -1)
-                average_context_layer = ops.cumavg(avg_v)              # HIP scan, fp32 accumulation
+                if self._avg_ahead is not None and not_padded:         # came out of the Performer launch
+                    average_context_layer, self._avg_ahead = self._avg_ahead, None
+                else:
+                    avg_v = v if not_padded else v * (dst_attention_mask > -1)
+                    average_context_layer = ops.cumavg(avg_v)          # HIP scan, fp32 accumulation
             out_dtype = self.context_layer_dtype or torch.float32
             qs = q_for_score if q_for_score.stride(-1) == 1 else q_for_score.contiguous()
             ks = k_for_score if k_for_score.stride(-1) == 1 else k_for_score.contiguous()

@@ -164,11 +164,17 @@ def performer_supported(D: int, nb: int) -> bool:
     return D in (64, 80, 128) and nbt <= 5
 
 
+def performer_avg_supported(q: torch.Tensor, nb: int) -> bool:
+    """The bf16 Performer kernel (bf16 data, d = 64) can emit the cumulative average of v in the same launch."""
+    return q.dtype == torch.bfloat16 and q.shape[-1] == 64 and (nb + 15) // 16 <= 5
+
+
 def performer_value(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torch.Tensor,
-                    projection: torch.Tensor) -> torch.Tensor:
+                    projection: torch.Tensor, want_avg: bool = False):
     """Causal Performer estimator + both concatenations in one launch.
     q,k,v (N,H,T,D); pos (>=T, D) = v_eye_learned_causal[0,0]; projection (nb, D).
-    Returns performer_value (N,H,T,3D) = [ctx(pos) | ctx(v) | v] in q's dtype."""
+    Returns performer_value (N,H,T,3D) = [ctx(pos) | ctx(v) | v] in q's dtype; with want_avg (see
+    performer_avg_supported) also the cumulative average of v, (N,H,T,D) -- the `cumavg` of step K."""
     lib = _lib.load()
     _lib.require_gpu(q, k, v, pos, projection)
     N, H, T, D = q.shape
@@ -182,10 +188,14 @@ def performer_value(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torc
     # the reference casts the projection buffer to the data dtype before using it
     proj = _cached("proj", (projection,), q.dtype, lambda: projection.to(q.dtype).float().contiguous())
     out = torch.empty((N, H, T, 3 * D), dtype=q.dtype, device=q.device)
+    avg = None
+    if want_avg:
+        assert performer_avg_supported(q, nb)
+        avg = torch.empty((N, H, T, D), dtype=q.dtype, device=q.device)
     _lib.check(lib.sea_performer_causal(_p(q), _p(k), _p(v), _p(pos), _lib.dtype_code(q.dtype), _p(proj), N, H, T, D, nb,
                                         _lib.strides3(q), _lib.strides3(k), _lib.strides3(v), pos.stride(0), _p(out),
-                                        _lib.stream_ptr()), "sea_performer_causal")
-    return out
+                                        _p(avg), _lib.stream_ptr()), "sea_performer_causal")
+    return (out, avg) if want_avg else out
 
 
 def predictor_mlp_supported(D1: int, D2: int, H: int, Din: int) -> bool:

@@ -341,3 +341,24 @@ def test_predictor_tail_select_bit_identical(ops, dtype, N, H, T, k):
     c2 = ops.csr_from_selection(*sel2, H, T_M, T, k, True, None, keep)
     c3, _ = ops.topk_to_csr(ops.predictor_tail(y0, cw * 0, cb * 0, lw, lb * 0, up=4, T_m=T_M)[0], keep, k, target_width=T)
     assert torch.equal(c2.bits, c3.bits) and torch.equal(c2.crow, c3.crow)
+
+
+@pytest.mark.parametrize("N,H,T", [(1, 2, 256), (2, 3, 200), (1, 4, 1000)])
+def test_performer_emits_cumulative_average(ops, N, H, T):
+    """The bf16 Performer launch can also write cumsum(v)/(t+1) (step K's input): equals the cumavg kernel's values
+    (fp32 accumulation on both sides, at most a bf16 rounding step apart) and leaves the main output untouched."""
+    import math
+    from sea_attention_amd.perlin_attention.performer import FastAttention
+    torch.manual_seed(11)
+    D = 64
+    fa = FastAttention(D, nb_features=int(D * math.log(D) / 8), causal=True, generalized_attention=True).to(DEV)
+    q = (torch.randn(N, H, T, D, device=DEV) * D ** -0.5).bfloat16(); k = torch.randn(N, H, T, D, device=DEV).bfloat16()
+    v = torch.randn(N, H, T, D, device=DEV).bfloat16(); pos = torch.randn(T, D, device=DEV).bfloat16()
+    out0 = ops.performer_value(q, k, v, pos, fa.projection_matrix)
+    out1, avg = ops.performer_value(q, k, v, pos, fa.projection_matrix, want_avg=True)
+    assert torch.equal(out0, out1)
+    ref = v.float().cumsum(-2) / torch.arange(1, T + 1, device=DEV).view(1, 1, -1, 1)
+    torch.testing.assert_close(avg.float(), ref, atol=1e-2, rtol=1e-2)
+    ca = ops.cumavg(v).float()
+    assert ((avg.float() - ca).abs() <= ca.abs() * 2.0 ** -7 + 1e-6).all()
+    assert (avg.float() != ca).float().mean().item() < 0.01
