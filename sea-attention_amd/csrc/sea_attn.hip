@@ -509,7 +509,13 @@ static int launch_attn(AttnParams p, hipStream_t s) {
     dim3 grid((unsigned)blocks), block(256);
     switch (lpr) {
       case 4: hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 4, 4>), grid, block, 0, s, p); break;
-      case 8: hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 8, 4>), grid, block, 0, s, p); break;
+      case 8: {
+        static const int u_env = [] { const char* e = getenv("SEA_ATTN_U"); return e ? atoi(e) : 4; }();   // A/B hook
+        if (u_env == 2) hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 8, 2>), grid, block, 0, s, p);
+        else if (u_env == 8) hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 8, 8>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 8, 4>), grid, block, 0, s, p);
+        break;
+      }
       default: hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 16, 4>), grid, block, 0, s, p); break;
     }
     return SEA_OK;
