@@ -62,7 +62,8 @@ struct ConvParams {
 constexpr int CONV_WAVES = 6;
 constexpr unsigned CONV_OOB = 0x7FFFFF00u;       // > any valid byte offset (launcher checks the image is < 1 GiB)
 
-template <typename T, int NT, int KS>
+// ONESEG: W <= 64, every row is one segment: the tap-validity tests and lane offsets are then kernel invariants.
+template <typename T, int NT, int KS, bool ONESEG>
 __global__ __launch_bounds__(CONV_WAVES * 64, (NT <= 4 ? 3 : 2)) void causal_conv_c8_kernel(ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int NTH = CONV_WAVES * 64;
@@ -142,7 +143,7 @@ __global__ __launch_bounds__(CONV_WAVES * 64, (NT <= 4 ? 3 : 2)) void causal_con
     // dead cursor / K-padding blocks: an all-ones-ish mask OR-ed into the offset keeps it beyond num_records
     // (pure arithmetic on purpose: a boolean here gets jump-threaded into divergent load paths)
     const unsigned dead = (c.live && (c.cci * 4 + lg < C8i)) ? 0u : CONV_OOB;
-    const int px = c.w0 + li;                                // this lane's pixel of N-tile 0
+    const int px = (ONESEG ? 0 : c.w0) + li;                 // this lane's pixel of N-tile 0
     const unsigned lbase = (unsigned)((lg * p.W + px) * 16) | dead;
     const int dw = p.dil * tj - p.pad_w;                     // column shift of this tap (pixels outside the row: zeros;
 #pragma unroll                                               //  pixels >= W of a ragged last segment are never stored)
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(CONV_WAVES * 64, (NT <= 4 ? 3 : 2)) void causal_con
     const int cbase = lg * 4 * NT;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-      const int wpix = c.w0 + mt * 16 + li;
+      const int wpix = (ONESEG ? 0 : c.w0) + mt * 16 + li;
       unsigned pk[2 * NT];
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
@@ -323,10 +324,12 @@ static int launch_conv(const ConvParams& p, hipStream_t s) {
   do {                                                                                                              \
     static bool configured = false;                                                                                 \
     if (lds > 64 * 1024 && !configured) {                                                                           \
-      (void)hipFuncSetAttribute((const void*)causal_conv_c8_kernel<T, NTV, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      (void)hipFuncSetAttribute((const void*)causal_conv_c8_kernel<T, NTV, KSV, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+      (void)hipFuncSetAttribute((const void*)causal_conv_c8_kernel<T, NTV, KSV, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       configured = true;                                                                                            \
     }                                                                                                               \
-    hipLaunchKernelGGL((causal_conv_c8_kernel<T, NTV, KSV>), grid, block, lds, s, p);                               \
+    if (p.W <= 64) hipLaunchKernelGGL((causal_conv_c8_kernel<T, NTV, KSV, true>), grid, block, lds, s, p);          \
+    else hipLaunchKernelGGL((causal_conv_c8_kernel<T, NTV, KSV, false>), grid, block, lds, s, p);                   \
   } while (0)
 #define SEA_CONV_NT(KSV)                                                                                            \
   switch (nt) {                                                                                                     \
