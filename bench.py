@@ -170,10 +170,13 @@ def main():
             rec["a"], rec["kw"] = a, kw
             return kw.get("out")
         try:
-            torch.cuda.synchronize()
+            if gather is not None:
+                gather.finish()                             # no collective in flight while the capture runs
+            sync_all()
             _A.ops.sparse_attention = recorder
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
+            # with a process group alive its watchdog thread polls events: keep the capture's error mode thread-local
+            with torch.cuda.graph(graph, **({"capture_error_mode": "thread_local"} if world > 1 else {})):
                 with torch.no_grad():
                     g_out = layer(None, None, None, query_layer=q, key_layer=kk, value_layer=v, attention_mask=mask)
         except Exception as e:                                  # capture unsupported on this stack: stay eager
