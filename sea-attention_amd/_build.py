@@ -32,11 +32,11 @@ def build_library(force=False, extra_flags=(), out=None, verbose=False):
         return out
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
            "-Wall", "-Wno-unused-function", *extra_flags,
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", out + ".tmp"]
+           *[os.path.join(CSRC, s) for s in SOURCES], "-o", out + f".tmp.{os.getpid()}"]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)
-    os.replace(out + ".tmp", out)
+    os.replace(out + f".tmp.{os.getpid()}", out)     # atomic: concurrent ranks building at once cannot tear the file
     return out
 
 
