@@ -1,59 +1,75 @@
-"""PerlinAttentionConfig + process-global default registry.
-Field-for-field the reference's dataclass (src/models/perlin_attention/config.py:12-61); the
-trainer builds it from CLI flags (src/trainer/perlin_trainer.py:137-155) and modules read the
-registered default at construction (attention.py:142)."""
+"""`PerlinAttentionConfig` and the process-wide default it is constructed from.
+
+The field set (names, types, defaults) is the drop-in contract with the reference's trainer and model code
+(src/models/perlin_attention/config.py:12-61): `src/trainer/perlin_trainer.py:137-155` fills it from CLI flags and
+registers it as the default, the attention modules pick the registered default up at construction
+(attention.py:142).  Each field below notes which step of this build consumes it.
+"""
+import dataclasses
 import json
-from dataclasses import asdict, dataclass
 
 
-@dataclass
+@dataclasses.dataclass
 class PerlinAttentionConfig:
-    reformer_n_hashs: int = 8
-    performer_nb_factor: int = 1
-    k: int = 7
-    k_flatten: bool = True
-    k_flatten_dim: str = 'causal_batch'
-    random_lookup: bool = False
+    # ---- baselines of the reference that share the config object (not used by the SEA hot path) -------------------
+    reformer_n_hashs: int = 8                      # reformer baseline only
+    # ---- step B: Performer estimator ---------------------------------------------------------------------------
+    performer_nb_factor: int = 1                   # nb_features = d * ln(d) / factor
+    # ---- step H: grouped top-k -----------------------------------------------------------------------------------
+    k: int = 7                                     # keys kept per (query, head) on average
+    k_flatten: bool = True                         # pool the heads of a row before selecting
+    k_flatten_dim: str = 'causal_batch'            # the only pooling the causal model uses
+    random_lookup: bool = False                    # (reference ablation; off)
     random_lookup_count: int = 3
-    attention_predictor_method: str = 'mlp'
-    attention_predictor_length: int = 128
+    # ---- steps D-G: attention predictor ------------------------------------------------------------------------------
+    attention_predictor_method: str = 'mlp'        # 'mlp' (this build) | 'comp' (not built)
+    attention_predictor_length: int = 128          # T_M, width of the compressed attention map
     attention_predictor_backend: str = 'performer'
-    attention_predictor_comp_book_size: int = 8
+    attention_predictor_comp_book_size: int = 8    # 'comp' predictor only
     attention_predictor_comp_patch_size: int = 16
     attention_predictor_comp_patch_count: int = 16
     attention_predictor_enc_per_layer: bool = False
-    layerwise: bool = False
+    # ---- training-time plumbing ----------------------------------------------------------------------------------
+    layerwise: bool = False                        # detach the layer input while distilling layer by layer
     lora_r: int = 32
     lora_enabled: bool = False
     lora_in_approx_enabled: bool = False
-    partial_attention_scaler: bool = True
+    # ---- steps J-L: sparse attention and output ----------------------------------------------------------------------
+    partial_attention_scaler: bool = True          # multiply the sparse probabilities by sigmoid(scale_0)
     out_add_performer_context: bool = False
     v_eye_length: int = 128
     out_norm: bool = False
-    causal: bool = False
-    use_cache: bool = False
+    causal: bool = False                           # perlin_opt forces True
+    use_cache: bool = False                        # kv-cache decoding (attention_state.py)
     compile: bool = False
-    context_output_method: str = 'mix'
-    k_oversample: float = 1.0
+    context_output_method: str = 'mix'             # lerp with the cumulative-average value by sigmoid(scale_1)
+    k_oversample: float = 1.0                      # multiplies k in the per-row keep count
 
-    def to_json(self):
-        return asdict(self)
+    def to_json(self) -> dict:
+        return {f.name: getattr(self, f.name) for f in dataclasses.fields(self)}
 
-    def check_validity(self):
-        if self.causal and self.k_flatten:
-            assert self.k_flatten_dim in ['causal_batch']
+    def check_validity(self) -> None:
+        causal_pooling = self.causal and self.k_flatten
+        assert (not causal_pooling) or self.k_flatten_dim in ('causal_batch',), self.k_flatten_dim
 
     def __repr__(self) -> str:
-        return f"PerlinAttentionConfig({json.dumps(self.to_json())})"
+        return "PerlinAttentionConfig(" + json.dumps(self.to_json()) + ")"
 
 
-DEFAULT_CONFIG = PerlinAttentionConfig()
+class _Registry:
+    """Holder of the process-wide default (the reference keeps a module global, config.py:53-61)."""
+    current = PerlinAttentionConfig()
 
 
-def register_default_config(config: PerlinAttentionConfig):
-    global DEFAULT_CONFIG
-    DEFAULT_CONFIG = config
+def register_default_config(config: PerlinAttentionConfig) -> None:
+    _Registry.current = config
 
 
 def get_default_config() -> PerlinAttentionConfig:
-    return DEFAULT_CONFIG
+    return _Registry.current
+
+
+def __getattr__(name):                             # `config.DEFAULT_CONFIG` stays readable for code that peeks at it
+    if name == "DEFAULT_CONFIG":
+        return _Registry.current
+    raise AttributeError(name)
