@@ -89,3 +89,52 @@ class ContextGatherer:
             if w is not None:
                 w.wait()
                 self._work[s] = None
+
+
+# ---- N < G: split the QUERY ROWS of steps G..L (secondary partitioning) -----------------------------------
+def row_shard_bounds(T_dst: int, world_size: int, rank: int, k: int = 64, T_src: int = None) -> Tuple[int, int]:
+    """Contiguous block of query rows for `rank`, balanced by the entries a causal row keeps: a row of width w
+    (= absolute position + 1) emits about min(w, k) keys per head, so the early rows are cheaper and the first
+    ranks get more of them.  Every step from the top-k on depends only on the row's own probabilities plus K/V
+    up to that row, so the blocks are independent; K/V are replicated (2*H*T*d elements, small next to the work)."""
+    T_src = T_dst if T_src is None else T_src
+    w = torch.arange(T_src - T_dst + 1, T_src + 1, dtype=torch.float64)
+    cost = torch.clamp_max(w, float(k)).cumsum(0)
+    total = float(cost[-1])
+    cuts = [0]
+    for r in range(1, world_size):
+        cuts.append(int(torch.searchsorted(cost, torch.tensor(total * r / world_size, dtype=torch.float64)).item()))
+    cuts.append(T_dst)
+    for i in range(1, len(cuts)):                      # monotone, never empty while rows remain
+        cuts[i] = max(cuts[i], cuts[i - 1])
+    return cuts[rank], cuts[rank + 1]
+
+
+def sparse_rows(ops, probs: torch.Tensor, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, lo: int, hi: int, top_k: int,
+                row_scale: torch.Tensor = None, avg: torch.Tensor = None, mix: torch.Tensor = None, out_dtype=None):
+    """Steps H..L for query rows [lo, hi) of a causal layer on the HIP kernels: the block is the LAST hi-lo rows of
+    the hi-long prefix, which is exactly the kernels' `T_dst < T_src` contract (row width = T_src - T_dst + t + 1).
+    probs (N,H,T,T_m) [or already sliced to the block], q (N,H,T,d), k/v (N,H,T,d).  Returns (N, hi-lo, H*d)."""
+    N, H, T, d = q.shape
+    T_m = probs.shape[-1]
+    pr = probs if probs.shape[-2] == hi - lo else probs[:, :, lo:hi]
+    keep = ops.keep_table_causal(H, hi, T_m, top_k)[lo:hi].contiguous().to(q.device)
+    csr, _ = ops.topk_to_csr(pr.contiguous(), keep, top_k, target_width=hi, is_causal=True)
+    sl = lambda t: None if t is None else t[:, :, lo:hi].contiguous()
+    ctx = torch.empty((N, hi - lo, H * d), dtype=out_dtype or torch.float32, device=q.device)
+    ops.sparse_attention(q[:, :, lo:hi], k[:, :, :hi], v[:, :, :hi], csr, row_scale=sl(row_scale), avg=sl(avg), mix=sl(mix),
+                         out=ctx.view(N, hi - lo, H, d).permute(0, 2, 1, 3))
+    return ctx
+
+
+def all_gather_rows(local: torch.Tensor, bounds: List[Tuple[int, int]], group=None) -> torch.Tensor:
+    """Gather ragged row blocks (N, t_r, C) from every rank into (N, T, C): one padded all-gather."""
+    world = dist.get_world_size(group)
+    sizes = [hi - lo for lo, hi in bounds]
+    mx = max(sizes)
+    N, _, C = local.shape
+    padded = torch.zeros((N, mx, C), dtype=local.dtype, device=local.device)
+    padded[:, :local.shape[1]] = local
+    bufs = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(bufs, padded, group=group)
+    return torch.cat([b[:, :s] for b, s in zip(bufs, sizes)], dim=1)

@@ -100,3 +100,37 @@ def test_context_gatherer_single_process_is_identity():
     s = g.next_slot(); g.local[s].fill_(5.0)
     assert g.launch(s) is g.local[s]
     g.finish()
+
+
+def test_row_shard_bounds_balance_the_kept_entries():
+    from sea_attention_amd.distributed import row_shard_bounds
+    T, k = 4096, 64
+    for w in (2, 4, 8):
+        spans = [row_shard_bounds(T, w, r, k) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == T and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        cost = torch.clamp_max(torch.arange(1, T + 1, dtype=torch.float64), k)
+        loads = [float(cost[lo:hi].sum()) for lo, hi in spans]
+        assert max(loads) / (sum(loads) / w) < 1.02
+        assert spans[0][1] - spans[0][0] >= spans[-1][1] - spans[-1][0]      # early (cheap) rows: longer block
+
+
+def _worker_rows(rank, world, port, ret):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from sea_attention_amd import distributed as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T, C = 37, 6
+    full = torch.arange(2 * T * C, dtype=torch.float32).view(2, T, C)
+    bounds = [D.row_shard_bounds(T, world, r, k=8) for r in range(world)]
+    lo, hi = bounds[rank]
+    got = D.all_gather_rows(full[:, lo:hi].contiguous(), bounds)
+    ok = torch.equal(got, full)
+    dist.barrier(); dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(3)
+
+
+def test_all_gather_of_ragged_row_blocks_world2():
+    port = _free_port()
+    mp.spawn(_worker_rows, args=(2, port, None), nprocs=2, join=True)

@@ -134,3 +134,20 @@ def test_padded_batch_sparse_mode():
     out_d, bd = run(layer, q * d ** -0.5, q.clone(), q.clone(), mask, False)
     out_s, bs = run(layer, q * d ** -0.5, q.clone(), q.clone(), mask, True)
     assert (out_d.context_layer - out_s.context_layer).abs().max().item() < 1e-4
+
+
+def test_row_sharded_sparse_path_equals_the_full_one():
+    """SURVEY 8e, N < G: query rows split in nnz-balanced blocks, K/V replicated; every block runs steps H..L on the HIP
+    kernels as the tail of its own prefix (T_dst < T_src).  Concatenated, the blocks ARE the unsharded result."""
+    from sea_attention_amd import distributed as D
+    N, H, T, d, T_M, k = 1, 8, 1024, 64, 256, 64
+    S.seed(11)
+    probs = torch.softmax(torch.randn((N, H, T, T_M), device=DEV), -1).bfloat16()
+    q = (torch.randn((N, H, T, d), device=DEV) * d ** -0.5).bfloat16()
+    kk, v = torch.randn((N, H, T, d), device=DEV).bfloat16(), torch.randn((N, H, T, d), device=DEV).bfloat16()
+    rs = torch.sigmoid(torch.randn((N, H, T), device=DEV)); mx = torch.sigmoid(torch.randn((N, H, T), device=DEV))
+    avg = ops.cumavg(v)
+    full = D.sparse_rows(ops, probs, q, kk, v, 0, T, k, rs, avg, mx)
+    for world in (2, 4):
+        parts = [D.sparse_rows(ops, probs, q, kk, v, *D.row_shard_bounds(T, world, r, k), k, rs, avg, mx) for r in range(world)]
+        assert torch.equal(torch.cat(parts, dim=1), full)
