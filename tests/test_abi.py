@@ -64,3 +64,35 @@ def test_ops_refuse_cpu_tensors():
     q = torch.randn(1, 1, 2, 8)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         ops.flat_csr_masked_bmm(q, torch.randn(1, 1, 4, 8), csr)
+
+
+def test_ctypes_signatures_match_the_header_prototypes():
+    """Every prototype of include/sea_hip.h against the ctypes table of _lib.py: same number of parameters, and pointer
+    / integer / float kinds line up (a drifted binding would pass garbage without any error)."""
+    src = open(os.path.join(ROOT, "include", "sea_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    protos = re.findall(r"\b(?:int|int64_t|const char\s*\*)\s+(sea_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", src, flags=re.S)
+    assert len(protos) == len(_lib.EXPORTED_SYMBOLS)
+
+    def kind_of_c(param):
+        p = " ".join(param.split())
+        if p in ("void", ""):
+            return None
+        if "*" in p or p.startswith("sea_stream_t"):
+            return "ptr"
+        if p.startswith("float"):
+            return "float"
+        return "int"
+
+    def kind_of_ctypes(t):
+        if t in (ctypes.c_float, ctypes.c_double):
+            return "float"
+        if t in (ctypes.c_int, ctypes.c_int32, ctypes.c_int64):
+            return "int"
+        return "ptr"                                    # c_void_p, c_char_p, POINTER(...)
+
+    for name, params in protos:
+        want = [k for k in (kind_of_c(x) for x in params.split(",")) if k is not None]
+        argtypes, _res = _lib._SIGNATURES[name]
+        got = [kind_of_ctypes(t) for t in argtypes]
+        assert got == want, f"{name}: header {want} vs ctypes {got}"
