@@ -314,15 +314,32 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
 //     of lane group g is feature 16*(2kk + j/4) + 4g + j%4, and the phi(Q) fragment is gathered in that order.
 // ======================================================================================================
 typedef __attribute__((ext_vector_type(8))) __bf16 pbf8;
+typedef __attribute__((ext_vector_type(8))) _Float16 ph8;
 typedef __attribute__((ext_vector_type(4))) short ps4;
-#define SEA_MFMA_BF(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pbf8, (a)), __builtin_bit_cast(pbf8, (b)), (c), 0, 0, 0)
 
-__device__ inline unsigned short bf_bits(float x) { return __builtin_bit_cast(unsigned short, __float2bfloat16(x)); }
-__device__ inline float bf_val(unsigned short b) { return __uint_as_float((uint32_t)b << 16); }
-// x -> (hi, lo) bf16 bit patterns with hi + lo ~ x to 16 significand bits
-__device__ inline void bf_split(float x, unsigned short& hi, unsigned short& lo) {
-  hi = bf_bits(x);
-  lo = bf_bits(x - bf_val(hi));
+// 16-bit storage type of the split operands: bf16 data splits into bf16 terms (2 x 8 significand bits), fp16 data into
+// fp16 terms (2 x 11 bits; the state S and the products stay well inside fp16's range for T up to tens of thousands)
+template <typename T> struct S16;
+template <> struct S16<__hip_bfloat16> {
+  static constexpr unsigned short ONE = 0x3F80;
+  __device__ static inline unsigned short bits(float x) { return __builtin_bit_cast(unsigned short, __float2bfloat16(x)); }
+  __device__ static inline float val(unsigned short b) { return __uint_as_float((uint32_t)b << 16); }
+  __device__ static inline f4 mfma(const uint4& a, const uint4& b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pbf8, a), __builtin_bit_cast(pbf8, b), c, 0, 0, 0);
+  }
+};
+template <> struct S16<__half> {
+  static constexpr unsigned short ONE = 0x3C00;
+  __device__ static inline unsigned short bits(float x) { return __builtin_bit_cast(unsigned short, __float2half(x)); }
+  __device__ static inline float val(unsigned short b) { return __half2float(__builtin_bit_cast(__half, b)); }
+  __device__ static inline f4 mfma(const uint4& a, const uint4& b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(ph8, a), __builtin_bit_cast(ph8, b), c, 0, 0, 0);
+  }
+};
+// x -> (hi, lo) 16-bit patterns with hi + lo ~ x to twice the type's significand bits
+template <typename T> __device__ inline void split16(float x, unsigned short& hi, unsigned short& lo) {
+  hi = S16<T>::bits(x);
+  lo = S16<T>::bits(x - S16<T>::val(hi));
 }
 __device__ inline uint2 pack4(const unsigned short (&v)[4]) {
   return make_uint2((uint32_t)v[0] | ((uint32_t)v[1] << 16), (uint32_t)v[2] | ((uint32_t)v[3] << 16));
@@ -333,9 +350,8 @@ __device__ inline uint2 lds_tr(const unsigned short* p) {      // ds_read_b64_tr
   return __builtin_bit_cast(uint2, v);
 }
 
-template <int NBT>
+template <typename T, int NBT>
 __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
-  using T = __hip_bfloat16;
   constexpr int D = 64, C = 64, NW = 8, NTH = 512, E = 2 * D;
   constexpr int NBP = NBT * 16;
   constexpr int KF = (NBT + 1) / 2;            // 32-wide k-steps over the (padded) features
@@ -382,7 +398,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   // projection (its values are bf16-exact: the reference casts the buffer to the data dtype), zero padded rows
   for (int i = tid; i < (D / 8) * NBP * 8; i += NTH) {
     const int j = i & 7, f = (i >> 3) % NBP, kc = (i >> 3) / NBP;
-    sW[i] = f < p.nb ? bf_bits(p.W[f * D + kc * 8 + j]) : (unsigned short)0;
+    sW[i] = f < p.nb ? S16<T>::bits(p.W[f * D + kc * 8 + j]) : (unsigned short)0;
   }
   // phi and A images: padded features / upper-triangular tiles are written once (zero) and never again
   for (int i = tid; i < 4 * C * LDP + 2 * C * LDA; i += NTH) sQh[i] = 0;
@@ -445,7 +461,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   auto tril_frag = [&](int ib, int ks) {
     unsigned short o[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = (ks * 32 + lg * 8 + j <= ib * 16 + li) ? (unsigned short)0x3F80 : (unsigned short)0;
+    for (int j = 0; j < 8; ++j) o[j] = (ks * 32 + lg * 8 + j <= ib * 16 + li) ? S16<T>::ONE : (unsigned short)0;
     const unsigned short (&o0)[4] = *reinterpret_cast<const unsigned short (*)[4]>(&o[0]);
     const unsigned short (&o1)[4] = *reinterpret_cast<const unsigned short (*)[4]>(&o[4]);
     return cat8(pack4(o0), pack4(o1));
@@ -483,7 +499,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 #pragma unroll
         for (int fb = 0; fb < NBT; ++fb) {
           const uint4 aw = *reinterpret_cast<const uint4*>(sW + ((4 * ks + lg) * NBP + fb * 16 + li) * 8);
-          acc[fb] = SEA_MFMA_BF(aw, bx, acc[fb]);
+          acc[fb] = S16<T>::mfma(aw, bx, acc[fb]);
         }
       }
       unsigned short* dh = which ? sKh : sQh;
@@ -497,7 +513,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
           const int f = fb * 16 + lg * 4 + r;
           float val = fmaxf(cnorm * acc[fb][r], 0.f) + 1e-3f;
           if (f >= p.nb || row >= rows) val = 0.f;           // padded features / rows beyond T contribute nothing
-          bf_split(val, hh[r], ll[r]);
+          split16<T>(val, hh[r], ll[r]);
         }
         // feature 32kk + 16a + 4g + j is stored at position 32kk + 8g + 4a + j: the 8 features lane group g needs of
         // a 32-wide k-step in (d) (4 of tile 2kk, 4 of tile 2kk+1) are then one 16-byte piece
@@ -522,9 +538,9 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
         const uint4 kl = *reinterpret_cast<const uint4*>(sKl + (jb * 16 + li) * LDP + ko);
         const uint4 qh = *reinterpret_cast<const uint4*>(sQh + (ib * 16 + li) * LDP + ko);
         const uint4 ql = *reinterpret_cast<const uint4*>(sQl + (ib * 16 + li) * LDP + ko);
-        acc = SEA_MFMA_BF(kh, qh, acc);
-        acc = SEA_MFMA_BF(kh, ql, acc);
-        acc = SEA_MFMA_BF(kl, qh, acc);
+        acc = S16<T>::mfma(kh, qh, acc);
+        acc = S16<T>::mfma(kh, ql, acc);
+        acc = S16<T>::mfma(kl, qh, acc);
       }
       const int trow = ib * 16 + li;                         // lane: A[trow][s0 .. s0+3]
       const int s0 = jb * 16 + lg * 4;
@@ -534,7 +550,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
       for (int r = 0; r < 4; ++r) {
         const float val = (s0 + r <= trow) ? acc[r] : 0.f;   // causal mask inside the diagonal tiles
         rs += val;
-        bf_split(val, hh[r], ll[r]);
+        split16<T>(val, hh[r], ll[r]);
       }
       *reinterpret_cast<uint2*>(sAh + trow * LDA + s0) = pack4(hh);
       *reinterpret_cast<uint2*>(sAl + trow * LDA + s0) = pack4(ll);
@@ -552,10 +568,10 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
         const uint2 qh = *reinterpret_cast<const uint2*>(sQh + row * LDP + f);
         const uint2 ql = *reinterpret_cast<const uint2*>(sQl + row * LDP + f);
         const float4 ks = *reinterpret_cast<const float4*>(sKsum + f);
-        s = fmaf(bf_val((unsigned short)(qh.x & 0xffff)) + bf_val((unsigned short)(ql.x & 0xffff)), ks.x + 1e-6f, s);
-        s = fmaf(bf_val((unsigned short)(qh.x >> 16)) + bf_val((unsigned short)(ql.x >> 16)), ks.y + 1e-6f, s);
-        s = fmaf(bf_val((unsigned short)(qh.y & 0xffff)) + bf_val((unsigned short)(ql.y & 0xffff)), ks.z + 1e-6f, s);
-        s = fmaf(bf_val((unsigned short)(qh.y >> 16)) + bf_val((unsigned short)(ql.y >> 16)), ks.w + 1e-6f, s);
+        s = fmaf(S16<T>::val((unsigned short)(qh.x & 0xffff)) + S16<T>::val((unsigned short)(ql.x & 0xffff)), ks.x + 1e-6f, s);
+        s = fmaf(S16<T>::val((unsigned short)(qh.x >> 16)) + S16<T>::val((unsigned short)(ql.x >> 16)), ks.y + 1e-6f, s);
+        s = fmaf(S16<T>::val((unsigned short)(qh.y & 0xffff)) + S16<T>::val((unsigned short)(ql.y & 0xffff)), ks.z + 1e-6f, s);
+        s = fmaf(S16<T>::val((unsigned short)(qh.y >> 16)) + S16<T>::val((unsigned short)(ql.y >> 16)), ks.w + 1e-6f, s);
       }
       sDenP[row * DSL + RB + part] = s;
       // k-sum increment: wave w owns rows 8w .. 8w+7; lane = (4-position group fc, row lane rr)
@@ -568,10 +584,10 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
           const int r2 = wv * (C / NW) + rr * RPL + j;
           const uint2 kh = *reinterpret_cast<const uint2*>(sKh + r2 * LDP + fc * 4);
           const uint2 kl = *reinterpret_cast<const uint2*>(sKl + r2 * LDP + fc * 4);
-          k4[0] += bf_val((unsigned short)(kh.x & 0xffff)) + bf_val((unsigned short)(kl.x & 0xffff));
-          k4[1] += bf_val((unsigned short)(kh.x >> 16)) + bf_val((unsigned short)(kl.x >> 16));
-          k4[2] += bf_val((unsigned short)(kh.y & 0xffff)) + bf_val((unsigned short)(kl.y & 0xffff));
-          k4[3] += bf_val((unsigned short)(kh.y >> 16)) + bf_val((unsigned short)(kl.y >> 16));
+          k4[0] += S16<T>::val((unsigned short)(kh.x & 0xffff)) + S16<T>::val((unsigned short)(kl.x & 0xffff));
+          k4[1] += S16<T>::val((unsigned short)(kh.x >> 16)) + S16<T>::val((unsigned short)(kl.x >> 16));
+          k4[2] += S16<T>::val((unsigned short)(kh.y & 0xffff)) + S16<T>::val((unsigned short)(kl.y & 0xffff));
+          k4[3] += S16<T>::val((unsigned short)(kh.y >> 16)) + S16<T>::val((unsigned short)(kl.y >> 16));
         }
       }
 #pragma unroll
@@ -623,8 +639,8 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
         for (int ks = 0; ks <= ib / 2; ++ks) {
           const uint4 ah = *reinterpret_cast<const uint4*>(sAh + (ib * 16 + li) * LDA + ks * 32 + lg * 8);
           const uint4 al = *reinterpret_cast<const uint4*>(sAl + (ib * 16 + li) * LDA + ks * 32 + lg * 8);
-          o[ib] = SEA_MFMA_BF(ah, vf[ks], o[ib]);
-          o[ib] = SEA_MFMA_BF(al, vf[ks], o[ib]);
+          o[ib] = S16<T>::mfma(ah, vf[ks], o[ib]);
+          o[ib] = S16<T>::mfma(al, vf[ks], o[ib]);
         }
       }
       // phi(Q) S: the state tiles, split, are the B operand; k-step kk pairs feature blocks 2kk and 2kk+1
@@ -633,8 +649,8 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
         unsigned short h0[4], h1[4], l0[4], l1[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          bf_split(S[2 * kk][r], h0[r], l0[r]);
-          if (2 * kk + 1 < NBT) bf_split(S[(2 * kk + 1 < NBT) ? 2 * kk + 1 : 0][r], h1[r], l1[r]);
+          split16<T>(S[2 * kk][r], h0[r], l0[r]);
+          if (2 * kk + 1 < NBT) split16<T>(S[(2 * kk + 1 < NBT) ? 2 * kk + 1 : 0][r], h1[r], l1[r]);
           else h1[r] = l1[r] = 0;
         }
         const uint4 bh = cat8(pack4(h0), pack4(h1)), bl = cat8(pack4(l0), pack4(l1));
@@ -642,9 +658,9 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
         for (int ib = 0; ib < RB; ++ib) {
           const uint4 ah = *reinterpret_cast<const uint4*>(sQh + (ib * 16 + li) * LDP + kk * 32 + lg * 8);
           const uint4 al = *reinterpret_cast<const uint4*>(sQl + (ib * 16 + li) * LDP + kk * 32 + lg * 8);
-          o[ib] = SEA_MFMA_BF(ah, bh, o[ib]);
-          o[ib] = SEA_MFMA_BF(ah, bl, o[ib]);
-          o[ib] = SEA_MFMA_BF(al, bh, o[ib]);
+          o[ib] = S16<T>::mfma(ah, bh, o[ib]);
+          o[ib] = S16<T>::mfma(ah, bl, o[ib]);
+          o[ib] = S16<T>::mfma(al, bh, o[ib]);
         }
       }
       const int col = e0 + li;
@@ -653,7 +669,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = ib * 16 + lg * 4 + r;
-          sO[row * LDO + col] = bf_bits(o[ib][r] * sDen[row]);
+          sO[row * LDO + col] = S16<T>::bits(o[ib][r] * sDen[row]);
         }
       }
       if (want_avg && jb >= EB / 2) {                      // wave-uniform: this wave's 16 columns are v features
@@ -662,7 +678,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
         for (int ib = 0; ib < RB; ++ib) {
           cum[ib] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int ks = 0; ks <= ib / 2; ++ks) cum[ib] = SEA_MFMA_BF(tril[ib][ks], vf[ks], cum[ib]);
+          for (int ks = 0; ks <= ib / 2; ++ks) cum[ib] = S16<T>::mfma(tril[ib][ks], vf[ks], cum[ib]);
         }
         const int gcol = col - D;
 #pragma unroll
@@ -670,7 +686,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = ib * 16 + lg * 4 + r;
-            sAvg[row * LDG + gcol] = bf_bits((cum[ib][r] + csum) * sRinv[row]);
+            sAvg[row * LDG + gcol] = S16<T>::bits((cum[ib][r] + csum) * sRinv[row]);
           }
         csum += __shfl(cum[RB - 1][3], 48 + li);           // column total of the chunk = its last row's prefix
       }
@@ -685,8 +701,8 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
             const int co = (rb >> 1) * 32 + 8 * pp_ + (rb & 1) * 4;      // positions of features 16rb + 4p .. +3
             const uint4 kh = cat8(lds_tr(sKh + (r0 + q) * LDP + co), lds_tr(sKh + (r0 + 4 + q) * LDP + co));
             const uint4 kl = cat8(lds_tr(sKl + (r0 + q) * LDP + co), lds_tr(sKl + (r0 + 4 + q) * LDP + co));
-            S[rb] = SEA_MFMA_BF(kh, vf[ks], S[rb]);
-            S[rb] = SEA_MFMA_BF(kl, vf[ks], S[rb]);
+            S[rb] = S16<T>::mfma(kh, vf[ks], S[rb]);
+            S[rb] = S16<T>::mfma(kl, vf[ks], S[rb]);
           }
         }
       }
@@ -719,7 +735,7 @@ static int launch_perf(const PerfParams& p, hipStream_t s) {
   return SEA_OK;
 }
 
-template <int NBT>
+template <typename T, int NBT>
 static int launch_perf_bf16(const PerfParams& p, hipStream_t s) {
   constexpr int D = 64, C = 64, NTH = 512, E = 2 * D, NBP = NBT * 16, FP = ((NBT + 1) / 2) * 32, LDP = FP + 8, LDA = C + 8;
   constexpr size_t lds = 2 * ((D / 8) * NBP * 8 + 2 * (D / 8) * C * 8 + C * E + 4 * C * LDP + 2 * C * LDA + C * (E + 8) + C * (D + 8)) +
@@ -727,10 +743,10 @@ static int launch_perf_bf16(const PerfParams& p, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute((const void*)performer_bf16_kernel<NBT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)performer_bf16_kernel<T, NBT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     configured = true;
   }
-  hipLaunchKernelGGL((performer_bf16_kernel<NBT>), dim3((unsigned)(p.N * p.H)), dim3(NTH), lds, s, p);
+  hipLaunchKernelGGL((performer_bf16_kernel<T, NBT>), dim3((unsigned)(p.N * p.H)), dim3(NTH), lds, s, p);
   return SEA_OK;
 }
 
@@ -742,10 +758,10 @@ static bool perf_force_fp32() {
 
 template <typename T>
 static int dispatch_perf(const PerfParams& p, int D, int nbt, hipStream_t s) {
-  if constexpr (std::is_same<T, __hip_bfloat16>::value) {
+  if constexpr (!std::is_same<T, float>::value) {           // 16-bit data, d = 64: split-operand 16-bit MFMA kernel
     if (D == 64 && !perf_force_fp32()) {
-      if (nbt <= 3) return launch_perf_bf16<3>(p, s);
-      if (nbt <= 5) return launch_perf_bf16<5>(p, s);
+      if (nbt <= 3) return launch_perf_bf16<T, 3>(p, s);
+      if (nbt <= 5) return launch_perf_bf16<T, 5>(p, s);
     }
   }
   if (D == 64 && nbt <= 3) return launch_perf<T, 64, 3, 64>(p, s);
@@ -780,8 +796,8 @@ extern "C" int sea_performer_causal(const void* q, const void* k, const void* v,
               SEA_EUNSUPPORTED, "%s: rows must be 16-byte aligned", nm);
   PerfParams p;
   p.q = q; p.k = k; p.v = v; p.pos = pos; p.W = proj; p.out = out; p.avg = avg_out;
-  SEA_REQUIRE(avg_out == nullptr || (dtype == SEA_BF16 && D == 64 && nb <= 80 && !perf_force_fp32() && ((uintptr_t)avg_out & 15) == 0),
-              SEA_EUNSUPPORTED, "%s: avg_out needs the bf16 kernel (bf16 data, D = 64)", nm);
+  SEA_REQUIRE(avg_out == nullptr || ((dtype == SEA_BF16 || dtype == SEA_F16) && D == 64 && nb <= 80 && !perf_force_fp32() && ((uintptr_t)avg_out & 15) == 0),
+              SEA_EUNSUPPORTED, "%s: avg_out needs the 16-bit MFMA kernel (bf16 / fp16 data, D = 64)", nm);
   for (int i = 0; i < 3; ++i) { p.qs[i] = q_strides[i]; p.ks[i] = k_strides[i]; p.vs[i] = v_strides[i]; }
   p.pos_stride = pos_stride;
   p.N = (int)N; p.H = (int)H; p.T = (int)T; p.nb = (int)nb;

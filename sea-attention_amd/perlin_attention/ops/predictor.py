@@ -166,7 +166,7 @@ def performer_supported(D: int, nb: int) -> bool:
 
 def performer_avg_supported(q: torch.Tensor, nb: int) -> bool:
     """The bf16 Performer kernel (bf16 data, d = 64) can emit the cumulative average of v in the same launch."""
-    return q.dtype == torch.bfloat16 and q.shape[-1] == 64 and (nb + 15) // 16 <= 5
+    return q.dtype in (torch.bfloat16, torch.float16) and q.shape[-1] == 64 and (nb + 15) // 16 <= 5
 
 
 def performer_value(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torch.Tensor,

@@ -118,7 +118,7 @@ def test_module_hip_estimator_matches_torch_estimator():
         assert err <= atol, (name, err)
 
 
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,H,T,D,nbf", [(1, 2, 256, 64, 8), (2, 3, 200, 64, 8), (1, 2, 130, 80, 8), (1, 2, 96, 128, 8),
                                          (1, 1, 64, 64, 4), (1, 4, 1024, 64, 8), (1, 2, 333, 64, 8)])
 def test_performer_value(ops, dtype, N, H, T, D, nbf):
@@ -148,6 +148,11 @@ def test_performer_value(ops, dtype, N, H, T, D, nbf):
         torch.testing.assert_close(ctx, ref, atol=2e-4, rtol=2e-4)
         mine = fa(q, k, vaug)                                           # the package's torch path (chunked GEMMs)
         torch.testing.assert_close(ctx, mine, atol=2e-4, rtol=2e-4)
+    elif dtype == torch.float16:
+        torch.testing.assert_close(ctx, ref, atol=4e-3, rtol=4e-3)
+        refh = ref.to(dtype).float()                      # d = 64: split-fp16 MFMA kernel, 2 x 11 significand bits
+        if D == 64:
+            assert ((ctx - refh).abs() <= refh.abs() * 2.0 ** -10 + 2.0 ** -14).all()
     else:
         torch.testing.assert_close(ctx, ref, atol=3e-2, rtol=2e-2)
         # bf16 data runs the split-bf16 MFMA kernel (D = 64): its result is the fp32 formula to ~2^-16 of the row's
