@@ -1,5 +1,6 @@
 // Shared device/host helpers for libsea_hip.so (gfx950 only: wave64, DPP, 160 KB LDS).
 #pragma once
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <hip/hip_bf16.h>
@@ -134,7 +135,8 @@ template <typename T> __device__ inline T wave_sum(T v) {
 }
 template <typename T> __device__ inline T wave_max(T v) {
   if constexpr (sizeof(T) == 4) {
-    return wave_reduce32(v, [](T a, T b) { return b > a ? b : a; });
+    if constexpr (std::is_same<T, float>::value) return wave_reduce32(v, [](float a, float b) { return fmaxf(a, b); });   // v_max_f32_dpp
+    else return wave_reduce32(v, [](T a, T b) { return a > b ? a : b; });
   } else {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { T t = __shfl_xor(v, o); v = t > v ? t : v; }
@@ -143,7 +145,8 @@ template <typename T> __device__ inline T wave_max(T v) {
 }
 template <typename T> __device__ inline T wave_min(T v) {
   if constexpr (sizeof(T) == 4) {
-    return wave_reduce32(v, [](T a, T b) { return b < a ? b : a; });
+    if constexpr (std::is_same<T, float>::value) return wave_reduce32(v, [](float a, float b) { return fminf(a, b); });
+    else return wave_reduce32(v, [](T a, T b) { return a < b ? a : b; });
   } else {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { T t = __shfl_xor(v, o); v = t < v ? t : v; }

@@ -155,8 +155,10 @@ struct TailRow {
     }
   }
 
-  // area resize -> LayerNorm -> (scores) -> softmax -> probs of head h (one wave); a[] returns the probabilities
-  __device__ __forceinline__ void head(const TailParams& p, const float* zr, int lane, int64_t obase, float (&a)[E]) const {
+  // area resize -> LayerNorm -> (scores) -> softmax -> probs of head h (one wave); a[] returns the probabilities.
+  // FULLROW: T_M == 64 * E, every lane slot is a real pixel -- no per-element predicates, packed 8-byte stores.
+  template <bool FULLROW>
+  __device__ __forceinline__ void head_impl(const TailParams& p, const float* zr, int lane, int64_t obase, float (&a)[E]) const {
     const float invT = 1.0f / (float)p.T_M;
     float s1 = 0.f;
 #pragma unroll
@@ -168,26 +170,30 @@ struct TailRow {
     float s2 = 0.f;
 #pragma unroll
     for (int e = 0; e < E; ++e)
-      if (lane * E + e < p.T_M) { const float d = a[e] - mean; s2 += d * d; }
+      if (FULLROW || lane * E + e < p.T_M) { const float d = a[e] - mean; s2 += d * d; }
     const float rstd = rsqrtf(wave_sum(s2) * invT + p.eps);
     float mx = -INFINITY;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
       a[e] = (a[e] - mean) * rstd * g[e] + be[e];
-      if (lane * E + e < p.T_M) mx = fmaxf(mx, a[e]);
+      if (FULLROW || lane * E + e < p.T_M) mx = fmaxf(mx, a[e]);
     }
     mx = wave_max(mx);
-    if (p.scores) store_run<T, E>(reinterpret_cast<T*>(p.scores) + obase, a, lane * E, p.T_M);
+    if (p.scores) store_run<T, E>(reinterpret_cast<T*>(p.scores) + obase, a, lane * E, FULLROW ? 64 * E : p.T_M);
     float se = 0.f;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      a[e] = (lane * E + e < p.T_M) ? __expf(a[e] - mx) : 0.f;
+      a[e] = (FULLROW || lane * E + e < p.T_M) ? __expf(a[e] - mx) : 0.f;
       se += a[e];
     }
     const float inv = 1.0f / wave_sum(se);
 #pragma unroll
     for (int e = 0; e < E; ++e) a[e] *= inv;
-    store_run<T, E>(reinterpret_cast<T*>(p.probs) + obase, a, lane * E, p.T_M);
+    store_run<T, E>(reinterpret_cast<T*>(p.probs) + obase, a, lane * E, FULLROW ? 64 * E : p.T_M);
+  }
+  __device__ __forceinline__ void head(const TailParams& p, const float* zr, int lane, int64_t obase, float (&a)[E]) const {
+    if (p.T_M == 64 * E) head_impl<true>(p, zr, lane, obase, a);      // wave-uniform
+    else head_impl<false>(p, zr, lane, obase, a);
   }
 };
 
