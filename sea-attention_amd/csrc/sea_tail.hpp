@@ -146,10 +146,14 @@ struct TailRow {
         const int xs = (int)floorf((float)(j * Wp) / (float)p.T_M);
         const int xe = (int)ceilf((float)((j + 1) * Wp) / (float)p.T_M);
         rcnt[e] = 1.0f / (float)(xe - xs);
+        // source pixel of tap x: (x - 1) / UP; UP is a power of two in every configuration the reference builds
+        // (x4), so the 12 runtime integer divisions per lane (~20 VALU each) become shifts
+        const bool up_pow2 = (p.UP & (p.UP - 1)) == 0;          // block-uniform
+        const int up_sh = __ffs(p.UP) - 1;
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
           const int x = xs + k;
-          if (x < xe) src[e][k] = (x == 0 || x == Wp - 1) ? p.W4 : (x - 1) / p.UP;
+          if (x < xe) src[e][k] = (x == 0 || x == Wp - 1) ? p.W4 : (up_pow2 ? ((x - 1) >> up_sh) : (x - 1) / p.UP);
         }
       }
     }

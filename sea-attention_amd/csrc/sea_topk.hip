@@ -348,6 +348,8 @@ __device__ __forceinline__ void select_body(const TopkParams& p, uint32_t (&key)
   // ---- outputs ----------------------------------------------------------------------------------
   const int w_t = row_width(t, p.T_dst, p.T_src, p.is_causal);
   const float scale = interp_scale(w_t, p.T_m);
+  const bool tm_pow2 = (p.T_m & (p.T_m - 1)) == 0;      // block-uniform
+  const int tm_sh = __ffs(p.T_m) - 1;
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     const int c = j * TK_THREADS + tid;
@@ -377,7 +379,7 @@ __device__ __forceinline__ void select_body(const TopkParams& p, uint32_t (&key)
       const int i = __ffsll((long long)m) - 1;
       m &= m - 1;
       const int f = ((i >> 2) * TK_THREADS + tid) * 4 + (i & 3);
-      const int h = f / p.T_m, b = f - h * p.T_m;
+      const int h = tm_pow2 ? (f >> tm_sh) : f / p.T_m, b = f - h * p.T_m;   // T_m is a power of two in practice: shift
       int w = (int)(interp_bound(b + 1, scale) - interp_bound(b, scale));
       w = w < p.max_k ? w : p.max_k;
       if (w > 0) atomicAdd(&s_head[h], w);
