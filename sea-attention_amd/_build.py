@@ -30,7 +30,9 @@ def build_library(force=False, extra_flags=(), out=None, verbose=False):
     out = out or LIB_PATH
     if not force and out == LIB_PATH and not is_stale():
         return out
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+    # -fno-slp-vectorize: the SLP pass packs adjacent scalar f32 adds/muls into v_pk_* pairs plus the v_mov traffic
+    # to form the register pairs; on gfx950 that is a net loss in these VALU-issue-bound kernels (A/B: -1.5 % step)
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize",
            "-Wall", "-Wno-unused-function", *extra_flags,
            *[os.path.join(CSRC, s) for s in SOURCES], "-o", out + f".tmp.{os.getpid()}"]
     if verbose:
