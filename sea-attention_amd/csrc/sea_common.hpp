@@ -153,12 +153,28 @@ template <typename T> __device__ inline T wave_min(T v) {
     return v;
   }
 }
-// inclusive scan over the 64 lanes
+// inclusive scan over the 64 lanes.  32-bit types: the GFX9 DPP scan -- row_shr 1/2/4/8 inside each row of 16 lanes, then
+// row_bcast:15 (lane 15 of rows 0,2 into rows 1,3) and row_bcast:31 (lane 31 into rows 2,3): six VALU instructions
+// instead of six dependent ds_bpermute round trips.
+template <int CTRL, int ROW_MASK> __device__ inline uint32_t dpp_shift_u32(uint32_t v) {   // lanes without a source get 0
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
 template <typename T> __device__ inline T wave_incl_scan(T v) {
-  const int l = lane_id();
+  if constexpr (sizeof(T) == 4 && std::is_integral<T>::value) {
+    uint32_t x = (uint32_t)v;
+    x += dpp_shift_u32<0x111, 0xF>(x);     // row_shr:1
+    x += dpp_shift_u32<0x112, 0xF>(x);     // row_shr:2
+    x += dpp_shift_u32<0x114, 0xF>(x);     // row_shr:4
+    x += dpp_shift_u32<0x118, 0xF>(x);     // row_shr:8
+    x += dpp_shift_u32<0x142, 0xA>(x);     // row_bcast:15 -> rows 1 and 3
+    x += dpp_shift_u32<0x143, 0xC>(x);     // row_bcast:31 -> rows 2 and 3
+    return (T)x;
+  } else {
+    const int l = lane_id();
 #pragma unroll
-  for (int o = 1; o < 64; o <<= 1) { T t = __shfl_up(v, o); if (l >= o) v += t; }
-  return v;
+    for (int o = 1; o < 64; o <<= 1) { T t = __shfl_up(v, o); if (l >= o) v += t; }
+    return v;
+  }
 }
 
 // index load at the API edge: int32 internally, int64 for torch CSR tensors
