@@ -124,6 +124,15 @@ template <typename T, typename Op> __device__ inline T wave_reduce32(T v, Op op)
   }
   return v;
 }
+// v[l] + v[l ^ 16] and v[l] + v[l ^ 32] for every lane, through the gfx950 row-swap instructions (no LDS crossbar)
+__device__ inline float xor16_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ inline float xor32_sum(float v) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 template <typename T> __device__ inline T wave_sum(T v) {
   if constexpr (sizeof(T) == 4) {
     return wave_reduce32(v, [](T a, T b) { return a + b; });

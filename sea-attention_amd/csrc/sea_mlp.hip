@@ -134,14 +134,14 @@ __global__ __launch_bounds__(MLP_WAVES * 64) void predictor_mlp_kernel(MlpParams
         acc1[i][2] = round16<T>(acc1[i][2] + b.z); acc1[i][3] = round16<T>(acc1[i][3] + b.w);
         s += (acc1[i][0] + acc1[i][1]) + (acc1[i][2] + acc1[i][3]);
       }
-      s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+      s = xor32_sum(xor16_sum(s));
       const float mean = s * (1.0f / (float)D1);
       float q2 = 0.f;
 #pragma unroll
       for (int i = 0; i < NT1; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const float d = acc1[i][r] - mean; q2 += d * d; }
-      q2 += __shfl_xor(q2, 16); q2 += __shfl_xor(q2, 32);
+      q2 = xor32_sum(xor16_sum(q2));
       const float rstd = rsqrtf(q2 * (1.0f / (float)D1) + p.eps1);
 #pragma unroll
       for (int i = 0; i < NT1; ++i) {
@@ -195,14 +195,14 @@ __global__ __launch_bounds__(MLP_WAVES * 64) void predictor_mlp_kernel(MlpParams
         a[0] = round16<T>(a[0] + b.x); a[1] = round16<T>(a[1] + b.y); a[2] = round16<T>(a[2] + b.z); a[3] = round16<T>(a[3] + b.w);
         s += (a[0] + a[1]) + (a[2] + a[3]);
       }
-      s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+      s = xor32_sum(xor16_sum(s));
       const float mean = s * (1.0f / (float)Wd);
       float q2 = 0.f;
 #pragma unroll
       for (int i = 0; i < HT; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) { const float d = acc2[hf * HT + i][r] - mean; q2 += d * d; }
-      q2 += __shfl_xor(q2, 16); q2 += __shfl_xor(q2, 32);
+      q2 = xor32_sum(xor16_sum(q2));
       const float rstd = rsqrtf(q2 * (1.0f / (float)Wd) + p.eps2);
 #pragma unroll
       for (int i = 0; i < HT; ++i) {

@@ -554,7 +554,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
       }
       *reinterpret_cast<uint2*>(sAh + trow * LDA + s0) = pack4(hh);
       *reinterpret_cast<uint2*>(sAl + trow * LDA + s0) = pack4(ll);
-      rs += __shfl_xor(rs, 16); rs += __shfl_xor(rs, 32);
+      rs = xor32_sum(xor16_sum(rs));
       if (lg == 0) sDenP[trow * DSL + jb] = rs;              // one writer per (row, key block)
     }
     {
