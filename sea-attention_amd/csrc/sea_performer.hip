@@ -592,8 +592,12 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
+        if constexpr (FG == 16) {
+          k4[j] = xor16_sum(xor32_sum(k4[j]));                   // (l, l+32) then (+16): same association as the shuffle form
+        } else {
 #pragma unroll
-        for (int o = FG * (RRN / 2); o >= FG; o >>= 1) k4[j] += __shfl_down(k4[j], o);   // fixed order
+          for (int o = FG * (RRN / 2); o >= FG; o >>= 1) k4[j] += __shfl_down(k4[j], o);   // fixed order
+        }
       }
       if (lane < FG) *reinterpret_cast<float4*>(sKsP + wv * FP + fc * 4) = make_float4(k4[0], k4[1], k4[2], k4[3]);
     }
