@@ -223,3 +223,28 @@ def test_empty_rows_and_zero_keep(ops):
     assert torch.all(csr.crow[0, 11:21] == csr.crow[0, 10])
     out = ops.sparse_attention(q.to(DEV), kk.to(DEV), v.to(DEV), csr)
     assert torch.all(out[:, :, 10:20] == 0) and torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("N,H,T_dst,T_src,T_M,k,d", [(2, 4, 5, 200, 32, 8, 32), (1, 8, 1, 777, 64, 16, 64), (1, 3, 40, 64, 16, 4, 64),
+                                                     (1, 12, 17, 1030, 256, 64, 64)])
+def test_tail_rows_of_a_longer_prefix_match_the_oracle(ops, N, H, T_dst, T_src, T_M, k, d):
+    """The `T_dst < T_src` contract kv-cache decoding and row sharding rest on: the query rows are the LAST T_dst rows of
+    a T_src-long causal sequence (row width = T_src - T_dst + t + 1, `target_width = arange(1..T_src)[-T_dst:]`,
+    causal_resize_m_to_t.py:951-955).  Top-k mask and CSR bit-exact, attention within tolerance."""
+    g = torch.Generator().manual_seed(5)
+    probs = torch.softmax(torch.randn((N, H, T_dst, T_M), generator=g), -1)
+    q = torch.randn((N, H, T_dst, d), generator=g) * d ** -0.5
+    kk, v = torch.randn((N, H, T_src, d), generator=g), torch.randn((N, H, T_src, d), generator=g)
+    rs = torch.sigmoid(torch.randn((N, H, T_dst), generator=g))
+    keep = O.keep_counts_module(H, T_src, T_M, k)[-T_dst:].contiguous()
+    mask = O.grouped_topk_mask(probs, keep)
+    crow, col = O.resize_m_to_t_csr(mask, k, T_src, True)
+    ref = O.sparse_attention(q, kk, v, crow, col, rs)
+    csr, m_dev = ops.topk_to_csr(probs.to(DEV), keep.to(torch.int32).to(DEV), k, target_width=T_src, want_mask=True)
+    assert torch.equal(m_dev.cpu(), mask.float())
+    assert torch.equal(csr.crow.cpu().long(), crow)
+    for n in range(N):
+        z = int(crow[n, -1])
+        assert torch.equal(csr.col[n, :z].cpu().long(), col[n, :z])
+    out = ops.sparse_attention(q.to(DEV), kk.to(DEV), v.to(DEV), csr, row_scale=rs.to(DEV))
+    torch.testing.assert_close(out.cpu(), ref, atol=1e-4, rtol=1e-3)
