@@ -572,6 +572,7 @@ __global__ __launch_bounds__(TK_THREADS) void csr_emit_kernel(EmitParams p) {
     for (int win = (carry / EM_WIN) * EM_WIN; win < carry + total; win += EM_WIN) {
       int off = carry + excl;                                       // row-relative offset of this thread's first entry
       if (nent > 0 && off < win + EM_WIN && off + nent > win) {
+        const bool inside = off >= win && off + nent <= win + EM_WIN;
         for (uint32_t m = word; m;) {
           const int bit = __ffs(m) - 1;
           m &= m - 1;
@@ -581,9 +582,15 @@ __global__ __launch_bounds__(TK_THREADS) void csr_emit_kernel(EmitParams p) {
           const int wd = hi - lo;
           const int hb = h * p.T_src;
           if (wd <= p.max_k) {
-            for (int j = 0; j < wd; ++j) {
-              const int o = off + j - win;
-              if ((unsigned)o < (unsigned)EM_WIN) s_out[o] = hb + hi - 1 - j;
+            if (inside) {                                           // the common case: no per-entry window test
+              int* dst = s_out + (off - win);
+              const int c0 = hb + hi - 1;
+              for (int j = 0; j < wd; ++j) dst[j] = c0 - j;
+            } else {
+              for (int j = 0; j < wd; ++j) {
+                const int o = off + j - win;
+                if ((unsigned)o < (unsigned)EM_WIN) s_out[o] = hb + hi - 1 - j;
+              }
             }
             off += wd;
           } else {                                                  // thinned pixel: the reference's fp32 stepping
