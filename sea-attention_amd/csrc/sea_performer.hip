@@ -358,19 +358,24 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   constexpr int FP = KF * 32;                  // padded feature count
   constexpr int RB = C / 16, EB = E / 16;
   static_assert(EB == NW, "one 16-column block of [pos | v] per wave");
-  constexpr int LDP = FP + 8;                  // phi rows (elements); +16 B against bank aliasing
-  constexpr int LDA = C + 8;                   // A rows
+  // LDS row strides picked with a bank model of the two access patterns (64 banks x 4 B; b128 row reads are served in
+  // 4 lane groups of 16, transposing b64 reads in 2 of 32): 160 / 224 B rows make the operand row reads conflict-free
+  // (4 cycles per wave instruction; the first version's 144 B rows: 8), 192 B rows halve the conflicts of the
+  // transposing reads of phi(K) (4 cycles; 144 B: 8; the conflict-free 2 needs a swizzle); rows stay 16-byte multiples
+  constexpr int LDQ2 = FP + 16;                // phi(Q) rows (elements): row reads only
+  constexpr int LDK2 = (FP == 64) ? 96 : FP + 8; // phi(K) rows (16-byte multiples): transposing reads + a few row reads
+  constexpr int LDA = C + 16;                  // A rows: row reads only
   constexpr int DSL = RB + NTH / C;            // denominator partial slots per row
   extern __shared__ __attribute__((aligned(16))) char smem_b[];
   unsigned short* sW = reinterpret_cast<unsigned short*>(smem_b);   // [D/8][NBP][8]   projection, k-chunked
   unsigned short* sQ = sW + (D / 8) * NBP * 8;                      // [D/8][C][8]
   unsigned short* sK = sQ + (D / 8) * C * 8;                        // [D/8][C][8]
   unsigned short* sV = sK + (D / 8) * C * 8;                        // [C][E] 256-byte rows, chunk-swizzled
-  unsigned short* sQh = sV + C * E;                                 // [C][LDP]
-  unsigned short* sQl = sQh + C * LDP;
-  unsigned short* sKh = sQl + C * LDP;
-  unsigned short* sKl = sKh + C * LDP;
-  unsigned short* sAh = sKl + C * LDP;                              // [C][LDA]
+  unsigned short* sQh = sV + C * E;                                 // [C][LDQ2]
+  unsigned short* sQl = sQh + C * LDQ2;
+  unsigned short* sKh = sQl + C * LDQ2;                             // [C][LDK2]
+  unsigned short* sKl = sKh + C * LDK2;
+  unsigned short* sAh = sKl + C * LDK2;                             // [C][LDA]
   unsigned short* sAl = sAh + C * LDA;
   constexpr int LDO = E + 8;
   unsigned short* sO = sAl + C * LDA;                               // [C][LDO]  the chunk's result rows, flushed one chunk later
@@ -401,7 +406,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
     sW[i] = f < p.nb ? S16<T>::bits(p.W[f * D + kc * 8 + j]) : (unsigned short)0;
   }
   // phi and A images: padded features / upper-triangular tiles are written once (zero) and never again
-  for (int i = tid; i < 4 * C * LDP + 2 * C * LDA; i += NTH) sQh[i] = 0;
+  for (int i = tid; i < 2 * C * LDQ2 + 2 * C * LDK2 + 2 * C * LDA; i += NTH) sQh[i] = 0;
   for (int i = tid; i < FP; i += NTH) sKsum[i] = 0.f;
   for (int i = tid; i < C * DSL; i += NTH) sDenP[i] = 0.f;   // slots of key blocks above the diagonal stay zero
 
@@ -518,8 +523,9 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
         // feature 32kk + 16a + 4g + j is stored at position 32kk + 8g + 4a + j: the 8 features lane group g needs of
         // a 32-wide k-step in (d) (4 of tile 2kk, 4 of tile 2kk+1) are then one 16-byte piece
         const int pos = (fb >> 1) * 32 + lg * 8 + (fb & 1) * 4;
-        *reinterpret_cast<uint2*>(dh + row * LDP + pos) = pack4(hh);
-        *reinterpret_cast<uint2*>(dl + row * LDP + pos) = pack4(ll);
+        const int ldx = which ? LDK2 : LDQ2;
+        *reinterpret_cast<uint2*>(dh + row * ldx + pos) = pack4(hh);
+        *reinterpret_cast<uint2*>(dl + row * ldx + pos) = pack4(ll);
       }
     }
     __syncthreads();
@@ -534,10 +540,10 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 #pragma unroll
       for (int ks = 0; ks < KF; ++ks) {
         const int ko = ks * 32 + lg * 8;
-        const uint4 kh = *reinterpret_cast<const uint4*>(sKh + (jb * 16 + li) * LDP + ko);
-        const uint4 kl = *reinterpret_cast<const uint4*>(sKl + (jb * 16 + li) * LDP + ko);
-        const uint4 qh = *reinterpret_cast<const uint4*>(sQh + (ib * 16 + li) * LDP + ko);
-        const uint4 ql = *reinterpret_cast<const uint4*>(sQl + (ib * 16 + li) * LDP + ko);
+        const uint4 kh = *reinterpret_cast<const uint4*>(sKh + (jb * 16 + li) * LDK2 + ko);
+        const uint4 kl = *reinterpret_cast<const uint4*>(sKl + (jb * 16 + li) * LDK2 + ko);
+        const uint4 qh = *reinterpret_cast<const uint4*>(sQh + (ib * 16 + li) * LDQ2 + ko);
+        const uint4 ql = *reinterpret_cast<const uint4*>(sQl + (ib * 16 + li) * LDQ2 + ko);
         acc = S16<T>::mfma(kh, qh, acc);
         acc = S16<T>::mfma(kh, ql, acc);
         acc = S16<T>::mfma(kl, qh, acc);
@@ -565,8 +571,8 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 #pragma unroll
       for (int g4 = 0; g4 < PER / 4; ++g4) {
         const int f = part * PER + g4 * 4;
-        const uint2 qh = *reinterpret_cast<const uint2*>(sQh + row * LDP + f);
-        const uint2 ql = *reinterpret_cast<const uint2*>(sQl + row * LDP + f);
+        const uint2 qh = *reinterpret_cast<const uint2*>(sQh + row * LDQ2 + f);
+        const uint2 ql = *reinterpret_cast<const uint2*>(sQl + row * LDQ2 + f);
         const float4 ks = *reinterpret_cast<const float4*>(sKsum + f);
         s = fmaf(S16<T>::val((unsigned short)(qh.x & 0xffff)) + S16<T>::val((unsigned short)(ql.x & 0xffff)), ks.x + 1e-6f, s);
         s = fmaf(S16<T>::val((unsigned short)(qh.x >> 16)) + S16<T>::val((unsigned short)(ql.x >> 16)), ks.y + 1e-6f, s);
@@ -582,8 +588,8 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 #pragma unroll
         for (int j = 0; j < RPL; ++j) {
           const int r2 = wv * (C / NW) + rr * RPL + j;
-          const uint2 kh = *reinterpret_cast<const uint2*>(sKh + r2 * LDP + fc * 4);
-          const uint2 kl = *reinterpret_cast<const uint2*>(sKl + r2 * LDP + fc * 4);
+          const uint2 kh = *reinterpret_cast<const uint2*>(sKh + r2 * LDK2 + fc * 4);
+          const uint2 kl = *reinterpret_cast<const uint2*>(sKl + r2 * LDK2 + fc * 4);
           k4[0] += S16<T>::val((unsigned short)(kh.x & 0xffff)) + S16<T>::val((unsigned short)(kl.x & 0xffff));
           k4[1] += S16<T>::val((unsigned short)(kh.x >> 16)) + S16<T>::val((unsigned short)(kl.x >> 16));
           k4[2] += S16<T>::val((unsigned short)(kh.y & 0xffff)) + S16<T>::val((unsigned short)(kl.y & 0xffff));
@@ -660,8 +666,8 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
         const uint4 bh = cat8(pack4(h0), pack4(h1)), bl = cat8(pack4(l0), pack4(l1));
 #pragma unroll
         for (int ib = 0; ib < RB; ++ib) {
-          const uint4 ah = *reinterpret_cast<const uint4*>(sQh + (ib * 16 + li) * LDP + kk * 32 + lg * 8);
-          const uint4 al = *reinterpret_cast<const uint4*>(sQl + (ib * 16 + li) * LDP + kk * 32 + lg * 8);
+          const uint4 ah = *reinterpret_cast<const uint4*>(sQh + (ib * 16 + li) * LDQ2 + kk * 32 + lg * 8);
+          const uint4 al = *reinterpret_cast<const uint4*>(sQl + (ib * 16 + li) * LDQ2 + kk * 32 + lg * 8);
           o[ib] = S16<T>::mfma(ah, bh, o[ib]);
           o[ib] = S16<T>::mfma(ah, bl, o[ib]);
           o[ib] = S16<T>::mfma(al, bh, o[ib]);
@@ -703,8 +709,8 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
           for (int ks = 0; ks < C / 32; ++ks) {
             const int r0 = ks * 32 + lg * 8;
             const int co = (rb >> 1) * 32 + 8 * pp_ + (rb & 1) * 4;      // positions of features 16rb + 4p .. +3
-            const uint4 kh = cat8(lds_tr(sKh + (r0 + q) * LDP + co), lds_tr(sKh + (r0 + 4 + q) * LDP + co));
-            const uint4 kl = cat8(lds_tr(sKl + (r0 + q) * LDP + co), lds_tr(sKl + (r0 + 4 + q) * LDP + co));
+            const uint4 kh = cat8(lds_tr(sKh + (r0 + q) * LDK2 + co), lds_tr(sKh + (r0 + 4 + q) * LDK2 + co));
+            const uint4 kl = cat8(lds_tr(sKl + (r0 + q) * LDK2 + co), lds_tr(sKl + (r0 + 4 + q) * LDK2 + co));
             S[rb] = S16<T>::mfma(kh, vf[ks], S[rb]);
             S[rb] = S16<T>::mfma(kl, vf[ks], S[rb]);
           }
@@ -741,8 +747,8 @@ static int launch_perf(const PerfParams& p, hipStream_t s) {
 
 template <typename T, int NBT>
 static int launch_perf_bf16(const PerfParams& p, hipStream_t s) {
-  constexpr int D = 64, C = 64, NTH = 512, E = 2 * D, NBP = NBT * 16, FP = ((NBT + 1) / 2) * 32, LDP = FP + 8, LDA = C + 8;
-  constexpr size_t lds = 2 * ((D / 8) * NBP * 8 + 2 * (D / 8) * C * 8 + C * E + 4 * C * LDP + 2 * C * LDA + C * (E + 8) + C * (D + 8)) +
+  constexpr int D = 64, C = 64, NTH = 512, E = 2 * D, NBP = NBT * 16, FP = ((NBT + 1) / 2) * 32, LDQ2 = FP + 16, LDK2 = (FP == 64) ? 96 : FP + 8, LDA = C + 16;
+  constexpr size_t lds = 2 * ((D / 8) * NBP * 8 + 2 * (D / 8) * C * 8 + C * E + 2 * C * LDQ2 + 2 * C * LDK2 + 2 * C * LDA + C * (E + 8) + C * (D + 8)) +
                          sizeof(float) * (FP + C + C * (C / 16 + NTH / C) + 8 * FP + C);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool configured = false;
