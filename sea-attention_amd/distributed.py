@@ -69,6 +69,7 @@ class ContextGatherer:
                     if self.world > 1 else self.local)
         self._work = [None] * depth
         self._i = 0
+        self._sync_only = False
 
     def next_slot(self) -> int:
         slot = self._i % self.depth
@@ -81,7 +82,15 @@ class ContextGatherer:
 
     def launch(self, slot: int) -> torch.Tensor:
         if self.world > 1:
-            self._work[slot] = dist.all_gather_into_tensor(self.out[slot], self.local[slot], group=self.group, async_op=True)
+            if not self._sync_only:
+                try:
+                    self._work[slot] = dist.all_gather_into_tensor(self.out[slot], self.local[slot], group=self.group,
+                                                                    async_op=True)
+                    return self.out[slot]
+                except (RuntimeError, NotImplementedError):   # backend without the fused / asynchronous form: every
+                    self._sync_only = True                    # rank takes the same branch (same software everywhere)
+            chunks = list(self.out[slot].chunk(self.world, dim=0))
+            dist.all_gather(chunks, self.local[slot], group=self.group)
         return self.out[slot]
 
     def finish(self) -> None:
