@@ -48,3 +48,8 @@ def lora_forward_lora(linear: nn.Linear, linear_x: torch.Tensor, lora: LoraLinea
         N, H, T, D = heads
         y = y.view(N, T, H, D).permute(0, 2, 1, 3).contiguous()
     return y
+
+
+def lora_forward(linear: nn.Linear, lora: LoraLinear, x: torch.Tensor, enabled: bool):
+    """linear(x) with the low-rank update folded in (lora.py:95-99 of the reference)."""
+    return lora_forward_lora(linear, lora_forward_linear(linear, x), lora, x, enabled)
