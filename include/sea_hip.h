@@ -256,6 +256,23 @@ int sea_performer_causal(const void* q, const void* k, const void* v, const void
                          const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                          int64_t pos_stride, void* out, void* avg_out, sea_stream_t stream);
 
+/* Sequence-parallel form of sea_performer_causal.  One workgroup walks one (n, h) pair's rows in order, so N*H pairs
+ * fill N*H compute units: the reference's configurations that put ONE sequence on a GPU (BASELINE configs 4-5: 32-40
+ * pairs on 256 CUs) leave most of the chip idle.  With n_segments > 1 the T rows are cut into segments of whole
+ * 64-row chunks; a first launch leaves every segment's state increment (sum phi(k)^T [pos|v], sum phi(k), sum v) in
+ * `workspace`, the second starts each segment from the sum of the increments before it (added in segment order:
+ * results are reproducible run to run; they differ from the one-segment kernel in fp32 summation order only).
+ * sea_performer_plan proposes n_segments for a shape (1 when N*H already fills the chip) and the workspace size;
+ * the caller owns the workspace (16-byte aligned, no initialisation needed).  n_segments = 1 is
+ * sea_performer_causal (workspace may be NULL).  Same role in the reference as sea_performer_causal. */
+int sea_performer_plan(int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb, int dtype,
+                       int64_t* n_segments, int64_t* workspace_bytes);
+int sea_performer_causal_segmented(const void* q, const void* k, const void* v, const void* pos, int dtype,
+                                   const float* proj, int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb,
+                                   const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                                   int64_t pos_stride, void* out, void* avg_out, int64_t n_segments,
+                                   void* workspace, int64_t workspace_bytes, sea_stream_t stream);
+
 /* Algorithmic bytes of one sea_sparse_attention launch:
  * Z*(2*D*s + 4) + N*H*T_dst*(2*D*s + 4).  Host-side helper, no device work. */
 int64_t sea_sparse_attention_bytes(int64_t Z, int64_t N, int64_t H, int64_t T_dst, int64_t D, int elem_bytes);

@@ -44,10 +44,15 @@ struct PerfParams {
   int64_t qs[3], ks[3], vs[3];
   int64_t pos_stride;
   int N, H, T, nb;
+  // sequence-parallel form (few (n,h) pairs): the T rows are cut into nseg segments of seg_len rows (a multiple of the
+  // chunk size).  Pass 1 (STATE_ONLY kernels, grid.y = nseg-1) leaves every segment's state increment in `carry`,
+  // pass 2 (grid.y = nseg) starts each segment from the sum of the increments before it.  nseg = 1: one pass.
+  float* carry;
+  int nseg, seg_len;
 };
 
 // NW = waves per workgroup (8: two per SIMD, so one wave's LDS/MFMA latency hides behind the other's issue)
-template <typename T, int D, int NBT, int C, int NW>
+template <typename T, int D, int NBT, int C, int NW, bool STATE_ONLY>
 __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
   constexpr int NTH = NW * 64;
   constexpr int VEC = Elem<T>::VEC;
@@ -76,6 +81,8 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
   const int li = lane & 15, lg = lane >> 4;   // MFMA lane coordinates
   const int nh = blockIdx.x;
   const int n = nh / p.H, h = nh - n * p.H;
+  const int seg = blockIdx.y;
+  const int t_begin = seg * p.seg_len, t_end = min(p.T, t_begin + p.seg_len);
   const T* qb = reinterpret_cast<const T*>(p.q) + n * p.qs[0] + h * p.qs[1];
   const T* kb = reinterpret_cast<const T*>(p.k) + n * p.ks[0] + h * p.ks[1];
   const T* vb = reinterpret_cast<const T*>(p.v) + n * p.vs[0] + h * p.vs[1];
@@ -87,13 +94,30 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
     const int r = i / LDW, c = i - r * LDW;
     sW[i] = (r < p.nb && c < D) ? p.W[r * D + c] : 0.f;
   }
-  for (int i = tid; i < NBP; i += NTH) sKsum[i] = 0.f;
 
+  // state = sum of the increments of the segments before this one (fixed order); raw per-thread register images
+  constexpr int CARRY = JB * NBT * 4 * NTH + NBP;
   f4 S[JB][NBT];
 #pragma unroll
   for (int a = 0; a < JB; ++a)
 #pragma unroll
     for (int b = 0; b < NBT; ++b) S[a][b] = f4{0.f, 0.f, 0.f, 0.f};
+  {
+    float ks0 = 0.f;
+    if (!STATE_ONLY) {
+      for (int s2 = 0; s2 < seg; ++s2) {
+        const float* cr = p.carry + ((int64_t)nh * (p.nseg - 1) + s2) * CARRY;
+#pragma unroll
+        for (int a = 0; a < JB; ++a)
+#pragma unroll
+          for (int b = 0; b < NBT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[a][b][r] += cr[((a * NBT + b) * 4 + r) * NTH + tid];
+        if (tid < NBP) ks0 += cr[JB * NBT * 4 * NTH + tid];
+      }
+    }
+    if (tid < NBP) sKsum[tid] = ks0;
+  }
 
 #ifdef SEA_STAMP
   unsigned long long _tprev = __builtin_amdgcn_s_memtime();
@@ -108,19 +132,19 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
       const int ch = tid + i * NTH;
       const int r = ch / (D / VEC), c = (ch - r * (D / VEC)) * VEC;
       pq[i] = pk[i] = pv[i] = pp[i] = make_uint4(0, 0, 0, 0);
-      if (ch < C * (D / VEC) && t0n + r < p.T) {
+      if (ch < C * (D / VEC) && t0n + r < t_end) {
         const int64_t t = t0n + r;
-        pq[i] = *reinterpret_cast<const uint4*>(qb + t * p.qs[2] + c);
+        if (!STATE_ONLY) pq[i] = *reinterpret_cast<const uint4*>(qb + t * p.qs[2] + c);
         pk[i] = *reinterpret_cast<const uint4*>(kb + t * p.ks[2] + c);
         pv[i] = *reinterpret_cast<const uint4*>(vb + t * p.vs[2] + c);
         pp[i] = *reinterpret_cast<const uint4*>(pb + t * p.pos_stride + c);
       }
     }
   };
-  issue_loads(0);
+  issue_loads(t_begin);
 
-  for (int t0 = 0; t0 < p.T; t0 += C) {
-    const int rows = min(C, p.T - t0);
+  for (int t0 = t_begin; t0 < t_end; t0 += C) {
+    const int rows = min(C, t_end - t0);
     // ---- (a) registers -> LDS as fp32: Q, K (C x D), V = [pos | v] (C x 2D); copy v into out[..., 2D:3D] ------
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -128,7 +152,7 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
       if (ch < C * (D / VEC)) {
         const int r = ch / (D / VEC), c = (ch - r * (D / VEC)) * VEC;
         float fq[VEC], fk[VEC], fv[VEC], fp[VEC];
-        if (r < rows) *reinterpret_cast<uint4*>(ob + (int64_t)(t0 + r) * (3 * D) + 2 * D + c) = pv[i];
+        if (!STATE_ONLY && r < rows) *reinterpret_cast<uint4*>(ob + (int64_t)(t0 + r) * (3 * D) + 2 * D + c) = pv[i];
         unpack16<T>(pq[i], fq); unpack16<T>(pk[i], fk); unpack16<T>(pv[i], fv); unpack16<T>(pp[i], fp);
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -139,14 +163,14 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
         }
       }
     }
-    if (t0 + C < p.T) issue_loads(t0 + C);                 // next chunk: in flight during phases (b)..(e)
-    for (int i = tid; i < C * DSL; i += NTH) sDenP[i] = 0.f;
+    if (t0 + C < t_end) issue_loads(t0 + C);               // next chunk: in flight during phases (b)..(e)
+    if (!STATE_ONLY) for (int i = tid; i < C * DSL; i += NTH) sDenP[i] = 0.f;
     __syncthreads();
     PSTAMP(0);   // (a) staging
 
     // ---- (b) feature maps phi(Q), phi(K): (C x D) @ W^T -> (C x NBP) -------------------------------------
     // a wave takes (matrix, row block) pairs: one A fragment feeds NBT independent accumulators
-    for (int grp = wv; grp < 2 * RB; grp += NW) {
+    for (int grp = (STATE_ONLY ? RB : 0) + wv; grp < 2 * RB; grp += NW) {   // the state-only pass needs phi(K) alone
       const int which = grp / RB, ib = grp - which * RB;        // 0: Q, 1: K
       const float* src = which ? sK : sQ;
       f4 acc[NBT];
@@ -178,6 +202,7 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
     PSTAMP(1);   // (b) feature maps
 
     // ---- (c) A = tril(phi(Q) phi(K)^T) (C x C, lower-triangular blocks), row sums into sDen -------------------
+    if constexpr (!STATE_ONLY) {
     for (int tile = wv; tile < RB * (RB + 1) / 2; tile += NW) {
       int ib = 0, rem = tile;
       while (rem > ib) { rem -= ib + 1; ++ib; }          // tile -> (ib, jb) with jb <= ib
@@ -217,6 +242,7 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
       sDen[tid] = s;
     }
     __syncthreads();
+    }
     PSTAMP(2);   // (c) A + denominators
     // the diagonal part of the denominator also carries eps: sum_r phi(q)_r * eps is already in the carry term;
     // the intra-chunk part needs none (eps is added once to the k-sum, not per key).
@@ -227,6 +253,7 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
     for (int a_ = 0; a_ < JB; ++a_) {
       const int jb = wv + NW * a_;
       if (jb < EB) {
+        if constexpr (!STATE_ONLY) {
         f4 o[RB];
 #pragma unroll
         for (int ib = 0; ib < RB; ++ib) o[ib] = f4{0.f, 0.f, 0.f, 0.f};
@@ -266,6 +293,7 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
             if (row < rows) ob[(int64_t)(t0 + row) * (3 * D) + col] = from_f<T>(o[ib][r] / sDen[row]);
           }
         }
+        }
         // (e) state update: one V fragment feeds the NBT state tiles of this column block
 #pragma unroll 4
         for (int ks = 0; ks < C / 4; ++ks) {
@@ -288,6 +316,16 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
     }
     __syncthreads();
     PSTAMP(4);   // ksum
+  }
+  if constexpr (STATE_ONLY) {
+    float* cw = p.carry + ((int64_t)nh * (p.nseg - 1) + seg) * CARRY;
+#pragma unroll
+    for (int a = 0; a < JB; ++a)
+#pragma unroll
+      for (int b = 0; b < NBT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cw[((a * NBT + b) * 4 + r) * NTH + tid] = S[a][b][r];
+    if (tid < NBP) cw[JB * NBT * 4 * NTH + tid] = sKsum[tid];
   }
 }
 
@@ -350,7 +388,7 @@ __device__ inline uint2 lds_tr(const unsigned short* p) {      // ds_read_b64_tr
   return __builtin_bit_cast(uint2, v);
 }
 
-template <typename T, int NBT>
+template <typename T, int NBT, bool STATE_ONLY>
 __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   constexpr int D = 64, C = 64, NW = 8, NTH = 512, E = 2 * D;
   constexpr int NBP = NBT * 16;
@@ -393,6 +431,8 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   const int li = lane & 15, lg = lane >> 4;
   const int nh = blockIdx.x;
   const int n = nh / p.H, h = nh - n * p.H;
+  const int seg = blockIdx.y;                              // sequence-parallel form, see PerfParams
+  const int t_begin = seg * p.seg_len, t_end = min(p.T, t_begin + p.seg_len);
   const T* qb = reinterpret_cast<const T*>(p.q) + n * p.qs[0] + h * p.qs[1];
   const T* kb = reinterpret_cast<const T*>(p.k) + n * p.ks[0] + h * p.ks[1];
   const T* vb = reinterpret_cast<const T*>(p.v) + n * p.vs[0] + h * p.vs[1];
@@ -407,12 +447,29 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   }
   // phi and A images: padded features / upper-triangular tiles are written once (zero) and never again
   for (int i = tid; i < 2 * C * LDQ2 + 2 * C * LDK2 + 2 * C * LDA; i += NTH) sQh[i] = 0;
-  for (int i = tid; i < FP; i += NTH) sKsum[i] = 0.f;
   for (int i = tid; i < C * DSL; i += NTH) sDenP[i] = 0.f;   // slots of key blocks above the diagonal stay zero
 
+  // carry image of one (n, h, segment): per-thread state registers, the k-sum, the per-thread column sum of v
+  constexpr int CARRY = NBT * 4 * NTH + FP + NTH;
   f4 S[NBT];
 #pragma unroll
   for (int b = 0; b < NBT; ++b) S[b] = f4{0.f, 0.f, 0.f, 0.f};
+  float csum = 0.f;                                        // running column sum of v (cumulative-average output)
+  {
+    float ks0 = 0.f;
+    if (!STATE_ONLY) {
+      for (int s2 = 0; s2 < seg; ++s2) {                   // fixed order: bitwise reproducible
+        const float* cr = p.carry + ((int64_t)nh * (p.nseg - 1) + s2) * CARRY;
+#pragma unroll
+        for (int b = 0; b < NBT; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) S[b][r] += cr[(b * 4 + r) * NTH + tid];
+        if (tid < FP) ks0 += cr[NBT * 4 * NTH + tid];
+        csum += cr[NBT * 4 * NTH + FP + tid];
+      }
+    }
+    if (tid < FP) sKsum[tid] = ks0;
+  }
 
   // one 16-byte piece of each tensor per thread and chunk; prefetched one chunk ahead
   const int sr = tid >> 3, sc = tid & 7;        // staging row, 8-element column chunk
@@ -432,8 +489,8 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   bu4 pq, pk, pv, pp;
   auto issue_loads = [&](int t0n) {
     const int t = t0n + sr;
-    const bool ok = t < p.T;
-    pq = __builtin_amdgcn_raw_buffer_load_b128(rq, ok ? (int)((t * p.qs[2] + sc * 8) * 2) : (int)OOB, 0, 0);
+    const bool ok = t < t_end;
+    pq = __builtin_amdgcn_raw_buffer_load_b128(rq, (ok && !STATE_ONLY) ? (int)((t * p.qs[2] + sc * 8) * 2) : (int)OOB, 0, 0);
     pk = __builtin_amdgcn_raw_buffer_load_b128(rk, ok ? (int)((t * p.ks[2] + sc * 8) * 2) : (int)OOB, 0, 0);
     pv = __builtin_amdgcn_raw_buffer_load_b128(rv, ok ? (int)((t * p.vs[2] + sc * 8) * 2) : (int)OOB, 0, 0);
     pp = __builtin_amdgcn_raw_buffer_load_b128(rp, ok ? (int)((t * p.pos_stride + sc * 8) * 2) : (int)OOB, 0, 0);
@@ -441,7 +498,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 #ifdef SEA_STAMP
   unsigned long long _tprev = __builtin_amdgcn_s_memtime();
 #endif
-  issue_loads(0);
+  issue_loads(t_begin);
   // the result tile of a chunk leaves LDS as 16-byte row pieces at the START of the next chunk, i.e. before that
   // chunk's prefetch loads are issued: a wait for those loads never has younger stores in front of it
   auto flush_out = [&](int t0p, int rowsp) {
@@ -462,7 +519,6 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 
   // cumulative average of v (step K's input) on the waves that own the v columns: prefix sum over the chunk rows =
   // tril(ones) . V on the matrix cores (1.0 and v are exact in bf16, fp32 accumulation) + the running column sum
-  float csum = 0.f;
   auto tril_frag = [&](int ib, int ks) {
     unsigned short o[8];
 #pragma unroll
@@ -478,21 +534,21 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 #pragma unroll
     for (int ks = 0; ks < C / 32; ++ks) tril[ib][ks] = tril_frag(ib, ks);
 
-  for (int t0 = 0; t0 < p.T; t0 += C) {
-    const int rows = min(C, p.T - t0);
+  for (int t0 = t_begin; t0 < t_end; t0 += C) {
+    const int rows = min(C, t_end - t0);
     // ---- (a) staging ---------------------------------------------------------------------------------
-    if (SEA_EXP != 32 && SEA_EXP != 31) __builtin_amdgcn_raw_buffer_store_b128(pv, ro, sr < rows ? ((t0 + sr) * (3 * D) + 2 * D + sc * 8) * 2 : (int)OOB, 0, 0);
+    if (!STATE_ONLY && SEA_EXP != 32 && SEA_EXP != 31) __builtin_amdgcn_raw_buffer_store_b128(pv, ro, sr < rows ? ((t0 + sr) * (3 * D) + 2 * D + sc * 8) * 2 : (int)OOB, 0, 0);
     *reinterpret_cast<bu4*>(sQ + (sc * C + sr) * 8) = pq;
     *reinterpret_cast<bu4*>(sK + (sc * C + sr) * 8) = pk;
     *reinterpret_cast<bu4*>(sV + sr * E + vchunk(sr, sc) * 8) = pp;
     *reinterpret_cast<bu4*>(sV + sr * E + vchunk(sr, D / 8 + sc) * 8) = pv;
-    if (t0 > 0 && SEA_EXP != 31) flush_out(t0 - C, C);      // (block-uniform)
+    if (!STATE_ONLY && t0 > t_begin && SEA_EXP != 31) flush_out(t0 - C, C);      // (block-uniform)
     if (SEA_EXP != 33) issue_loads(t0 + C);                                   // rows beyond T come back as zeros
     __syncthreads();
     PSTAMP(0);   // (a) staging
 
     // ---- (b) feature maps, transposed: X^T[f][t] = sum_d W[f][d] x[t][d]; wave = (Q | K, row block) ----------
-    {
+    if (!STATE_ONLY || wv >= RB) {                           // the state-only pass needs phi(K) alone (wave-uniform)
       const int which = wv / RB, rb = wv - which * RB;
       const unsigned short* src = which ? sK : sQ;
       f4 acc[NBT];
@@ -532,6 +588,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
     PSTAMP(1);   // (b) feature maps
 
     // ---- (c) A^T tiles (lower triangle), denominator and k-sum partials ------------------------------------
+    if constexpr (!STATE_ONLY)
     for (int tile = wv; tile < RB * (RB + 1) / 2; tile += NW) {
       int ib = 0, rem = tile;
       while (rem > ib) { rem -= ib + 1; ++ib; }              // tile -> (query block ib, key block jb <= ib)
@@ -568,6 +625,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
       const int row = tid & (C - 1), part = tid / C;         // 8 parts x (FP/8) positions
       constexpr int PER = FP / (NTH / C);
       float s = 0.f;
+      if constexpr (!STATE_ONLY)
 #pragma unroll
       for (int g4 = 0; g4 < PER / 4; ++g4) {
         const int f = part * PER + g4 * 4;
@@ -639,6 +697,14 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
           vf[ks] = cat8(a, b);
         }
       }
+      if constexpr (STATE_ONLY) {
+        if (want_avg && jb >= EB / 2) {                    // column total of the chunk = the last row's prefix
+          f4 cum = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks <= (RB - 1) / 2; ++ks) cum = S16<T>::mfma(tril[RB - 1][ks], vf[ks], cum);
+          csum += __shfl(cum[3], 48 + li);
+        }
+      } else {
       f4 o[RB];
 #pragma unroll
       for (int ib = 0; ib < RB; ++ib) o[ib] = f4{0.f, 0.f, 0.f, 0.f};
@@ -700,6 +766,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
           }
         csum += __shfl(cum[RB - 1][3], 48 + li);           // column total of the chunk = its last row's prefix
       }
+      }
       // (e) S[f][e] += sum_s phi(k_s)[f] V[s][e]: A operand = phi(K)^T by transposing reads of the row-major images
       {
         const int q = li >> 2, pp_ = li & 3;
@@ -720,9 +787,17 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
     __syncthreads();
     PSTAMP(3);   // (d)+(e)
   }
-  {
-    const int t0l = ((p.T - 1) / C) * C;
-    flush_out(t0l, p.T - t0l);
+  if constexpr (STATE_ONLY) {
+    float* cw = p.carry + ((int64_t)nh * (p.nseg - 1) + seg) * CARRY;
+#pragma unroll
+    for (int b = 0; b < NBT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cw[(b * 4 + r) * NTH + tid] = S[b][r];
+    if (tid < FP) cw[NBT * 4 * NTH + tid] = sKsum[tid];
+    cw[NBT * 4 * NTH + FP + tid] = csum;
+  } else {
+    const int t0l = t_begin + ((t_end - t_begin - 1) / C) * C;
+    flush_out(t0l, t_end - t0l);
   }
 }
 
@@ -738,12 +813,20 @@ static int launch_perf(const PerfParams& p, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool configured = false;   // one per template instantiation; the attribute call is a slow driver round trip
   if (lds > 64 * 1024 && !configured) {
-    (void)hipFuncSetAttribute((const void*)performer_kernel<T, D, NBT, C, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)performer_kernel<T, D, NBT, C, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)performer_kernel<T, D, NBT, C, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     configured = true;
   }
-  hipLaunchKernelGGL((performer_kernel<T, D, NBT, C, NW>), dim3((unsigned)(p.N * p.H)), dim3(NW * 64), lds, s, p);
+  if (p.seg_len % C != 0) return SEA_EINVAL;
+  if (p.nseg > 1)
+    hipLaunchKernelGGL((performer_kernel<T, D, NBT, C, NW, true>), dim3((unsigned)(p.N * p.H), (unsigned)(p.nseg - 1)), dim3(NW * 64), lds, s, p);
+  hipLaunchKernelGGL((performer_kernel<T, D, NBT, C, NW, false>), dim3((unsigned)(p.N * p.H), (unsigned)p.nseg), dim3(NW * 64), lds, s, p);
   return SEA_OK;
 }
+
+// floats of carry per (n, h, segment) of the fp32 kernel: the per-thread state registers + the k-sum
+template <int D, int NBT, int NW = 8>
+constexpr int64_t perf_carry_floats() { return (int64_t)(((2 * D / 16) + NW - 1) / NW) * NBT * 4 * NW * 64 + NBT * 16; }
 
 template <typename T, int NBT>
 static int launch_perf_bf16(const PerfParams& p, hipStream_t s) {
@@ -753,12 +836,19 @@ static int launch_perf_bf16(const PerfParams& p, hipStream_t s) {
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute((const void*)performer_bf16_kernel<T, NBT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)performer_bf16_kernel<T, NBT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)performer_bf16_kernel<T, NBT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     configured = true;
   }
-  hipLaunchKernelGGL((performer_bf16_kernel<T, NBT>), dim3((unsigned)(p.N * p.H)), dim3(NTH), lds, s, p);
+  if (p.seg_len % C != 0) return SEA_EINVAL;
+  if (p.nseg > 1)
+    hipLaunchKernelGGL((performer_bf16_kernel<T, NBT, true>), dim3((unsigned)(p.N * p.H), (unsigned)(p.nseg - 1)), dim3(NTH), lds, s, p);
+  hipLaunchKernelGGL((performer_bf16_kernel<T, NBT, false>), dim3((unsigned)(p.N * p.H), (unsigned)p.nseg), dim3(NTH), lds, s, p);
   return SEA_OK;
 }
+
+template <int NBT>
+constexpr int64_t perf_bf16_carry_floats() { return (int64_t)NBT * 4 * 512 + ((NBT + 1) / 2) * 32 + 512; }
 
 // SEA_PERFORMER_FP32=1 keeps bf16 data on the fp32-MFMA kernel (A/B timing, parity debugging)
 static bool perf_force_fp32() {
@@ -791,11 +881,54 @@ extern "C" int sea_debug_perf_stamps(unsigned long long* host8) {
 }
 #endif
 
-extern "C" int sea_performer_causal(const void* q, const void* k, const void* v, const void* pos, int dtype,
-                                    const float* proj, int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb,
-                                    const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
-                                    int64_t pos_stride, void* out, void* avg_out, sea_stream_t stream) {
-  const char* nm = "sea_performer_causal";
+// carry floats per (n, h, segment) of the kernel dispatch_perf picks (0: unsupported shape)
+static int64_t perf_carry_floats_for(int dtype, int D, int nbt) {
+  if (dtype != SEA_F32 && D == 64 && !perf_force_fp32()) {
+    if (nbt <= 3) return perf_bf16_carry_floats<3>();
+    if (nbt <= 5) return perf_bf16_carry_floats<5>();
+  }
+  if (D == 64 && nbt <= 3) return perf_carry_floats<64, 3>();
+  if (D == 64 && nbt <= 5) return perf_carry_floats<64, 5>();
+  if (D == 80 && nbt <= 3) return perf_carry_floats<80, 3>();
+  if (D == 80 && nbt <= 5) return perf_carry_floats<80, 5>();
+  if (D == 128 && nbt <= 5) return perf_carry_floats<128, 5>();
+  return 0;
+}
+
+// rows per segment: whole 64-row chunks (a multiple of every kernel's chunk size), segments as even as possible
+static int64_t perf_seg_len(int64_t T, int64_t nseg) {
+  const int64_t chunks = (T + 63) / 64;
+  return ((chunks + nseg - 1) / nseg) * 64;
+}
+
+extern "C" int sea_performer_plan(int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb, int dtype,
+                                  int64_t* n_segments, int64_t* workspace_bytes) {
+  const char* nm = "sea_performer_plan";
+  SEA_REQUIRE(n_segments && workspace_bytes, SEA_EINVAL, "%s: null pointer", nm);
+  SEA_REQUIRE(N > 0 && H > 0 && T > 0 && D > 0 && nb > 0, SEA_EINVAL, "%s: bad shape", nm);
+  const int64_t cf = perf_carry_floats_for(dtype, (int)D, (int)((nb + 15) / 16));
+  SEA_REQUIRE(cf > 0, SEA_EUNSUPPORTED, "%s: unsupported head size D=%lld / feature count nb=%lld", nm, (long long)D, (long long)nb);
+  // One workgroup walks one (n, h) pair's rows in order; with fewer pairs than compute units the rows are cut into
+  // segments (pass 1 re-does the phi(K) / state part of all but the last: ~1/3 extra work for nseg x the parallelism).
+  const int64_t pairs = N * H, chunks = (T + 63) / 64;
+  int64_t nseg = 1;
+  if (pairs <= 128 && chunks >= 8) {
+    nseg = 256 / pairs;                                      // all workgroups of a pass resident at once (1 per CU: LDS)
+    if (nseg > chunks / 4) nseg = chunks / 4;
+    if (nseg > 16) nseg = 16;
+    const int64_t len = perf_seg_len(T, nseg);
+    nseg = (T + len - 1) / len;                              // no empty segment
+  }
+  *n_segments = nseg;
+  *workspace_bytes = pairs * (nseg - 1) * cf * (int64_t)sizeof(float);
+  return SEA_OK;
+}
+
+static int perf_entry(const char* nm, const void* q, const void* k, const void* v, const void* pos, int dtype,
+                      const float* proj, int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb,
+                      const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                      int64_t pos_stride, void* out, void* avg_out, int64_t n_segments, void* workspace,
+                      int64_t workspace_bytes, sea_stream_t stream) {
   SEA_REQUIRE(q && k && v && pos && proj && out && q_strides && k_strides && v_strides, SEA_EINVAL, "%s: null pointer", nm);
   SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_F16 || dtype == SEA_BF16, SEA_EINVAL, "%s: bad dtype %d", nm, dtype);
   SEA_REQUIRE(N > 0 && H > 0 && T > 0 && D > 0 && nb > 0, SEA_EINVAL, "%s: bad shape", nm);
@@ -812,6 +945,17 @@ extern "C" int sea_performer_causal(const void* q, const void* k, const void* v,
   p.pos_stride = pos_stride;
   p.N = (int)N; p.H = (int)H; p.T = (int)T; p.nb = (int)nb;
   const int nbt = (int)((nb + 15) / 16);
+  SEA_REQUIRE(n_segments >= 1 && n_segments <= 64, SEA_EINVAL, "%s: n_segments %lld outside 1..64", nm, (long long)n_segments);
+  p.nseg = (int)n_segments;
+  p.seg_len = (int)perf_seg_len(T, n_segments);
+  p.carry = reinterpret_cast<float*>(workspace);
+  if (n_segments > 1) {
+    SEA_REQUIRE((n_segments - 1) * (int64_t)p.seg_len < T, SEA_EINVAL, "%s: %lld segments leave one empty at T=%lld (use sea_performer_plan)",
+                nm, (long long)n_segments, (long long)T);
+    const int64_t need = N * H * (n_segments - 1) * perf_carry_floats_for(dtype, (int)D, nbt) * (int64_t)sizeof(float);
+    SEA_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= need, SEA_EINVAL,
+                "%s: workspace of %lld bytes needed (16-byte aligned), got %lld", nm, (long long)need, (long long)workspace_bytes);
+  }
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (dtype == SEA_F32) rc = dispatch_perf<float>(p, (int)D, nbt, s);
@@ -820,4 +964,21 @@ extern "C" int sea_performer_causal(const void* q, const void* k, const void* v,
   SEA_REQUIRE(rc == SEA_OK, rc, "%s: unsupported head size D=%lld / feature count nb=%lld", nm, (long long)D, (long long)nb);
   SEA_CHECK_LAUNCH(nm);
   return SEA_OK;
+}
+
+extern "C" int sea_performer_causal(const void* q, const void* k, const void* v, const void* pos, int dtype,
+                                    const float* proj, int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb,
+                                    const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                                    int64_t pos_stride, void* out, void* avg_out, sea_stream_t stream) {
+  return perf_entry("sea_performer_causal", q, k, v, pos, dtype, proj, N, H, T, D, nb, q_strides, k_strides, v_strides,
+                    pos_stride, out, avg_out, 1, nullptr, 0, stream);
+}
+
+extern "C" int sea_performer_causal_segmented(const void* q, const void* k, const void* v, const void* pos, int dtype,
+                                              const float* proj, int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb,
+                                              const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                                              int64_t pos_stride, void* out, void* avg_out, int64_t n_segments,
+                                              void* workspace, int64_t workspace_bytes, sea_stream_t stream) {
+  return perf_entry("sea_performer_causal_segmented", q, k, v, pos, dtype, proj, N, H, T, D, nb, q_strides, k_strides,
+                    v_strides, pos_stride, out, avg_out, n_segments, workspace, workspace_bytes, stream);
 }

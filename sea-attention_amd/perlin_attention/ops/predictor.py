@@ -169,12 +169,28 @@ def performer_avg_supported(q: torch.Tensor, nb: int) -> bool:
     return q.dtype in (torch.bfloat16, torch.float16) and q.shape[-1] == 64 and (nb + 15) // 16 <= 5
 
 
+_PLAN_CACHE = {}
+
+
+def performer_plan(N: int, H: int, T: int, D: int, nb: int, dtype) -> tuple:
+    """(n_segments, workspace_bytes) the library proposes for a shape (`sea_performer_plan`): 1 segment when N*H
+    workgroups already fill the chip, else the rows are cut so that about 256 workgroups run."""
+    key = (N, H, T, D, nb, dtype)
+    if key not in _PLAN_CACHE:
+        import ctypes
+        nseg, ws = (ctypes.c_int64 * 1)(), (ctypes.c_int64 * 1)()
+        _lib.check(_lib.load().sea_performer_plan(N, H, T, D, nb, _lib.dtype_code(dtype), nseg, ws), "sea_performer_plan")
+        _PLAN_CACHE[key] = (int(nseg[0]), int(ws[0]))
+    return _PLAN_CACHE[key]
+
+
 def performer_value(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torch.Tensor,
-                    projection: torch.Tensor, want_avg: bool = False):
-    """Causal Performer estimator + both concatenations in one launch.
+                    projection: torch.Tensor, want_avg: bool = False, n_segments: int = None):
+    """Causal Performer estimator + both concatenations (one launch; two when the rows are cut into segments).
     q,k,v (N,H,T,D); pos (>=T, D) = v_eye_learned_causal[0,0]; projection (nb, D).
     Returns performer_value (N,H,T,3D) = [ctx(pos) | ctx(v) | v] in q's dtype; with want_avg (see
-    performer_avg_supported) also the cumulative average of v, (N,H,T,D) -- the `cumavg` of step K."""
+    performer_avg_supported) also the cumulative average of v, (N,H,T,D) -- the `cumavg` of step K.
+    n_segments: None = the library's plan for the shape; 1 = the single sequential pass."""
     lib = _lib.load()
     _lib.require_gpu(q, k, v, pos, projection)
     N, H, T, D = q.shape
@@ -192,9 +208,16 @@ def performer_value(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torc
     if want_avg:
         assert performer_avg_supported(q, nb)
         avg = torch.empty((N, H, T, D), dtype=q.dtype, device=q.device)
-    _lib.check(lib.sea_performer_causal(_p(q), _p(k), _p(v), _p(pos), _lib.dtype_code(q.dtype), _p(proj), N, H, T, D, nb,
-                                        _lib.strides3(q), _lib.strides3(k), _lib.strides3(v), pos.stride(0), _p(out),
-                                        _p(avg), _lib.stream_ptr()), "sea_performer_causal")
+    nseg, ws_bytes = performer_plan(N, H, T, D, nb, q.dtype)
+    if n_segments is not None and n_segments != nseg:                 # caller's choice (tests, A/B timing)
+        nseg = int(n_segments)
+        one_pair = performer_plan(1, 1, 4096, D, nb, q.dtype)         # a shape the plan always cuts: bytes per (pair, segment)
+        ws_bytes = N * H * (nseg - 1) * (one_pair[1] // (one_pair[0] - 1))
+    ws = torch.empty((max(ws_bytes, 16),), dtype=torch.uint8, device=q.device) if nseg > 1 else None
+    _lib.check(lib.sea_performer_causal_segmented(
+        _p(q), _p(k), _p(v), _p(pos), _lib.dtype_code(q.dtype), _p(proj), N, H, T, D, nb, _lib.strides3(q), _lib.strides3(k),
+        _lib.strides3(v), pos.stride(0), _p(out), _p(avg), nseg, _p(ws), ws_bytes, _lib.stream_ptr()),
+        "sea_performer_causal_segmented")
     return (out, avg) if want_avg else out
 
 

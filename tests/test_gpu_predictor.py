@@ -367,3 +367,48 @@ def test_performer_emits_cumulative_average(ops, N, H, T):
     ca = ops.cumavg(v).float()
     assert ((avg.float() - ca).abs() <= ca.abs() * 2.0 ** -7 + 1e-6).all()
     assert (avg.float() != ca).float().mean().item() < 0.01
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,N,H,T,D,nbf", [
+    (torch.bfloat16, 1, 4, 1024, 64, 8),     # split-bf16 kernel, plan cuts (4 pairs)
+    (torch.float16, 1, 3, 777, 64, 8),       # ragged last segment / last chunk
+    (torch.bfloat16, 1, 4, 1024, 128, 8),    # fp32-MFMA kernel, 32-row chunks
+    (torch.bfloat16, 2, 2, 640, 80, 8),
+    (torch.float32, 1, 2, 900, 64, 8),
+])
+def test_performer_sequence_parallel_equals_sequential(ops, dtype, N, H, T, D, nbf):
+    """`sea_performer_causal_segmented`: cutting the rows into segments (two launches, carried state) gives the rows of
+    the one-pass kernel up to fp32 summation order -- i.e. at most one rounding step of the output dtype apart on a
+    small fraction of the elements -- for the plan's choice and for forced 2 / 4 segments; the copy of v stays exact."""
+    import math
+    from sea_attention_amd.perlin_attention.performer import FastAttention
+    from sea_attention_amd.perlin_attention.ops import predictor as PR
+    torch.manual_seed(21)
+    nb = int(D * math.log(D) / nbf)
+    fa = FastAttention(D, nb_features=nb, causal=True, generalized_attention=True).to(DEV)
+    q = (torch.randn(N, H, T, D, device=DEV) * D ** -0.5).to(dtype); k = torch.randn(N, H, T, D, device=DEV).to(dtype)
+    v = torch.randn(N, H, T, D, device=DEV).to(dtype); pos = torch.randn(T, D, device=DEV).to(dtype)
+    plan = PR.performer_plan(N, H, T, D, nb, dtype)
+    assert plan[0] > 1 and plan[1] > 0                               # few pairs: the plan cuts
+    assert PR.performer_plan(64, 8, T, D, nb, dtype) == (1, 0)       # many pairs: it does not
+    want_avg = PR.performer_avg_supported(q, nb)
+    seq = ops.performer_value(q, k, v, pos, fa.projection_matrix, want_avg=want_avg, n_segments=1)
+    eps = {torch.bfloat16: 2.0 ** -7, torch.float16: 2.0 ** -10, torch.float32: 2.0 ** -18}[dtype]
+    for nseg in (None, 2, 4):
+        got = ops.performer_value(q, k, v, pos, fa.projection_matrix, want_avg=want_avg, n_segments=nseg)
+        pairs = [(got[0], seq[0]), (got[1], seq[1])] if want_avg else [(got, seq)]
+        for g, s in pairs:
+            g, s = g.float(), s.float()
+            assert torch.isfinite(g).all()
+            assert ((g - s).abs() <= s.abs() * eps + 1e-6).all(), (nseg, (g - s).abs().max().item())
+            if dtype != torch.float32:
+                assert (g != s).float().mean().item() < 0.02, nseg
+        main = got[0] if want_avg else got
+        assert torch.equal(main[..., 2 * D:], v)
+    # reproducible run to run (the carried increments are added in segment order)
+    a = ops.performer_value(q, k, v, pos, fa.projection_matrix, n_segments=4)
+    b = ops.performer_value(q, k, v, pos, fa.projection_matrix, n_segments=4)
+    assert torch.equal(a, b)
+    with pytest.raises(RuntimeError, match="empty"):                 # a cut that would leave a segment without rows
+        ops.performer_value(q, k, v, pos, fa.projection_matrix, n_segments=(T + 63) // 64 + 1)
