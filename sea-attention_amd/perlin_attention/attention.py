@@ -606,14 +606,43 @@ class PerlinAttention(nn.Module):
                 v_new = v[..., sl, :]
                 performer_value = torch.cat([performer_context_layer, v_new], dim=-1)
             # ---- D-G: predictor MLP, windowed CNN, softmax ---------------------------------------------------------
-            with timer("predictor"):
-                t_attention_predictor = self.attention_predictor_enc(performer_value)
-                x = self.attention_predictor_dec_row(t_attention_predictor)
-                cs = state.get(PerlinAttentionState.CNN, CnnWindowState)
-                cs, estimated_attention_score = cs.step(self.attention_predictor_cnn, x)
-                state.states[PerlinAttentionState.CNN] = cs
-                estimated_attention_probs = torch.softmax(estimated_attention_score.float(), dim=-1) \
-                    .to(estimated_attention_score.dtype).contiguous()
+            cs = state.get(PerlinAttentionState.CNN, CnnWindowState)
+            gates = None
+            if cs.rows is None and self._fused_mlp_ok(performer_value):
+                # the stateless path's kernels on the new rows: one-launch MLP (its output is the CNN input AFTER
+                # lnorm1, channel-blocked), the two MFMA convolutions over [cached window | new rows] (rows before the
+                # window read as zero padding; its LOOKBACK rows cover the convolutions' reach), tail on the new rows
+                with timer("predictor"):
+                    x, t_attention_predictor, row_scale_, avg_scale_ = ops.predictor_mlp(
+                        performer_value, self.attention_predictor_enc[0], self.attention_predictor_enc[1],
+                        self.attention_predictor_dec_row[0], self.attention_predictor_cnn[0].module,
+                        self.attention_predictor_dec_scaler[0], want_tpred=False)
+                    gates = (row_scale_, avg_scale_)
+                    xs = x if cs.rows_c8 is None else torch.cat([cs.rows_c8, x], dim=1)      # (N, rows, C/8, W, 8)
+                    new_cs = CnnWindowState(cs.lookback)
+                    new_cs.rows_c8 = xs[:, -cs.lookback:]
+                    state.states[PerlinAttentionState.CNN] = new_cs
+                    keepres, ln2 = self.attention_predictor_cnn[1].module, self.attention_predictor_cnn[2].module
+                    body = list(keepres.net.children())
+                    y = xs
+                    for li_ in range(0, len(body) - 2, 2):
+                        conv = body[li_].module
+                        y = ops.causal_conv_c8(y, conv.weight, conv.bias, conv.kernel_size, conv.dilation,
+                                               conv.padding[1], relu=True)
+                    conv4 = body[-1].module
+                    estimated_attention_probs, _ = ops.predictor_tail(
+                        y[:, -T_DST:].contiguous(), conv4.weight[:, :, 0, 0], conv4.bias, ln2.weight, ln2.bias, up=4, T_m=T_M,
+                        eps=ln2.eps, want_scores=False)
+            else:
+                assert cs.rows_c8 is None, "this state's CNN window was written by the HIP estimator (16-bit inference); " \
+                                           "keep dtype / mode fixed while decoding from it"
+                with timer("predictor"):
+                    t_attention_predictor = self.attention_predictor_enc(performer_value)
+                    x = self.attention_predictor_dec_row(t_attention_predictor)
+                    cs, estimated_attention_score = cs.step(self.attention_predictor_cnn, x)
+                    state.states[PerlinAttentionState.CNN] = cs
+                    estimated_attention_probs = torch.softmax(estimated_attention_score.float(), dim=-1) \
+                        .to(estimated_attention_score.dtype).contiguous()
             # ---- H-I: grouped top-k of the new rows (their absolute widths), interpolation to flat CSR -------------
             with timer("interp"):
                 # K_t of the new rows only (absolute positions T_SRC-T_DST+1 .. T_SRC), same fp32 expression as
@@ -626,9 +655,13 @@ class PerlinAttention(nn.Module):
                                          target_width=T_SRC, is_causal=True, z_cap=z_cap)
             # ---- J-L: gates, cumulative average (carried), fused sparse attention ----------------------------------
             with timer("attention"):
-                sig = torch.sigmoid(self.attention_predictor_dec_scaler(t_attention_predictor).float())
-                row_scale = sig[..., 0].contiguous() if self.pconfig.partial_attention_scaler else None
-                average_scale = sig[..., 1].contiguous()
+                if gates is not None:
+                    row_scale = gates[0] if self.pconfig.partial_attention_scaler else None
+                    average_scale = gates[1]
+                else:
+                    sig = torch.sigmoid(self.attention_predictor_dec_scaler(t_attention_predictor).float())
+                    row_scale = sig[..., 0].contiguous() if self.pconfig.partial_attention_scaler else None
+                    average_scale = sig[..., 1].contiguous()
                 cav = state.get(PerlinAttentionState.CUMAVG, CumAvgState)
                 cav, average_context_layer = cav.step(v_new)
                 state.states[PerlinAttentionState.CUMAVG] = cav

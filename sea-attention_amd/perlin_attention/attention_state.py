@@ -53,6 +53,9 @@ class CnnWindowState:
     def __init__(self, lookback: int = LOOKBACK):
         self.lookback = lookback
         self.rows: Optional[torch.Tensor] = None   # (N, C, <=lookback, W) trailing rows of the CNN input
+        # HIP estimator (16-bit inference): the same window AFTER the CNN's first LayerNorm, channel-blocked
+        # (N, <=lookback, C/8, W, 8), as the one-launch predictor MLP emits it; exactly one of the two is set
+        self.rows_c8: Optional[torch.Tensor] = None
 
     def step(self, cnn, x: torch.Tensor):
         """x (N, C, T_new, W): the CNN input rows of the new tokens.  Returns (new_state, y (N, C', T_new, W'))."""

@@ -99,3 +99,50 @@ def test_cached_call_checks_its_bookkeeping():
     x = torch.randn((1, 4, 20, 32), device=DEV)
     with torch.no_grad(), pytest.raises(AssertionError):    # 4 new rows on top of an EMPTY state cannot cover 20 keys
         cached(None, None, None, query_layer=x[:, :, -4:], key_layer=x, value_layer=x, attention_mask=_mask(1, 4, 20, torch.float32))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,T,T_M,k,T0,chunks", [(2, 4, 400, 128, 16, 300, (1, 1, 1, 7, 30, 60)),
+                                                   (1, 8, 330, 256, 32, 1, (1, 2, 6, 20, 300))])
+def test_cached_decoding_on_the_hip_estimator(dtype, N, H, T, T_M, k, T0, chunks):
+    """16-bit inference with d = 64: the cached path runs the stateless path's own estimator kernels on the new rows
+    (one-launch MLP, MFMA convolutions over [8-row window | new rows], tail), so MLP / CNN / softmax round exactly as in
+    the stateless forward; only the Performer differs (float64 running sums in torch vs the one-pass MFMA kernel).
+    The window state is the channel-blocked post-LayerNorm tensor; rows match the stateless forward."""
+    d = 64
+    assert T0 + sum(chunks) == T
+    full = _layer(H, d, T_M, k, T + 1, dtype, use_cache=False)
+    cached = _layer(H, d, T_M, k, T + 1, dtype, use_cache=True)
+    full.attention.force_torch_estimator = cached.attention.force_torch_estimator = False
+    cached.load_state_dict(full.state_dict())
+    S.seed(9)
+    x = torch.randn((N, H, T, d), device=DEV).to(dtype)
+    q = (x.float() * d ** -0.5).to(dtype)
+    with torch.no_grad():
+        ref = full(None, None, None, query_layer=q, key_layer=x, value_layer=x, attention_mask=_mask(N, T, T, dtype)).context_layer.float()
+        state, got, pos = None, [], 0
+        for step in (T0,) + tuple(chunks):
+            hi = pos + step
+            out = cached(None, None, None, query_layer=q[:, :, pos:hi], key_layer=x[:, :, :hi], value_layer=x[:, :, :hi],
+                         attention_mask=_mask(N, step, hi, dtype), last_state=state)
+            state = out.state
+            win = state.states[PerlinAttentionState.CNN]
+            assert win.rows is None and win.rows_c8 is not None and win.rows_c8.shape[1] == min(hi, CnnWindowState.LOOKBACK)
+            assert win.rows_c8.shape[2:] == (2 * H // 8, T_M // 4, 8)
+            got.append(out.context_layer.float())
+            pos = hi
+    got = torch.cat(got, dim=1)
+    err = (got - ref).abs().amax(-1)
+    scale = ref.abs().amax(-1).clamp_min(1.0)
+    bad = (err > 3e-2 * scale).float().mean().item()
+    rel = ((got - ref).norm() / ref.norm()).item()
+    print(f"hip-estimator decode {dtype} T_M={T_M}: rows off {bad:.3f}, rel {rel:.4f}")
+    # measured: bf16 rel 0.017-0.032 / rows off <= 0.08, fp16 rel <= 0.004 / rows off <= 0.01 (the torch-estimator path
+    # in bf16 sits at rel ~0.1: there MLP / CNN round differently on the two sides as well)
+    lim_rel, lim_bad = (0.08, 0.2) if dtype == torch.bfloat16 else (0.03, 0.05)
+    assert rel < lim_rel and bad < lim_bad, (bad, rel, err.max().item())
+    # a state written by the HIP estimator cannot continue on the torch estimator (different window contents)
+    cached.attention.force_torch_estimator = True
+    with torch.no_grad(), pytest.raises(AssertionError, match="HIP estimator"):
+        cached(None, None, None, query_layer=q[:, :, -1:], key_layer=torch.cat([x, x[:, :, -1:]], 2), value_layer=torch.cat([x, x[:, :, -1:]], 2),
+               attention_mask=_mask(N, 1, T + 1, dtype), last_state=state)
