@@ -273,6 +273,24 @@ int sea_performer_causal_segmented(const void* q, const void* k, const void* v, 
                                    int64_t pos_stride, void* out, void* avg_out, int64_t n_segments,
                                    void* workspace, int64_t workspace_bytes, sea_stream_t stream);
 
+/* Stateful form of the causal Performer for kv-cache decoding (role of the reference's StatefulCausalPerformer,
+ * attention_state.py:43-140, called from attention.py:559-566 when pconfig.use_cache): the T rows handed in CONTINUE a
+ * sequence of which t_base rows have been seen.  state_in (NULL for t_base = 0) / state_out (NULL: not wanted) are
+ * opaque images of sea_performer_state_bytes(N,H,D,nb,dtype) bytes holding, per (n,h), the running sums
+ * sum phi(k)^T [pos|v], sum phi(k) and sum v in FP32 -- the kernel's own accumulators, so decoding continues the very
+ * sums the one-pass kernel would have formed (the reference keeps them in FP64 on the torch side).  q,k,v bring the
+ * NEW rows only; pos points at the value embedding's row t_base.  avg_out as in sea_performer_causal (its divisor
+ * uses the absolute row index); pass it whenever the state is to carry the column sums of v (16-bit kernel).
+ * state_in and state_out may alias when n_segments = 1.  n_segments / workspace as in sea_performer_causal_segmented (1 / NULL for the
+ * few rows of a decode step; a prefill may cut). */
+int64_t sea_performer_state_bytes(int64_t N, int64_t H, int64_t D, int64_t nb, int dtype);
+int sea_performer_causal_step(const void* q, const void* k, const void* v, const void* pos, int dtype,
+                              const float* proj, int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb,
+                              const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                              int64_t pos_stride, void* out, void* avg_out, const void* state_in, void* state_out,
+                              int64_t state_bytes, int64_t t_base, int64_t n_segments, void* workspace,
+                              int64_t workspace_bytes, sea_stream_t stream);
+
 /* Algorithmic bytes of one sea_sparse_attention launch:
  * Z*(2*D*s + 4) + N*H*T_dst*(2*D*s + 4).  Host-side helper, no device work. */
 int64_t sea_sparse_attention_bytes(int64_t Z, int64_t N, int64_t H, int64_t T_dst, int64_t D, int elem_bytes);

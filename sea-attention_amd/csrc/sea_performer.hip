@@ -49,6 +49,12 @@ struct PerfParams {
   // pass 2 (grid.y = nseg) starts each segment from the sum of the increments before it.  nseg = 1: one pass.
   float* carry;
   int nseg, seg_len;
+  // stateful form (kv-cache decoding): the rows handed in continue a sequence.  state_in / state_out are per-(n,h)
+  // images in the carry format (state registers, k-sum, column sum of v); t_base = rows the state has already seen
+  // (only the cumulative average needs the absolute row index).  Either may be null.
+  const float* state_in;
+  float* state_out;
+  int t_base;
 };
 
 // NW = waves per workgroup (8: two per SIMD, so one wave's LDS/MFMA latency hides behind the other's issue)
@@ -104,6 +110,16 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
     for (int b = 0; b < NBT; ++b) S[a][b] = f4{0.f, 0.f, 0.f, 0.f};
   {
     float ks0 = 0.f;
+    if (!STATE_ONLY && p.state_in) {                       // increments of pass 1 do not include the incoming state
+      const float* cr = p.state_in + (int64_t)nh * CARRY;
+#pragma unroll
+      for (int a = 0; a < JB; ++a)
+#pragma unroll
+        for (int b = 0; b < NBT; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) S[a][b][r] = cr[((a * NBT + b) * 4 + r) * NTH + tid];
+      if (tid < NBP) ks0 = cr[JB * NBT * 4 * NTH + tid];
+    }
     if (!STATE_ONLY) {
       for (int s2 = 0; s2 < seg; ++s2) {
         const float* cr = p.carry + ((int64_t)nh * (p.nseg - 1) + s2) * CARRY;
@@ -326,6 +342,15 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) cw[((a * NBT + b) * 4 + r) * NTH + tid] = S[a][b][r];
     if (tid < NBP) cw[JB * NBT * 4 * NTH + tid] = sKsum[tid];
+  } else if (p.state_out && seg == p.nseg - 1) {           // the block that walked the last rows holds the final state
+    float* cw = p.state_out + (int64_t)nh * CARRY;
+#pragma unroll
+    for (int a = 0; a < JB; ++a)
+#pragma unroll
+      for (int b = 0; b < NBT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cw[((a * NBT + b) * 4 + r) * NTH + tid] = S[a][b][r];
+    if (tid < NBP) cw[JB * NBT * 4 * NTH + tid] = sKsum[tid];
   }
 }
 
@@ -457,6 +482,15 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   float csum = 0.f;                                        // running column sum of v (cumulative-average output)
   {
     float ks0 = 0.f;
+    if (!STATE_ONLY && p.state_in) {                       // increments of pass 1 do not include the incoming state
+      const float* cr = p.state_in + (int64_t)nh * CARRY;
+#pragma unroll
+      for (int b = 0; b < NBT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[b][r] = cr[(b * 4 + r) * NTH + tid];
+      if (tid < FP) ks0 = cr[NBT * 4 * NTH + tid];
+      csum = cr[NBT * 4 * NTH + FP + tid];
+    }
     if (!STATE_ONLY) {
       for (int s2 = 0; s2 < seg; ++s2) {                   // fixed order: bitwise reproducible
         const float* cr = p.carry + ((int64_t)nh * (p.nseg - 1) + s2) * CARRY;
@@ -671,7 +705,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 #pragma unroll
       for (int i = 0; i < DSL; ++i) s += sDenP[tid * DSL + i];
       sDen[tid] = 1.0f / s;                                  // the 16 column waves multiply by the reciprocal
-      sRinv[tid] = 1.0f / (float)(t0 + tid + 1);
+      sRinv[tid] = 1.0f / (float)(p.t_base + t0 + tid + 1);
     } else if (tid >= C && tid < C + FP) {
       const int f = tid - C;
       float s = sKsum[f];
@@ -798,6 +832,15 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   } else {
     const int t0l = t_begin + ((t_end - t_begin - 1) / C) * C;
     flush_out(t0l, t_end - t0l);
+    if (p.state_out && seg == p.nseg - 1) {                // the block that walked the last rows holds the final state
+      float* cw = p.state_out + (int64_t)nh * CARRY;
+#pragma unroll
+      for (int b = 0; b < NBT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cw[(b * 4 + r) * NTH + tid] = S[b][r];
+      if (tid < FP) cw[NBT * 4 * NTH + tid] = sKsum[tid];
+      cw[NBT * 4 * NTH + FP + tid] = csum;
+    }
   }
 }
 
@@ -928,7 +971,8 @@ static int perf_entry(const char* nm, const void* q, const void* k, const void* 
                       const float* proj, int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb,
                       const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                       int64_t pos_stride, void* out, void* avg_out, int64_t n_segments, void* workspace,
-                      int64_t workspace_bytes, sea_stream_t stream) {
+                      int64_t workspace_bytes, const void* state_in, void* state_out, int64_t state_bytes, int64_t t_base,
+                      sea_stream_t stream) {
   SEA_REQUIRE(q && k && v && pos && proj && out && q_strides && k_strides && v_strides, SEA_EINVAL, "%s: null pointer", nm);
   SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_F16 || dtype == SEA_BF16, SEA_EINVAL, "%s: bad dtype %d", nm, dtype);
   SEA_REQUIRE(N > 0 && H > 0 && T > 0 && D > 0 && nb > 0, SEA_EINVAL, "%s: bad shape", nm);
@@ -949,6 +993,16 @@ static int perf_entry(const char* nm, const void* q, const void* k, const void* 
   p.nseg = (int)n_segments;
   p.seg_len = (int)perf_seg_len(T, n_segments);
   p.carry = reinterpret_cast<float*>(workspace);
+  p.state_in = reinterpret_cast<const float*>(state_in);
+  p.state_out = reinterpret_cast<float*>(state_out);
+  p.t_base = (int)t_base;
+  if (state_in || state_out) {
+    const int64_t need = N * H * perf_carry_floats_for(dtype, (int)D, nbt) * (int64_t)sizeof(float);
+    SEA_REQUIRE(need > 0 && state_bytes >= need && ((((uintptr_t)state_in) | ((uintptr_t)state_out)) & 15) == 0 && t_base >= 0,
+                SEA_EINVAL, "%s: state images of %lld bytes needed (16-byte aligned), got %lld", nm, (long long)need, (long long)state_bytes);
+    SEA_REQUIRE(state_in != nullptr || t_base == 0, SEA_EINVAL, "%s: t_base %lld without state_in", nm, (long long)t_base);
+    SEA_REQUIRE(n_segments == 1 || state_in != state_out, SEA_EINVAL, "%s: state_in and state_out may alias only with one segment", nm);
+  }
   if (n_segments > 1) {
     SEA_REQUIRE((n_segments - 1) * (int64_t)p.seg_len < T, SEA_EINVAL, "%s: %lld segments leave one empty at T=%lld (use sea_performer_plan)",
                 nm, (long long)n_segments, (long long)T);
@@ -971,7 +1025,7 @@ extern "C" int sea_performer_causal(const void* q, const void* k, const void* v,
                                     const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                                     int64_t pos_stride, void* out, void* avg_out, sea_stream_t stream) {
   return perf_entry("sea_performer_causal", q, k, v, pos, dtype, proj, N, H, T, D, nb, q_strides, k_strides, v_strides,
-                    pos_stride, out, avg_out, 1, nullptr, 0, stream);
+                    pos_stride, out, avg_out, 1, nullptr, 0, nullptr, nullptr, 0, 0, stream);
 }
 
 extern "C" int sea_performer_causal_segmented(const void* q, const void* k, const void* v, const void* pos, int dtype,
@@ -980,5 +1034,21 @@ extern "C" int sea_performer_causal_segmented(const void* q, const void* k, cons
                                               int64_t pos_stride, void* out, void* avg_out, int64_t n_segments,
                                               void* workspace, int64_t workspace_bytes, sea_stream_t stream) {
   return perf_entry("sea_performer_causal_segmented", q, k, v, pos, dtype, proj, N, H, T, D, nb, q_strides, k_strides,
-                    v_strides, pos_stride, out, avg_out, n_segments, workspace, workspace_bytes, stream);
+                    v_strides, pos_stride, out, avg_out, n_segments, workspace, workspace_bytes, nullptr, nullptr, 0, 0, stream);
+}
+
+extern "C" int64_t sea_performer_state_bytes(int64_t N, int64_t H, int64_t D, int64_t nb, int dtype) {
+  if (N <= 0 || H <= 0 || D <= 0 || nb <= 0) return 0;
+  return N * H * perf_carry_floats_for(dtype, (int)D, (int)((nb + 15) / 16)) * (int64_t)sizeof(float);
+}
+
+extern "C" int sea_performer_causal_step(const void* q, const void* k, const void* v, const void* pos, int dtype,
+                                         const float* proj, int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb,
+                                         const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                                         int64_t pos_stride, void* out, void* avg_out, const void* state_in,
+                                         void* state_out, int64_t state_bytes, int64_t t_base, int64_t n_segments,
+                                         void* workspace, int64_t workspace_bytes, sea_stream_t stream) {
+  return perf_entry("sea_performer_causal_step", q, k, v, pos, dtype, proj, N, H, T, D, nb, q_strides, k_strides,
+                    v_strides, pos_stride, out, avg_out, n_segments, workspace, workspace_bytes, state_in, state_out,
+                    state_bytes, t_base, stream);
 }

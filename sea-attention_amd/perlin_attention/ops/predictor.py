@@ -221,6 +221,47 @@ def performer_value(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torc
     return (out, avg) if want_avg else out
 
 
+def performer_step(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torch.Tensor, projection: torch.Tensor,
+                   state_in: torch.Tensor = None, t_base: int = 0, want_avg: bool = True, n_segments: int = 1):
+    """Stateful causal Performer (`sea_performer_causal_step`): q,k,v (N,H,T_new,D) are the NEW rows of sequences
+    that have seen `t_base` rows, `state_in` the image a previous call returned (None at t_base = 0), pos the value
+    embedding's rows t_base .. t_base+T_new-1.  Returns (performer_value (N,H,T_new,3D), cumulative average of v for
+    the new rows or None, state_out).  Images are opaque fp32 tensors; a new one is returned (the input is kept)."""
+    lib = _lib.load()
+    _lib.require_gpu(q, k, v, pos, projection)
+    N, H, T, D = q.shape
+    assert k.shape == q.shape and v.shape == q.shape and pos.shape[-1] == D and pos.shape[0] >= T
+    nb = projection.shape[0]
+    q, k, v = (t if t.stride(-1) == 1 else t.contiguous() for t in (q, k, v))
+    k = k if k.dtype == q.dtype else k.to(q.dtype)
+    v = v if v.dtype == q.dtype else v.to(q.dtype)
+    pos = pos if pos.dtype == q.dtype else pos.to(q.dtype)
+    pos = pos if pos.stride(-1) == 1 else pos.contiguous()
+    assert pos.data_ptr() % 16 == 0, "value-embedding rows must start 16-byte aligned"
+    proj = _cached("proj", (projection,), q.dtype, lambda: projection.to(q.dtype).float().contiguous())
+    sb = int(lib.sea_performer_state_bytes(N, H, D, nb, _lib.dtype_code(q.dtype)))
+    assert sb > 0, "unsupported head size / feature count"
+    assert (state_in is None) == (t_base == 0), "a state image goes with the number of rows it has seen"
+    if state_in is not None:
+        assert state_in.dtype == torch.float32 and state_in.numel() * 4 == sb and state_in.is_contiguous()
+    state_out = torch.empty((sb // 4,), dtype=torch.float32, device=q.device)
+    out = torch.empty((N, H, T, 3 * D), dtype=q.dtype, device=q.device)
+    avg = None
+    if want_avg:
+        assert performer_avg_supported(q, nb)
+        avg = torch.empty((N, H, T, D), dtype=q.dtype, device=q.device)
+    ws, ws_bytes = None, 0
+    if n_segments > 1:
+        one_pair = performer_plan(1, 1, 4096, D, nb, q.dtype)
+        ws_bytes = N * H * (n_segments - 1) * (one_pair[1] // (one_pair[0] - 1))
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=q.device)
+    _lib.check(lib.sea_performer_causal_step(
+        _p(q), _p(k), _p(v), _p(pos), _lib.dtype_code(q.dtype), _p(proj), N, H, T, D, nb, _lib.strides3(q), _lib.strides3(k),
+        _lib.strides3(v), pos.stride(0), _p(out), _p(avg), _p(state_in), _p(state_out), sb, int(t_base), int(n_segments),
+        _p(ws), ws_bytes, _lib.stream_ptr()), "sea_performer_causal_step")
+    return out, avg, state_out
+
+
 def predictor_mlp_supported(D1: int, D2: int, H: int, Din: int) -> bool:
     """Shapes csrc/sea_mlp.hip is instantiated for (launch_mlp)."""
     return (D1, D2) in ((128, 128), (128, 64), (128, 256), (160, 128)) and H % 4 == 0 and Din % 8 == 0 and Din <= 256

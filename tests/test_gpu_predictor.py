@@ -412,3 +412,42 @@ def test_performer_sequence_parallel_equals_sequential(ops, dtype, N, H, T, D, n
     assert torch.equal(a, b)
     with pytest.raises(RuntimeError, match="empty"):                 # a cut that would leave a segment without rows
         ops.performer_value(q, k, v, pos, fa.projection_matrix, n_segments=(T + 63) // 64 + 1)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype,N,H,T,D", [(torch.bfloat16, 2, 4, 448, 64), (torch.float16, 1, 4, 300, 64)])
+def test_performer_step_continues_the_sequence(ops, dtype, N, H, T, D):
+    """`sea_performer_causal_step` (kv-cache decoding): feeding the rows in pieces with the carried state image gives
+    the rows -- and the cumulative average of v -- of the one-pass kernel.  Pieces that end on 64-row chunk boundaries
+    continue the very same fp32 sums (bitwise equal); single rows / ragged pieces regroup the in-chunk sums (one
+    rounding step of the output dtype on a small fraction of the elements)."""
+    import math
+    from sea_attention_amd.perlin_attention.performer import FastAttention
+    torch.manual_seed(31)
+    nb = int(D * math.log(D) / 8)
+    fa = FastAttention(D, nb_features=nb, causal=True, generalized_attention=True).to(DEV)
+    q = (torch.randn(N, H, T, D, device=DEV) * D ** -0.5).to(dtype); k = torch.randn(N, H, T, D, device=DEV).to(dtype)
+    v = torch.randn(N, H, T, D, device=DEV).to(dtype); pos = torch.randn(T + 8, D, device=DEV).to(dtype)
+    ref, ref_avg = ops.performer_value(q, k, v, pos, fa.projection_matrix, want_avg=True, n_segments=1)
+
+    def feed(cuts, nseg_first=1):
+        state, t0, outs, avgs = None, 0, [], []
+        for i, t1 in enumerate(cuts):
+            o, a, state = ops.performer_step(q[:, :, t0:t1], k[:, :, t0:t1], v[:, :, t0:t1], pos[t0:], fa.projection_matrix,
+                                             state_in=state, t_base=t0, n_segments=nseg_first if i == 0 else 1)
+            outs.append(o); avgs.append(a); t0 = t1
+        return torch.cat(outs, 2), torch.cat(avgs, 2)
+
+    out, avg = feed((128, 320, T) if T > 320 else (64, 256, T))         # chunk-aligned pieces
+    assert torch.equal(out, ref) and torch.equal(avg, ref_avg)
+    eps = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    cuts = [200] + list(range(201, 216)) + [T - 37, T]                   # a ragged prefill, 15 single rows, two longer pieces
+    for nseg_first in (1, 2):                                            # the prefill piece may itself be cut into segments
+        out, avg = feed(cuts, nseg_first)
+        for g, s in ((out, ref), (avg, ref_avg)):
+            g, s = g.float(), s.float()
+            assert ((g - s).abs() <= s.abs() * eps + 1e-6).all(), (g - s).abs().max().item()
+            assert (g != s).float().mean().item() < 0.02
+        assert torch.equal(out[..., 2 * D:], v)
+    with pytest.raises(AssertionError):                                  # an image without its row count
+        ops.performer_step(q[:, :, :8], k[:, :, :8], v[:, :, :8], pos, fa.projection_matrix, state_in=None, t_base=5)
