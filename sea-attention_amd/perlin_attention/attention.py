@@ -561,7 +561,20 @@ class PerlinAttention(nn.Module):
         bench = get_bench()
         T_M = self.pconfig.attention_predictor_length
         LB = CnnWindowState.LOOKBACK
-        if last_state is None and T_DST > 4 * LB and q.is_cuda and self.benchmarking:
+        ps = state.get(PerlinAttentionState.PERFORMER, PerformerState)
+        cs = state.get(PerlinAttentionState.CNN, CnnWindowState)
+        cav = state.get(PerlinAttentionState.CUMAVG, CumAvgState)
+        # 16-bit inference, d = 64: the whole estimator stays on the stateless path's kernels.  The Performer continues
+        # its own fp32 sums from a state image (`sea_performer_causal_step`), which also carries the column sums of v
+        # for the cumulative average; a call that brings many rows (a prefill) is just a long step.
+        hip_all = (self._hip_estimator_ok(q) and ps.S is None and cs.rows is None and cav.cumsum is None
+                   and v_for_atten is v and q_for_atten.dtype == k_for_atten.dtype == v.dtype
+                   and ops.performer_avg_supported(q_for_atten, self.performer_nb_features)
+                   and self._fused_mlp_ok(torch.empty((N, H, 0, 3 * HID), dtype=q.dtype, device=q.device)))
+        if not hip_all:
+            assert ps.image is None and cs.rows_c8 is None and not cav.in_image, \
+                "this state was written by the HIP estimator (16-bit inference); keep dtype / mode fixed while decoding from it"
+        if last_state is None and T_DST > 4 * LB and q.is_cuda and self.benchmarking and not hip_all:
             # ---- prefill: the rows come from the stateless fast path (HIP estimator + kernels, one pass); the state a
             # later call needs is rebuilt from sums over the prefix plus a cached-mode pass over the last LOOKBACK rows
             self.pconfig.use_cache = False
@@ -590,25 +603,32 @@ class PerlinAttention(nn.Module):
             # ---- A-C: value augmentation + causal Performer on the new rows, running sums carried ------------------
             with timer("performer"):
                 sl = slice(T_SRC - T_DST, T_SRC)
-                pos = self.v_eye_learned_causal[:, :, sl, :]
-                qa = q_for_atten.float()
-                ka, va = k_for_atten[..., sl, :].float(), v_for_atten[..., sl, :].float()
-                vaug = torch.cat([pos.expand(va.shape).float(), va], dim=-1)
-                ps = state.get(PerlinAttentionState.PERFORMER, PerformerState)
-                outs = []
-                for c0 in range(0, T_DST, 256):                      # bounded (chunk x chunk) score tiles (prefill)
-                    c1 = min(T_DST, c0 + 256)
-                    ps, o = ps.step(self.performer.feature_map(qa[..., c0:c1, :]),
-                                    self.performer.feature_map(ka[..., c0:c1, :]), vaug[..., c0:c1, :])
-                    outs.append(o)
-                state.states[PerlinAttentionState.PERFORMER] = ps
-                performer_context_layer = torch.cat(outs, dim=-2).to(q_for_atten.dtype)
                 v_new = v[..., sl, :]
-                performer_value = torch.cat([performer_context_layer, v_new], dim=-1)
+                avg_rows = None
+                if hip_all:
+                    nseg = ops.performer_plan(N, H, T_DST, HID, self.performer_nb_features, q.dtype)[0]
+                    performer_value, avg_rows, image = ops.performer_step(
+                        q_for_atten, k_for_atten[..., sl, :], v_new, self.v_eye_learned_causal[0, 0, seen:, :],
+                        self.performer.projection_matrix, state_in=ps.image, t_base=seen, n_segments=nseg)
+                    ps = PerformerState()
+                    ps.image, ps.seq_index = image, T_SRC
+                else:
+                    pos = self.v_eye_learned_causal[:, :, sl, :]
+                    qa = q_for_atten.float()
+                    ka, va = k_for_atten[..., sl, :].float(), v_for_atten[..., sl, :].float()
+                    vaug = torch.cat([pos.expand(va.shape).float(), va], dim=-1)
+                    outs = []
+                    for c0 in range(0, T_DST, 256):                  # bounded (chunk x chunk) score tiles (prefill)
+                        c1 = min(T_DST, c0 + 256)
+                        ps, o = ps.step(self.performer.feature_map(qa[..., c0:c1, :]),
+                                        self.performer.feature_map(ka[..., c0:c1, :]), vaug[..., c0:c1, :])
+                        outs.append(o)
+                    performer_context_layer = torch.cat(outs, dim=-2).to(q_for_atten.dtype)
+                    performer_value = torch.cat([performer_context_layer, v_new], dim=-1)
+                state.states[PerlinAttentionState.PERFORMER] = ps
             # ---- D-G: predictor MLP, windowed CNN, softmax ---------------------------------------------------------
-            cs = state.get(PerlinAttentionState.CNN, CnnWindowState)
             gates = None
-            if cs.rows is None and self._fused_mlp_ok(performer_value):
+            if hip_all:
                 # the stateless path's kernels on the new rows: one-launch MLP (its output is the CNN input AFTER
                 # lnorm1, channel-blocked), the two MFMA convolutions over [cached window | new rows] (rows before the
                 # window read as zero padding; its LOOKBACK rows cover the convolutions' reach), tail on the new rows
@@ -634,8 +654,6 @@ class PerlinAttention(nn.Module):
                         y[:, -T_DST:].contiguous(), conv4.weight[:, :, 0, 0], conv4.bias, ln2.weight, ln2.bias, up=4, T_m=T_M,
                         eps=ln2.eps, want_scores=False)
             else:
-                assert cs.rows_c8 is None, "this state's CNN window was written by the HIP estimator (16-bit inference); " \
-                                           "keep dtype / mode fixed while decoding from it"
                 with timer("predictor"):
                     t_attention_predictor = self.attention_predictor_enc(performer_value)
                     x = self.attention_predictor_dec_row(t_attention_predictor)
@@ -662,8 +680,12 @@ class PerlinAttention(nn.Module):
                     sig = torch.sigmoid(self.attention_predictor_dec_scaler(t_attention_predictor).float())
                     row_scale = sig[..., 0].contiguous() if self.pconfig.partial_attention_scaler else None
                     average_scale = sig[..., 1].contiguous()
-                cav = state.get(PerlinAttentionState.CUMAVG, CumAvgState)
-                cav, average_context_layer = cav.step(v_new)
+                if avg_rows is not None:                          # the Performer launch produced it (sums live in its image)
+                    average_context_layer = avg_rows
+                    cav = CumAvgState()
+                    cav.prev_len, cav.in_image = T_SRC, True
+                else:
+                    cav, average_context_layer = cav.step(v_new)
                 state.states[PerlinAttentionState.CUMAVG] = cav
                 qs = q_for_score if q_for_score.stride(-1) == 1 else q_for_score.contiguous()
                 ks = k_for_score if k_for_score.stride(-1) == 1 else k_for_score.contiguous()

@@ -30,10 +30,14 @@ class PerformerState:
     def __init__(self):
         self.S: Optional[torch.Tensor] = None      # (N, H, nb, e) float64
         self.ksum: Optional[torch.Tensor] = None   # (N, H, nb)    float64
+        # HIP estimator (16-bit inference, d = 64): the same sums -- and the column sums of v -- as the opaque fp32
+        # image `sea_performer_causal_step` reads and writes (the kernel's own accumulators); S / ksum stay None
+        self.image: Optional[torch.Tensor] = None
         self.seq_index = 0
 
     def step(self, qp: torch.Tensor, kp: torch.Tensor, v: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
         """qp, kp (N,H,T_new,nb) feature maps of the NEW rows, v (N,H,T_new,e).  Returns ctx (N,H,T_new,e) float32."""
+        assert self.image is None, "this state continues on the HIP Performer"
         qd, kd, vd = qp.double(), kp.double(), v.double()
         S0 = self.S if self.S is not None else torch.zeros(kd.shape[:2] + (kd.shape[-1], vd.shape[-1]), dtype=torch.float64, device=kd.device)
         k0 = self.ksum if self.ksum is not None else torch.zeros(kd.shape[:2] + (kd.shape[-1],), dtype=torch.float64, device=kd.device)
@@ -71,9 +75,11 @@ class CumAvgState:
     def __init__(self):
         self.cumsum: Optional[torch.Tensor] = None   # (N, H, 1, D) float32
         self.prev_len = 0
+        self.in_image = False                        # HIP estimator: the sums live in PerformerState.image
 
     def step(self, v_new: torch.Tensor):
         """v_new (N,H,T_new,D).  Returns (new_state, cumulative average rows (N,H,T_new,D) in v's dtype)."""
+        assert not self.in_image, "this state continues on the HIP Performer"
         cs = v_new.float().cumsum(-2)
         if self.cumsum is not None:
             cs = cs + self.cumsum

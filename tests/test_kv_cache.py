@@ -146,3 +146,30 @@ def test_cached_decoding_on_the_hip_estimator(dtype, N, H, T, T_M, k, T0, chunks
     with torch.no_grad(), pytest.raises(AssertionError, match="HIP estimator"):
         cached(None, None, None, query_layer=q[:, :, -1:], key_layer=torch.cat([x, x[:, :, -1:]], 2), value_layer=torch.cat([x, x[:, :, -1:]], 2),
                attention_mask=_mask(N, 1, T + 1, dtype), last_state=state)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+def test_cached_decoding_in_whole_chunks_is_bitwise_the_stateless_forward(dtype):
+    """All-HIP cached path fed in pieces that end on the Performer's 64-row chunk boundaries: the state image continues
+    the very same fp32 sums, MLP / convolutions / tail / selection / attention are per-row deterministic, so the
+    context rows equal the stateless forward BIT FOR BIT (and so does the probability map)."""
+    N, H, d, T, T_M, k = 2, 4, 64, 384, 128, 16
+    full = _layer(H, d, T_M, k, T, dtype, use_cache=False)
+    cached = _layer(H, d, T_M, k, T, dtype, use_cache=True)
+    full.attention.force_torch_estimator = cached.attention.force_torch_estimator = False
+    cached.load_state_dict(full.state_dict())
+    S.seed(13)
+    x = torch.randn((N, H, T, d), device=DEV).to(dtype)
+    q = (x.float() * d ** -0.5).to(dtype)
+    with torch.no_grad():
+        ref = full(None, None, None, query_layer=q, key_layer=x, value_layer=x, attention_mask=_mask(N, T, T, dtype))
+        state, ctx, maps, pos = None, [], [], 0
+        for hi in (128, 192, 320, 384):
+            out = cached(None, None, None, query_layer=q[:, :, pos:hi], key_layer=x[:, :, :hi], value_layer=x[:, :, :hi],
+                         attention_mask=_mask(N, hi - pos, hi, dtype), last_state=state)
+            state = out.state
+            assert state.states[PerlinAttentionState.PERFORMER].image is not None and state.seq_len == hi
+            ctx.append(out.context_layer); maps.append(out.estimated_attention_probs)
+            pos = hi
+    assert torch.equal(torch.cat(maps, dim=2), ref.estimated_attention_probs)
+    assert torch.equal(torch.cat(ctx, dim=1), ref.context_layer)
