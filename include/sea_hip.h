@@ -203,6 +203,11 @@ int sea_predictor_tail_select(const void* y, int dtype, int64_t N, int64_t C, in
  * Replaces `avg_v.cumsum(-2) / arange(1..T)` (attention.py:1220-1222).  out (N,H,T,D) contiguous. */
 int sea_cumavg(const void* v, int dtype, int64_t N, int64_t H, int64_t T, int64_t D, const int64_t* v_strides,
                void* out, sea_stream_t stream);
+/* The same with the T rows cut into n_slices slices (two launches: column totals per slice, then the averages
+ * starting from the totals before a slice) -- for the few (n,h) pairs of a one-sequence-per-GPU shard.
+ * workspace: N*H*n_slices*D floats, caller-owned.  16-bit data, D in {32,64,80,128}. */
+int sea_cumavg_sliced(const void* v, int dtype, int64_t N, int64_t H, int64_t T, int64_t D, const int64_t* v_strides,
+                      void* out, int64_t n_slices, void* workspace, int64_t workspace_bytes, sea_stream_t stream);
 
 /* Channel-blocked ("C8") predictor CNN for 16-bit data.
  * C8 layout of a logical (N, C, T, W) activation, C % 8 == 0:  memory (N, T, C/8, W, 8) -- 16-byte blocks of 8

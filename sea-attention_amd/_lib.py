@@ -38,6 +38,7 @@ _SIGNATURES = {
     "sea_predictor_tail": ([ptr, c_int, i64, i64, i64, i64, i64, i64, i64, _i64p, ptr, ptr, ptr, i64, ptr, ptr,
                             ctypes.c_float, ptr, ptr, ptr], c_int),
     "sea_cumavg": ([ptr, c_int, i64, i64, i64, i64, _i64p, ptr, ptr], c_int),
+    "sea_cumavg_sliced": ([ptr, c_int, i64, i64, i64, i64, _i64p, ptr, i64, ptr, i64, ptr], c_int),
     "sea_predictor_tail_select": ([ptr, c_int, i64, i64, i64, i64, i64, i64, i64, _i64p, ptr, ptr, i64, ptr, ptr,
                                    ctypes.c_float, ptr, ptr, ptr, i64, i64, c_int, c_int, ptr, ptr, ptr, ptr], c_int),
     "sea_predictor_mlp": ([ptr, c_int, i64, i64, i64, i64, _i64p, i64, i64, ptr, ptr, ptr, ctypes.c_float,

@@ -330,19 +330,24 @@ __global__ __launch_bounds__(1024) void cumavg_kernel(const T* v, T* out, int Tn
 // consecutive rows; a wave is RL = 64/FG row-lanes x FG feature groups, 16 waves split T.  Pass 1 sums the runs,
 // the run prefixes come from RL-1 shuffles inside the wave plus the 16 wave totals in LDS, pass 2 re-reads the
 // rows (L2 / Infinity Cache) and writes the averages.  Every load and store moves whole 128-byte lines.
-template <typename T, int FG>
-__global__ __launch_bounds__(1024) void cumavg_vec_kernel(const T* v, T* out, int Tn, int64_t vs_n, int64_t vs_h, int64_t vs_t,
-                                                         int H) {
+// Few (n,h) pairs: the rows are cut into `gridDim.y` slices of slice_len rows.  SUMS_ONLY leaves every slice's column
+// totals in carry[(nh * nslices + slice) * D], the second launch starts a slice from the totals before it.
+template <typename T, int FG, bool SUMS_ONLY>
+__global__ __launch_bounds__(1024) void cumavg_vec_kernel(const T* v, T* out, int T_all, int64_t vs_n, int64_t vs_h, int64_t vs_t,
+                                                         int H, int slice_len, float* carry) {
   constexpr int D = FG * 8, RL = 64 / FG;
+  const int slice = blockIdx.y, nslices = gridDim.y;
+  const int ts0 = slice * slice_len, Tn = min(T_all, ts0 + slice_len);     // this block's rows: [ts0, Tn)
   __shared__ float s_tot[16][D];
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   const int fg = lane % FG, r = lane / FG;
   const int nh = blockIdx.x;
   const int n = nh / H, h = nh - n * H;
-  const int seg_len = (Tn + 16 * RL - 1) / (16 * RL);
-  const int t0 = min(Tn, (wv * RL + r) * seg_len), t1 = min(Tn, t0 + seg_len);
+  const int seg_len = (Tn - ts0 + 16 * RL - 1) / (16 * RL);
+  // FG = 10 (d = 80): RL = 6 row-lanes use 60 lanes, the last 4 lanes of a wave own no rows
+  const int t0 = r < RL ? min(Tn, ts0 + (wv * RL + r) * seg_len) : Tn, t1 = min(Tn, t0 + seg_len);
   const T* vb = v + n * vs_n + h * vs_h + fg * 8;
-  T* ob = out + (int64_t)nh * Tn * D + fg * 8;
+  T* ob = out + (int64_t)nh * T_all * D + fg * 8;
   float s[8];
 #pragma unroll
   for (int j = 0; j < 8; ++j) s[j] = 0.f;
@@ -380,6 +385,21 @@ __global__ __launch_bounds__(1024) void cumavg_vec_kernel(const T* v, T* out, in
     if (r == RL - 1) s_tot[wv][fg * 8 + j] = inc;
   }
   __syncthreads();
+  if constexpr (SUMS_ONLY) {
+    if (threadIdx.x < D) {                                 // column totals of the slice, waves added in order
+      float tot = 0.f;
+      for (int w = 0; w < 16; ++w) tot += s_tot[w][threadIdx.x];
+      carry[((int64_t)nh * nslices + slice) * D + threadIdx.x] = tot;
+    }
+    return;
+  }
+  if (slice > 0 && r < RL) {
+    for (int s2 = 0; s2 < slice; ++s2) {                   // fixed order
+      const float* c = carry + ((int64_t)nh * nslices + s2) * D + fg * 8;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) run[j] += c[j];
+    }
+  }
   for (int w = 0; w < wv; ++w) {
     const float4 a = *reinterpret_cast<const float4*>(&s_tot[w][fg * 8]);
     const float4 b = *reinterpret_cast<const float4*>(&s_tot[w][fg * 8 + 4]);
@@ -531,9 +551,23 @@ extern "C" int sea_predictor_tail(const void* y, int dtype, int64_t N, int64_t C
   return SEA_OK;
 }
 
+static int cumavg_entry(const char* nm, const void* v, int dtype, int64_t N, int64_t H, int64_t T, int64_t D,
+                        const int64_t* v_strides, void* out, int64_t n_slices, void* workspace, int64_t workspace_bytes,
+                        sea_stream_t stream);
+
 extern "C" int sea_cumavg(const void* v, int dtype, int64_t N, int64_t H, int64_t T, int64_t D, const int64_t* v_strides,
                           void* out, sea_stream_t stream) {
-  const char* nm = "sea_cumavg";
+  return cumavg_entry("sea_cumavg", v, dtype, N, H, T, D, v_strides, out, 1, nullptr, 0, stream);
+}
+
+extern "C" int sea_cumavg_sliced(const void* v, int dtype, int64_t N, int64_t H, int64_t T, int64_t D, const int64_t* v_strides,
+                                 void* out, int64_t n_slices, void* workspace, int64_t workspace_bytes, sea_stream_t stream) {
+  return cumavg_entry("sea_cumavg_sliced", v, dtype, N, H, T, D, v_strides, out, n_slices, workspace, workspace_bytes, stream);
+}
+
+static int cumavg_entry(const char* nm, const void* v, int dtype, int64_t N, int64_t H, int64_t T, int64_t D,
+                        const int64_t* v_strides, void* out, int64_t n_slices, void* workspace, int64_t workspace_bytes,
+                        sea_stream_t stream) {
   SEA_REQUIRE(v && v_strides && out, SEA_EINVAL, "%s: null pointer", nm);
   SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_F16 || dtype == SEA_BF16, SEA_EINVAL, "%s: bad dtype %d", nm, dtype);
   SEA_REQUIRE(N > 0 && H > 0 && T > 0 && D > 0, SEA_EINVAL, "%s: bad shape", nm);
@@ -541,16 +575,25 @@ extern "C" int sea_cumavg(const void* v, int dtype, int64_t N, int64_t H, int64_
   SEA_REQUIRE(N * H * dslabs < (1ll << 31), SEA_EUNSUPPORTED, "%s: grid too large", nm);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)(N * H * dslabs)), block(1024);
-  // 16-byte vector path: 16-bit data, D in {32, 64, 128}, everything 16-byte aligned
-  const bool vec = dtype != SEA_F32 && (D == 32 || D == 64 || D == 128) && v_strides[0] % 8 == 0 && v_strides[1] % 8 == 0 &&
+  // 16-byte vector path: 16-bit data, D in {32, 64, 80, 128}, everything 16-byte aligned
+  const bool vec = dtype != SEA_F32 && (D == 32 || D == 64 || D == 80 || D == 128) && v_strides[0] % 8 == 0 && v_strides[1] % 8 == 0 &&
                    v_strides[2] % 8 == 0 && (((uintptr_t)v | (uintptr_t)out) & 15) == 0;
+  SEA_REQUIRE(n_slices >= 1 && n_slices <= 64 && n_slices <= T, SEA_EINVAL, "%s: n_slices %lld outside 1..min(64, T)", nm, (long long)n_slices);
+  SEA_REQUIRE(n_slices == 1 || vec, SEA_EUNSUPPORTED, "%s: slices need the vector kernel (16-bit data, D in {32,64,80,128}, aligned)", nm);
+  SEA_REQUIRE(n_slices == 1 || (workspace && workspace_bytes >= N * H * n_slices * D * (int64_t)sizeof(float)), SEA_EINVAL,
+              "%s: workspace of %lld bytes needed", nm, (long long)(N * H * n_slices * D * (int64_t)sizeof(float)));
   if (vec) {
-    dim3 g2((unsigned)(N * H));
-#define SEA_CUMAVG(TT, FGV) hipLaunchKernelGGL((cumavg_vec_kernel<TT, FGV>), g2, block, 0, s, (const TT*)v, (TT*)out, (int)T, \
-                                               v_strides[0], v_strides[1], v_strides[2], (int)H)
-    if (dtype == SEA_F16) { if (D == 32) SEA_CUMAVG(__half, 4); else if (D == 64) SEA_CUMAVG(__half, 8); else SEA_CUMAVG(__half, 16); }
-    else { if (D == 32) SEA_CUMAVG(__hip_bfloat16, 4); else if (D == 64) SEA_CUMAVG(__hip_bfloat16, 8); else SEA_CUMAVG(__hip_bfloat16, 16); }
+    const int slice_len = (int)((T + n_slices - 1) / n_slices);
+    const int ns = (int)((T + slice_len - 1) / slice_len);       // no empty slice
+    float* carry = reinterpret_cast<float*>(workspace);
+    dim3 g2((unsigned)(N * H), (unsigned)ns);
+#define SEA_CUMAVG1(TT, FGV, SO) hipLaunchKernelGGL((cumavg_vec_kernel<TT, FGV, SO>), g2, block, 0, s, (const TT*)v, (TT*)out, (int)T, \
+                                                    v_strides[0], v_strides[1], v_strides[2], (int)H, slice_len, carry)
+#define SEA_CUMAVG(TT, FGV) do { if (ns > 1) SEA_CUMAVG1(TT, FGV, true); SEA_CUMAVG1(TT, FGV, false); } while (0)
+    if (dtype == SEA_F16) { if (D == 32) SEA_CUMAVG(__half, 4); else if (D == 64) SEA_CUMAVG(__half, 8); else if (D == 80) SEA_CUMAVG(__half, 10); else SEA_CUMAVG(__half, 16); }
+    else { if (D == 32) SEA_CUMAVG(__hip_bfloat16, 4); else if (D == 64) SEA_CUMAVG(__hip_bfloat16, 8); else if (D == 80) SEA_CUMAVG(__hip_bfloat16, 10); else SEA_CUMAVG(__hip_bfloat16, 16); }
 #undef SEA_CUMAVG
+#undef SEA_CUMAVG1
     SEA_CHECK_LAUNCH(nm);
     return SEA_OK;
   }

@@ -142,7 +142,7 @@ def predictor_tail_select(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.T
     return probs, scores, (bits, row_nnz, head_off)
 
 
-def cumavg(v: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def cumavg(v: torch.Tensor, out: Optional[torch.Tensor] = None, n_slices: int = None) -> torch.Tensor:
     """Causal cumulative average over the time axis of (N,H,T,D), fp32 accumulation, dtype preserved.
     `out`: optional preallocated contiguous (N,H,T,D) result (lets a caller launch this on a side stream)."""
     lib = _lib.load()
@@ -153,6 +153,15 @@ def cumavg(v: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     if out is None:
         out = torch.empty((N, H, T, D), dtype=v.dtype, device=v.device)
     assert out.shape == (N, H, T, D) and out.dtype == v.dtype and out.is_contiguous()
+    # one workgroup per (n, h): with few pairs (a one-sequence-per-GPU shard) the rows are cut into slices
+    ns = n_slices if n_slices is not None else (min(16, 256 // (N * H)) if N * H <= 128 and T >= 2048 else 1)
+    vec_ok = (v.dtype != torch.float32 and D in (32, 64, 80, 128) and all(st % 8 == 0 for st in v.stride()[:3])
+              and v.data_ptr() % 16 == 0 and out.data_ptr() % 16 == 0)
+    if ns > 1 and vec_ok:
+        ws = torch.empty((N * H * ns * D,), dtype=torch.float32, device=v.device)
+        _lib.check(lib.sea_cumavg_sliced(_p(v), _lib.dtype_code(v.dtype), N, H, T, D, _lib.strides3(v), _p(out), ns, _p(ws),
+                                         ws.numel() * 4, _lib.stream_ptr()), "sea_cumavg_sliced")
+        return out
     _lib.check(lib.sea_cumavg(_p(v), _lib.dtype_code(v.dtype), N, H, T, D, _lib.strides3(v), _p(out),
                               _lib.stream_ptr()), "sea_cumavg")
     return out

@@ -83,7 +83,7 @@ def test_predictor_tail(ops, dtype, N, H, T, T_M, layout):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("N,H,T,D", [(2, 3, 100, 64), (1, 4, 4096, 64), (1, 2, 33, 80), (1, 2, 257, 128), (1, 1, 7, 16), (1, 2, 50, 32)])
+@pytest.mark.parametrize("N,H,T,D", [(2, 3, 100, 64), (1, 4, 4096, 64), (1, 2, 33, 80), (2, 3, 1500, 80), (1, 2, 257, 128), (1, 1, 7, 16), (1, 2, 50, 32)])
 def test_cumavg(ops, dtype, N, H, T, D):
     g = torch.Generator().manual_seed(2)
     v = torch.randn((N, H, T, D), generator=g).to(dtype)
@@ -451,3 +451,26 @@ def test_performer_step_continues_the_sequence(ops, dtype, N, H, T, D):
         assert torch.equal(out[..., 2 * D:], v)
     with pytest.raises(AssertionError):                                  # an image without its row count
         ops.performer_step(q[:, :, :8], k[:, :, :8], v[:, :, :8], pos, fa.projection_matrix, state_in=None, t_base=5)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,T,D", [(1, 4, 5000, 80), (1, 2, 4096, 128), (2, 2, 2500, 64)])
+def test_cumavg_sliced(ops, dtype, N, H, T, D):
+    """`sea_cumavg_sliced`: the rows cut into slices with carried column totals (two launches) -- the averages of the
+    one-launch kernel up to fp32 summation order; the default picks slices by itself when N*H is small."""
+    g = torch.Generator().manual_seed(4)
+    v = torch.randn((N, H, T, D), generator=g).to(dtype).to(DEV)
+    one = ops.cumavg(v, n_slices=1).float()
+    ref = v.float().cumsum(-2) / torch.arange(1, T + 1, device=DEV).view(1, 1, -1, 1)
+    eps = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    for ns in (None, 3, 16):
+        got = ops.cumavg(v, n_slices=ns).float()
+        assert ((got - one).abs() <= one.abs() * eps + 1e-6).all(), (ns, (got - one).abs().max().item())
+        assert (got != one).float().mean().item() < 0.02
+        torch.testing.assert_close(got, ref, atol=1e-2, rtol=1e-2)
+    with pytest.raises(RuntimeError, match="workspace"):
+        from sea_attention_amd import _lib
+        out = torch.empty_like(v)
+        _lib.check(_lib.load().sea_cumavg_sliced(v.data_ptr(), _lib.dtype_code(dtype), N, H, T, D, _lib.strides3(v), out.data_ptr(),
+                                                 4, None, 0, None), "sea_cumavg_sliced")
