@@ -57,6 +57,31 @@ struct PerfParams {
   int t_base;
 };
 
+typedef __attribute__((ext_vector_type(8))) __bf16 pbf8;
+typedef __attribute__((ext_vector_type(8))) _Float16 ph8;
+typedef __attribute__((ext_vector_type(4))) short ps4;
+
+// 16-bit storage type of the split operands: bf16 data splits into bf16 terms (2 x 8 significand bits), fp16 data into
+// fp16 terms (2 x 11 bits; the state S and the products stay well inside fp16's range for T up to tens of thousands)
+template <typename T> struct S16;
+template <> struct S16<__hip_bfloat16> {
+  static constexpr unsigned short ONE = 0x3F80;
+  __device__ static inline unsigned short bits(float x) { return __builtin_bit_cast(unsigned short, __float2bfloat16(x)); }
+  __device__ static inline float val(unsigned short b) { return __uint_as_float((uint32_t)b << 16); }
+  __device__ static inline f4 mfma(const uint4& a, const uint4& b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pbf8, a), __builtin_bit_cast(pbf8, b), c, 0, 0, 0);
+  }
+};
+template <> struct S16<__half> {
+  static constexpr unsigned short ONE = 0x3C00;
+  __device__ static inline unsigned short bits(float x) { return __builtin_bit_cast(unsigned short, __float2half(x)); }
+  __device__ static inline float val(unsigned short b) { return __half2float(__builtin_bit_cast(__half, b)); }
+  __device__ static inline f4 mfma(const uint4& a, const uint4& b, f4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(ph8, a), __builtin_bit_cast(ph8, b), c, 0, 0, 0);
+  }
+};
+template <> struct S16<float> {};     // (fp32 data never takes the 16-bit feature-map product)
+
 // NW = waves per workgroup (8: two per SIMD, so one wave's LDS/MFMA latency hides behind the other's issue)
 template <typename T, int D, int NBT, int C, int NW, bool STATE_ONLY>
 __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
@@ -68,11 +93,16 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
   constexpr int JB = (EB + NW - 1) / NW;      // column blocks owned by one wave
   constexpr int LDQ = D + 2, LDV = E + 16, LDP = NBP + 2, LDA = C + 2, LDW = D + 2;
   static_assert(LDA <= LDQ, "the A tile is overlaid on the Q tile");
+  // 16-bit data: q, k and the projection ARE 16-bit values, so the feature-map product runs exactly on the 16x16x32
+  // 16-bit MFMA (8x the fp32 MFMA rate) from raw 16-bit LDS images [k-chunk of 8][row][8]; everything downstream stays fp32
+  constexpr bool IS16 = !std::is_same<T, float>::value;
+  constexpr int DK = (D + 31) / 32 * 32;      // feature-map contraction length, zero padded to whole 32-wide k-steps
+  constexpr int F0 = IS16 ? 0 : NBP * LDW, F1 = IS16 ? C * LDA : C * LDQ, F2 = IS16 ? 0 : C * LDQ;
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* sW = smem;               // NBP x LDW   W (rows >= nb are zero)
-  float* sQ = sW + NBP * LDW;     // C x LDQ     Q chunk, later the masked A tile (C x LDA)
-  float* sK = sQ + C * LDQ;       // C x LDQ
-  float* sV = sK + C * LDQ;       // C x LDV     [pos | v]
+  float* sW = smem;               // NBP x LDW   W (rows >= nb are zero)                      [fp32 data only]
+  float* sQ = sW + F0;            // C x LDQ     Q chunk, later the masked A tile (C x LDA)   [16-bit data: the A tile only]
+  float* sK = sQ + F1;            // C x LDQ                                                  [fp32 data only]
+  float* sV = sK + F2;            // C x LDV     [pos | v]
   float* sQp = sV + C * LDV;      // C x LDP     phi(Q)
   float* sKp = sQp + C * LDP;     // C x LDP     phi(K)
   float* sKsum = sKp + C * LDP;   // NBP         running sum of phi(k)
@@ -80,6 +110,10 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
   constexpr int DSL = RB + NW * 64 / C;       // partial-denominator slots per row: RB key blocks + carry parts
   float* sDenP = sDen + C;        // C x DSL     partials, summed in a fixed order (bitwise reproducible)
   float* sA = sQ;
+  static_assert((F0 + F1 + F2 + C * LDV + 2 * C * LDP + NBP + C + C * DSL) % 4 == 0, "16-bit images start 16-byte aligned");
+  unsigned short* sW16 = reinterpret_cast<unsigned short*>(sDenP + C * DSL);   // [DK/8][NBP][8]
+  unsigned short* sQ16 = sW16 + (DK / 8) * NBP * 8;                             // [DK/8][C][8]
+  unsigned short* sK16 = sQ16 + (DK / 8) * C * 8;                               // [DK/8][C][8]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -96,9 +130,23 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
   T* ob = reinterpret_cast<T*>(p.out) + (int64_t)nh * p.T * (3 * D);
   const float cnorm = powf((float)D, -0.25f);
 
-  for (int i = tid; i < NBP * LDW; i += NTH) {
-    const int r = i / LDW, c = i - r * LDW;
-    sW[i] = (r < p.nb && c < D) ? p.W[r * D + c] : 0.f;
+  if constexpr (IS16) {
+    for (int i = tid; i < (DK / 8) * NBP * 8; i += NTH) {
+      const int j = i & 7, f = (i >> 3) % NBP, dd = ((i >> 3) / NBP) * 8 + j;
+      sW16[i] = (f < p.nb && dd < D) ? S16<T>::bits(p.W[f * D + dd]) : (unsigned short)0;
+    }
+    // padding k-chunks (D = 80: chunks 10, 11 of 12) are zeroed once; the staging below never writes them -- and must
+    // not race with this loop, so the live chunks are left alone here
+    if constexpr (DK > D)
+      for (int i = tid; i < 2 * ((DK - D) / 8) * C * 8; i += NTH) {
+        const int m = i / (((DK - D) / 8) * C * 8), rest = i - m * (((DK - D) / 8) * C * 8);
+        sQ16[(m * (DK / 8) + D / 8) * C * 8 + rest] = 0;
+      }
+  } else {
+    for (int i = tid; i < NBP * LDW; i += NTH) {
+      const int r = i / LDW, c = i - r * LDW;
+      sW[i] = (r < p.nb && c < D) ? p.W[r * D + c] : 0.f;
+    }
   }
 
   // state = sum of the increments of the segments before this one (fixed order); raw per-thread register images
@@ -169,11 +217,19 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
         const int r = ch / (D / VEC), c = (ch - r * (D / VEC)) * VEC;
         float fq[VEC], fk[VEC], fv[VEC], fp[VEC];
         if (!STATE_ONLY && r < rows) *reinterpret_cast<uint4*>(ob + (int64_t)(t0 + r) * (3 * D) + 2 * D + c) = pv[i];
-        unpack16<T>(pq[i], fq); unpack16<T>(pk[i], fk); unpack16<T>(pv[i], fv); unpack16<T>(pp[i], fp);
+        unpack16<T>(pv[i], fv); unpack16<T>(pp[i], fp);
+        if constexpr (IS16) {                                // raw 16-byte pieces: k-chunk c/8, row r
+          *reinterpret_cast<uint4*>(sQ16 + ((c / 8) * C + r) * 8) = pq[i];
+          *reinterpret_cast<uint4*>(sK16 + ((c / 8) * C + r) * 8) = pk[i];
+        } else {
+          unpack16<T>(pq[i], fq); unpack16<T>(pk[i], fk);
+        }
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-          sQ[r * LDQ + c + j] = fq[j];
-          sK[r * LDQ + c + j] = fk[j];
+          if constexpr (!IS16) {
+            sQ[r * LDQ + c + j] = fq[j];
+            sK[r * LDQ + c + j] = fk[j];
+          }
           sV[r * LDV + c + j] = fp[j];
           sV[r * LDV + D + c + j] = fv[j];
         }
@@ -188,6 +244,34 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
     // a wave takes (matrix, row block) pairs: one A fragment feeds NBT independent accumulators
     for (int grp = (STATE_ONLY ? RB : 0) + wv; grp < 2 * RB; grp += NW) {   // the state-only pass needs phi(K) alone
       const int which = grp / RB, ib = grp - which * RB;        // 0: Q, 1: K
+      if constexpr (IS16) {
+        // transposed product X^T[f][t] = sum_d W[f][d] x[t][d]: a lane ends up with 4 consecutive features of one row
+        const unsigned short* src16 = which ? sK16 : sQ16;
+        f4 acc[NBT];
+#pragma unroll
+        for (int fb = 0; fb < NBT; ++fb) acc[fb] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < DK / 32; ++ks) {
+          const uint4 bx = *reinterpret_cast<const uint4*>(src16 + ((4 * ks + lg) * C + ib * 16 + li) * 8);
+#pragma unroll
+          for (int fb = 0; fb < NBT; ++fb) {
+            const uint4 aw = *reinterpret_cast<const uint4*>(sW16 + ((4 * ks + lg) * NBP + fb * 16 + li) * 8);
+            acc[fb] = S16<T>::mfma(aw, bx, acc[fb]);
+          }
+        }
+        float* dst = which ? sKp : sQp;
+        const int row = ib * 16 + li;
+#pragma unroll
+        for (int fb = 0; fb < NBT; ++fb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int col = fb * 16 + lg * 4 + r;
+            float val = fmaxf(cnorm * acc[fb][r], 0.f) + 1e-3f;
+            if (col >= p.nb || row >= rows) val = 0.f;       // padded features / rows beyond T contribute nothing
+            dst[row * LDP + col] = val;
+          }
+        continue;
+      }
       const float* src = which ? sK : sQ;
       f4 acc[NBT];
 #pragma unroll
@@ -376,29 +460,6 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
 //   * S is, as in the fp32 kernel, the B operand of phi(Q).S straight from the accumulator registers; element j
 //     of lane group g is feature 16*(2kk + j/4) + 4g + j%4, and the phi(Q) fragment is gathered in that order.
 // ======================================================================================================
-typedef __attribute__((ext_vector_type(8))) __bf16 pbf8;
-typedef __attribute__((ext_vector_type(8))) _Float16 ph8;
-typedef __attribute__((ext_vector_type(4))) short ps4;
-
-// 16-bit storage type of the split operands: bf16 data splits into bf16 terms (2 x 8 significand bits), fp16 data into
-// fp16 terms (2 x 11 bits; the state S and the products stay well inside fp16's range for T up to tens of thousands)
-template <typename T> struct S16;
-template <> struct S16<__hip_bfloat16> {
-  static constexpr unsigned short ONE = 0x3F80;
-  __device__ static inline unsigned short bits(float x) { return __builtin_bit_cast(unsigned short, __float2bfloat16(x)); }
-  __device__ static inline float val(unsigned short b) { return __uint_as_float((uint32_t)b << 16); }
-  __device__ static inline f4 mfma(const uint4& a, const uint4& b, f4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(pbf8, a), __builtin_bit_cast(pbf8, b), c, 0, 0, 0);
-  }
-};
-template <> struct S16<__half> {
-  static constexpr unsigned short ONE = 0x3C00;
-  __device__ static inline unsigned short bits(float x) { return __builtin_bit_cast(unsigned short, __float2half(x)); }
-  __device__ static inline float val(unsigned short b) { return __half2float(__builtin_bit_cast(__half, b)); }
-  __device__ static inline f4 mfma(const uint4& a, const uint4& b, f4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(ph8, a), __builtin_bit_cast(ph8, b), c, 0, 0, 0);
-  }
-};
 // x -> (hi, lo) 16-bit patterns with hi + lo ~ x to twice the type's significand bits
 template <typename T> __device__ inline void split16(float x, unsigned short& hi, unsigned short& lo) {
   hi = S16<T>::bits(x);
@@ -851,8 +912,13 @@ using namespace sea;
 template <typename T, int D, int NBT, int C, int NW = 8>
 static int launch_perf(const PerfParams& p, hipStream_t s) {
   constexpr int E = 2 * D, NBP = NBT * 16;
-  constexpr size_t lds = sizeof(float) * (NBP * (D + 2) + 2 * C * (D + 2) + C * (E + 16) + 2 * C * (NBP + 2) + NBP + C +
-                                          C * (C / 16 + NW * 64 / C));
+  constexpr bool IS16 = !std::is_same<T, float>::value;
+  constexpr int DK = (D + 31) / 32 * 32;
+  constexpr size_t lds = IS16
+      ? sizeof(float) * (C * (C + 2) + C * (E + 16) + 2 * C * (NBP + 2) + NBP + C + C * (C / 16 + NW * 64 / C)) +
+            2 * ((DK / 8) * NBP * 8 + 2 * (DK / 8) * C * 8)
+      : sizeof(float) * (NBP * (D + 2) + 2 * C * (D + 2) + C * (E + 16) + 2 * C * (NBP + 2) + NBP + C +
+                         C * (C / 16 + NW * 64 / C));
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool configured = false;   // one per template instantiation; the attribute call is a slow driver round trip
   if (lds > 64 * 1024 && !configured) {
