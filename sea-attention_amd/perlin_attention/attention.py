@@ -396,10 +396,23 @@ class PerlinAttention(nn.Module):
                             for layer in body[:-2]:                                           # causal convs + ReLUs
                                 x = layer(x)
                         conv4 = body[-1].module
+                        T_M_ = self.pconfig.attention_predictor_length
+                        Hh = self.num_attention_heads
                         with timer("cnn.tail"):
-                            estimated_attention_probs, estimated_attention_score = ops.predictor_tail(
-                                x, conv4.weight[:, :, 0, 0], conv4.bias, ln2.weight, ln2.bias, up=4,
-                                T_m=self.pconfig.attention_predictor_length, eps=ln2.eps, want_scores=want_scores)
+                            if (c8 and query_skips == 1 and self.benchmarking and not_padded
+                                    and not get_bench().activate_temp_buffers
+                                    and ops.predictor_tail_select_supported(x, Hh, T_M_)):
+                                # as on the fused-MLP path: tail + top-k selection in one launch
+                                keep, _z = self._keep_table(Hh, q.shape[-2], T_SRC, T_M_, q.device)
+                                estimated_attention_probs, estimated_attention_score, sel = ops.predictor_tail_select(
+                                    x, conv4.weight[:, :, 0, 0], conv4.bias, ln2.weight, ln2.bias, up=4, T_m=T_M_,
+                                    keep=keep, k=int(self.pconfig.k), T_src=T_SRC, is_causal=True, eps=ln2.eps,
+                                    want_scores=want_scores)
+                                self._fused_selection = (estimated_attention_probs, sel)
+                            else:
+                                estimated_attention_probs, estimated_attention_score = ops.predictor_tail(
+                                    x, conv4.weight[:, :, 0, 0], conv4.bias, ln2.weight, ln2.bias, up=4,
+                                    T_m=T_M_, eps=ln2.eps, want_scores=want_scores)
                     if query_skips > 1:
                         estimated_attention_probs = estimated_attention_probs.repeat_interleave(query_skips, dim=-2)
                         if estimated_attention_score is not None:

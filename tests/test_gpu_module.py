@@ -151,3 +151,33 @@ def test_row_sharded_sparse_path_equals_the_full_one():
     for world in (2, 4):
         parts = [D.sparse_rows(ops, probs, q, kk, v, *D.row_shard_bounds(T, world, r, k), k, rs, avg, mx) for r in range(world)]
         assert torch.equal(torch.cat(parts, dim=1), full)
+
+
+@pytest.mark.parametrize("H,d", [(8, 64), (8, 80), (8, 128)])
+def test_bf16_fast_path_equals_probing_path(H, d):
+    """The shapes of BASELINE configs 3-5 in bf16: the layer's fast path (one-launch MLP where d allows it, C8 convolutions,
+    tail fused with the top-k selection, sequence-parallel Performer for the few (n,h) pairs of one sequence) against
+    the same layer with buffer probing on (separate tail and selection launches): same map and same CSR bit for bit, the
+    context within a rounding step; and the context stays within bf16 noise of dense mode."""
+    N, T, T_M, k = 1, 1024, 256, 32
+    layer = make_layer(H, d, T_M, k, T, torch.bfloat16)
+    layer.attention.context_layer_dtype = torch.bfloat16
+    S.seed(5)
+    x = torch.randn((N, H, T, d), device=DEV).to(torch.bfloat16)
+    mask = causal_mask(N, T, torch.bfloat16)
+    out_fast, _ = run(layer, x * d ** -0.5, x.clone(), x.clone(), mask, True, capture=False)
+    out_probe, bp = run(layer, x * d ** -0.5, x.clone(), x.clone(), mask, True, capture=True)
+    assert torch.equal(out_fast.estimated_attention_probs, out_probe.estimated_attention_probs)
+    a, b = out_fast.partial_attention_mask, out_probe.partial_attention_mask
+    assert torch.equal(a.crow, b.crow)
+    for n in range(N):
+        z = int(a.crow[n, -1])
+        assert torch.equal(a.col[n, :z], b.col[n, :z])
+    # (the probing path takes the cumulative average from its own kernel and keeps per-step buffers: same key sets, the
+    # context a rounding step apart here and there)
+    cf, cp = out_fast.context_layer.float(), out_probe.context_layer.float()
+    assert ((cf - cp).norm() / cp.norm()).item() < 4e-3
+    out_dense, _ = run(layer, x * d ** -0.5, x.clone(), x.clone(), mask, False, capture=False)
+    ref = out_dense.context_layer.float()
+    rel = ((out_fast.context_layer.float() - ref).norm() / ref.norm()).item()
+    assert rel < 3e-2, rel
