@@ -355,6 +355,141 @@ __global__ __launch_bounds__(NWB * 64) void sparse_attn_rows_kernel(AttnParams p
   }
 }
 
+// ---- d = 80 (OPT-2.7B heads), 16-bit data: 8 lanes per row, each with 8 + 2 elements -------------------------
+// The power-of-two mapping above gives a d = 80 row 16 lanes of which 10 carry data (4 rows per wave).  Here a row
+// takes 8 lanes: lane j holds elements 8j..8j+7 (one 16-byte load) plus the pair 64+2j, 65+2j (one 4-byte load), so a
+// wave advances 8 rows with every lane busy.  Same walk, same online softmax, same epilogue as sparse_attn_rows_kernel.
+template <typename T> __device__ inline float tail_dot(uint32_t q, uint32_t k, float d);
+template <> __device__ inline float tail_dot<__hip_bfloat16>(uint32_t q, uint32_t k, float d) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(sea_bf2, q), __builtin_bit_cast(sea_bf2, k), d, false);
+}
+template <> __device__ inline float tail_dot<__half>(uint32_t q, uint32_t k, float d) {
+  return __builtin_amdgcn_fdot2(__builtin_bit_cast(sea_h2, q), __builtin_bit_cast(sea_h2, k), d, false);
+}
+template <typename T> __device__ inline void unpack2(uint32_t r, float* f);
+template <> __device__ inline void unpack2<__hip_bfloat16>(uint32_t r, float* f) {
+  f[0] = __uint_as_float(r << 16); f[1] = __uint_as_float(r & 0xffff0000u);
+}
+template <> __device__ inline void unpack2<__half>(uint32_t r, float* f) {
+  const float2 t = __half22float2(__builtin_bit_cast(__half2, r));
+  f[0] = t.x; f[1] = t.y;
+}
+template <typename TO> __device__ inline void store2(TO* dst, float a, float b) { *reinterpret_cast<uint32_t*>(dst) = pack2<TO>(a, b); }
+template <> __device__ inline void store2<float>(float* dst, float a, float b) { *reinterpret_cast<float2*>(dst) = make_float2(a, b); }
+
+template <typename T, typename TO, int U, int NWB = 4>
+__global__ __launch_bounds__(NWB * 64) void sparse_attn_rows80_kernel(AttnParams p) {
+  constexpr int LPR = 8, VEC = 8, XT = 2, DM = LPR * VEC;     // DM = 64 elements in the 16-byte fragments
+  constexpr int RPW = 64 / LPR, RPB = NWB * RPW;
+  int pair, tb;
+  if (!map_block(p.N * p.H, p.TB, &pair, &tb)) return;
+  const int n = pair / p.H, h = pair - n * p.H;
+  const int lane = threadIdx.x & 63;
+  const int grp = lane / LPR, sub = lane - grp * LPR;
+  const int t = tb * RPB + (threadIdx.x >> 6) * RPW + grp;
+  const bool rowok = t < p.T_dst;
+  const int tt = rowok ? t : p.T_dst - 1;
+
+  const char* kbase = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.k) + n * p.ks[0] + h * p.ks[1]);
+  const char* vbase = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.v) + n * p.vs[0] + h * p.vs[1]);
+  const uint32_t kst = (uint32_t)p.ks[2] * (uint32_t)sizeof(T), vst = (uint32_t)p.vs[2] * (uint32_t)sizeof(T);
+  const uint32_t off_m = (uint32_t)(sub * VEC) * (uint32_t)sizeof(T);              // 16-byte fragment
+  const uint32_t off_x = (uint32_t)(DM + sub * XT) * (uint32_t)sizeof(T);          // 4-byte pair
+
+  const T* qrow = reinterpret_cast<const T*>(p.q) + n * p.qs[0] + h * p.qs[1] + (int64_t)tt * p.qs[2];
+  const uint4 qraw = *reinterpret_cast<const uint4*>(qrow + sub * VEC);
+  const uint32_t qx = *reinterpret_cast<const uint32_t*>(qrow + DM + sub * XT);
+  const int row_beg = p.crow[(int64_t)n * (p.T_dst + 1) + tt];
+  const int32_t* ho = p.head_off + ((int64_t)n * p.T_dst + tt) * (p.H + 1);
+  const int beg = row_beg + ho[h];
+  const int end = rowok ? row_beg + ho[h + 1] : beg;
+  const int32_t* col = p.col + n * p.col_stride_n;
+  const int hcol = h * p.T_src;
+
+  float m = -INFINITY, l = 0.f;
+  float acc[VEC + XT];
+#pragma unroll
+  for (int j = 0; j < VEC + XT; ++j) acc[j] = 0.f;
+
+  int zmax = end - beg;
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) zmax = max(zmax, __shfl_xor(zmax, o));
+  const int last = end - 1;
+  const int grp_lane0 = (lane - sub) << 2;
+  for (int i0 = 0; i0 < zmax; i0 += LPR) {
+    int cidx;
+    {
+      const int e = beg + i0 + sub;
+      const int ec = e < end ? e : (last >= beg ? last : 0);
+      cidx = (end > beg) ? (col[ec] - hcol) : 0;
+    }
+#pragma unroll
+    for (int u0 = 0; u0 < LPR; u0 += U) {
+      if (i0 + u0 < zmax) {                                // wave-uniform
+        bool ok[U];
+        uint4 kr[U], vr[U];
+        uint32_t kx[U], vx[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          ok[u] = beg + i0 + u0 + u < end;
+          const uint32_t key_c = (uint32_t)__builtin_amdgcn_ds_bpermute(grp_lane0 + ((u0 + u) << 2), cidx);
+          const uint32_t ko = __umul24(key_c, kst), vo = __umul24(key_c, vst);
+          kr[u] = *reinterpret_cast<const uint4*>(kbase + (ko + off_m));
+          kx[u] = *reinterpret_cast<const uint32_t*>(kbase + (ko + off_x));
+          vr[u] = *reinterpret_cast<const uint4*>(vbase + (vo + off_m));
+          vx[u] = *reinterpret_cast<const uint32_t*>(vbase + (vo + off_x));
+        }
+        float s[U];
+        float mnew = m;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          float d = tail_dot<T>(qx, kx[u], frag_dot<T>(qraw, kr[u]));
+          d = group_sum<LPR>(d);
+          s[u] = ok[u] ? d : -INFINITY;
+          mnew = fmaxf(mnew, s[u]);
+        }
+        const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+        const float alpha = __expf(m - msafe);
+        l *= alpha;
+#pragma unroll
+        for (int j = 0; j < VEC + XT; ++j) acc[j] *= alpha;
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const float pu = __expf(s[u] - msafe);
+          float vf[VEC + XT];
+          unpack16<T>(vr[u], vf);
+          unpack2<T>(vx[u], vf + VEC);
+          l += pu;
+#pragma unroll
+          for (int j = 0; j < VEC + XT; ++j) acc[j] = fmaf(pu, vf[j], acc[j]);
+        }
+        m = mnew;
+      }
+    }
+  }
+
+  if (rowok) {
+    const int64_t ridx = ((int64_t)n * p.H + h) * p.T_dst + t;
+    float scale = (l > 0.f) ? (1.0f / l) : 0.f;
+    if (p.row_scale) scale *= p.row_scale[ridx];
+    float o[VEC + XT];
+#pragma unroll
+    for (int j = 0; j < VEC + XT; ++j) o[j] = acc[j] * scale;
+    if (p.mix) {
+      const float a = p.mix[ridx];
+      const T* ap = reinterpret_cast<const T*>(p.avg) + n * p.as[0] + h * p.as[1] + (int64_t)t * p.as[2];
+      float af[VEC + XT];
+      unpack16<T>(*reinterpret_cast<const uint4*>(ap + sub * VEC), af);
+      unpack2<T>(*reinterpret_cast<const uint32_t*>(ap + DM + sub * XT), af + VEC);
+#pragma unroll
+      for (int j = 0; j < VEC + XT; ++j) o[j] = o[j] * a + (1.0f - a) * af[j];
+    }
+    TO* op = reinterpret_cast<TO*>(p.out) + n * p.os[0] + h * p.os[1] + (int64_t)t * p.os[2];
+    store_frag<TO, VEC>(op + sub * VEC, o);
+    store2<TO>(op + DM + sub * XT, o[VEC], o[VEC + 1]);
+  }
+}
+
 // ---- unfused SDDMM: one wave per (n, t) row, all heads -----------------------------------------------
 struct SddmmParams {
   const void *q, *k;
@@ -501,6 +636,19 @@ static int launch_attn(AttnParams p, hipStream_t s) {
     if (nwb == 16) hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 8, 4, 16>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 8, 4, 8>), grid, block, 0, s, p);
     return SEA_OK;
+  }
+  if constexpr (sizeof(T) == 2) {
+    static const bool no80 = [] { const char* e = getenv("SEA_ATTN_NO80"); return e && e[0] == '1'; }();   // A/B hook
+    if (attn_variant() == 1 && p.D == 80 && small && !no80) {      // d = 80: 8 lanes x (8 + 2) elements per row
+      const int rpb = 4 * 8;
+      p.TB = (p.T_dst + rpb - 1) / rpb;
+      const int64_t blocks = (int64_t)8 * ((NH + 7) / 8) * p.TB;
+      static const int u80 = [] { const char* e = getenv("SEA_ATTN_U"); return e ? atoi(e) : 4; }();       // A/B hook
+      if (u80 == 2) hipLaunchKernelGGL((sparse_attn_rows80_kernel<T, TO, 2>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+      else if (u80 == 8) hipLaunchKernelGGL((sparse_attn_rows80_kernel<T, TO, 8>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+      else hipLaunchKernelGGL((sparse_attn_rows80_kernel<T, TO, 4>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+      return SEA_OK;
+    }
   }
   if (attn_variant() == 1 && lpr <= 16 && small) {
     const int rpb = 4 * (64 / lpr);
