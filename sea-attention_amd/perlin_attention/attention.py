@@ -553,6 +553,14 @@ class PerlinAttention(nn.Module):
             )
 
     # ------------------------------------------------------------------------------------------------
+    def _decode_keep(self, H, T_DST, T_SRC, T_M):
+        """K_t of the new rows only (absolute positions T_SRC-T_DST+1 .. T_SRC), same fp32 expression as
+        ops.keep_table_causal (attention.py:849-866), and the capacity bound of their CSR."""
+        ctl = torch.arange(T_SRC - T_DST + 1, T_SRC + 1, dtype=torch.long)
+        per = H * (self.pconfig.k * self.pconfig.k_oversample * T_M / ctl)
+        keep_cpu = torch.clamp_max(torch.clamp_min(torch.round(per), 1), H * T_M).to(torch.int32)
+        return keep_cpu, ops.z_capacity(keep_cpu, H, T_DST, T_SRC, T_M, int(self.pconfig.k), True)
+
     def _forward_cached(self, q, k, v, q_for_atten, k_for_atten, v_for_atten, q_for_score, k_for_score,
                         attention_mask, last_state):
         """KV-cache decoding (reference: the `use_cache` branches of attention.py:391-439,527-572,
@@ -641,6 +649,7 @@ class PerlinAttention(nn.Module):
                 state.states[PerlinAttentionState.PERFORMER] = ps
             # ---- D-G: predictor MLP, windowed CNN, softmax ---------------------------------------------------------
             gates = None
+            fused_sel = None
             if hip_all:
                 # the stateless path's kernels on the new rows: one-launch MLP (its output is the CNN input AFTER
                 # lnorm1, channel-blocked), the two MFMA convolutions over [cached window | new rows] (rows before the
@@ -663,9 +672,18 @@ class PerlinAttention(nn.Module):
                         y = ops.causal_conv_c8(y, conv.weight, conv.bias, conv.kernel_size, conv.dilation,
                                                conv.padding[1], relu=True)
                     conv4 = body[-1].module
-                    estimated_attention_probs, _ = ops.predictor_tail(
-                        y[:, -T_DST:].contiguous(), conv4.weight[:, :, 0, 0], conv4.bias, ln2.weight, ln2.bias, up=4, T_m=T_M,
-                        eps=ln2.eps, want_scores=False)
+                    y_new = y[:, -T_DST:].contiguous()
+                    if ops.predictor_tail_select_supported(y_new, H, T_M):
+                        # tail + top-k selection of the new rows in one launch (their absolute widths: T_src given)
+                        keep_cpu, z_cap = self._decode_keep(H, T_DST, T_SRC, T_M)
+                        estimated_attention_probs, _, fused_sel = ops.predictor_tail_select(
+                            y_new, conv4.weight[:, :, 0, 0], conv4.bias, ln2.weight, ln2.bias, up=4, T_m=T_M,
+                            keep=keep_cpu.to(q.device, non_blocking=True), k=int(self.pconfig.k), T_src=T_SRC,
+                            is_causal=True, eps=ln2.eps, want_scores=False)
+                    else:
+                        estimated_attention_probs, _ = ops.predictor_tail(
+                            y_new, conv4.weight[:, :, 0, 0], conv4.bias, ln2.weight, ln2.bias, up=4, T_m=T_M,
+                            eps=ln2.eps, want_scores=False)
             else:
                 with timer("predictor"):
                     t_attention_predictor = self.attention_predictor_enc(performer_value)
@@ -676,14 +694,12 @@ class PerlinAttention(nn.Module):
                         .to(estimated_attention_score.dtype).contiguous()
             # ---- H-I: grouped top-k of the new rows (their absolute widths), interpolation to flat CSR -------------
             with timer("interp"):
-                # K_t of the new rows only (absolute positions T_SRC-T_DST+1 .. T_SRC), same fp32 expression as
-                # ops.keep_table_causal (attention.py:849-866)
-                ctl = torch.arange(T_SRC - T_DST + 1, T_SRC + 1, dtype=torch.long)
-                per = H * (self.pconfig.k * self.pconfig.k_oversample * T_M / ctl)
-                keep_cpu = torch.clamp_max(torch.clamp_min(torch.round(per), 1), H * T_M).to(torch.int32)
-                z_cap = ops.z_capacity(keep_cpu, H, T_DST, T_SRC, T_M, int(self.pconfig.k), True)
-                csr, _ = ops.topk_to_csr(estimated_attention_probs, keep_cpu.to(q.device), int(self.pconfig.k),
-                                         target_width=T_SRC, is_causal=True, z_cap=z_cap)
+                if fused_sel is not None:
+                    csr = ops.csr_from_selection(*fused_sel, H, T_M, T_SRC, int(self.pconfig.k), True, z_cap)
+                else:
+                    keep_cpu, z_cap = self._decode_keep(H, T_DST, T_SRC, T_M)
+                    csr, _ = ops.topk_to_csr(estimated_attention_probs, keep_cpu.to(q.device), int(self.pconfig.k),
+                                             target_width=T_SRC, is_causal=True, z_cap=z_cap)
             # ---- J-L: gates, cumulative average (carried), fused sparse attention ----------------------------------
             with timer("attention"):
                 if gates is not None:
