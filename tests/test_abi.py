@@ -96,3 +96,35 @@ def test_ctypes_signatures_match_the_header_prototypes():
         argtypes, _res = _lib._SIGNATURES[name]
         got = [kind_of_ctypes(t) for t in argtypes]
         assert got == want, f"{name}: header {want} vs ctypes {got}"
+
+
+def test_host_side_planning_entries():
+    """`sea_performer_plan`, `sea_performer_state_bytes`, `sea_sparse_attention_bytes` are host arithmetic (no device
+    work): the plan cuts the rows only when N*H leaves the chip idle, segments are whole 64-row chunks, none empty."""
+    lib = _lib.load()
+    BF16 = _lib.dtype_code(torch.bfloat16)
+
+    def plan(N, H, T, D, nb):
+        a, b = (ctypes.c_int64 * 1)(), (ctypes.c_int64 * 1)()
+        assert lib.sea_performer_plan(N, H, T, D, nb, BF16, a, b) == 0
+        return int(a[0]), int(b[0])
+
+    assert plan(8, 32, 4096, 64, 33) == (1, 0)                      # headline batch: 256 pairs, one pass
+    assert plan(4, 40, 4096, 128, 77) == (1, 0)                     # 160 pairs > 128: not cut
+    nseg, ws = plan(1, 32, 8192, 80, 43)                            # BASELINE config 4, one sequence per GPU
+    assert nseg == 8 and ws > 0 and ws % 16 == 0
+    nseg5, ws5 = plan(1, 40, 4096, 128, 77)                         # config 5: 40 pairs -> 6 segments (240 workgroups)
+    assert nseg5 == 6 and ws5 > 0
+    assert plan(1, 4, 300, 64, 33) == (1, 0)                        # short sequence: fewer than 8 chunks
+    for T in (513, 1000, 2049, 5000):
+        n, _ = plan(1, 2, T, 64, 33)
+        chunks = (T + 63) // 64
+        seg_len = ((chunks + n - 1) // n) * 64
+        assert 1 <= n <= 16 and (n - 1) * seg_len < T <= n * seg_len, (T, n)
+    a, b = (ctypes.c_int64 * 1)(), (ctypes.c_int64 * 1)()
+    assert lib.sea_performer_plan(1, 1, 1024, 96, 40, BF16, a, b) == -2      # SEA_EUNSUPPORTED head size
+    assert b"D=96" in lib.sea_last_error()
+    sb = lib.sea_performer_state_bytes(2, 4, 64, 33, BF16)
+    assert sb > 0 and sb % (2 * 4) == 0 and lib.sea_performer_state_bytes(2, 4, 96, 33, BF16) == 0
+    # algorithmic bytes of the graded kernel: Z (2 d s + 4) + N H T (2 d s + 4)   (SURVEY 8d)
+    assert lib.sea_sparse_attention_bytes(1000, 2, 3, 10, 64, 2) == 1000 * (2 * 64 * 2 + 4) + 2 * 3 * 10 * (2 * 64 * 2 + 4)
