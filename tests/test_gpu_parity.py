@@ -248,3 +248,35 @@ def test_tail_rows_of_a_longer_prefix_match_the_oracle(ops, N, H, T_dst, T_src, 
         assert torch.equal(csr.col[n, :z].cpu().long(), col[n, :z])
     out = ops.sparse_attention(q.to(DEV), kk.to(DEV), v.to(DEV), csr, row_scale=rs.to(DEV))
     torch.testing.assert_close(out.cpu(), ref, atol=1e-4, rtol=1e-3)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.bfloat16, 1e-2), (torch.float16, 2e-3)])
+@pytest.mark.parametrize("N,H,T_dst,T_src,T_M,k", [(1, 6, 9, 500, 64, 16), (2, 4, 33, 300, 32, 8), (1, 5, 257, 257, 64, 16)])
+def test_d80_rows_on_eight_lanes_match_the_oracle(ops, dtype, tol, N, H, T_dst, T_src, T_M, k):
+    """d = 80 heads in 16-bit data take `sparse_attn_rows80_kernel` (8 lanes x (8 + 2) elements per row).  Against the
+    oracle on the same 16-bit inputs: full epilogue (row scale, mix with the cumulative average), the last T_dst rows
+    of a longer prefix, row counts that leave the last workgroup / wave partly empty, fp32 and 16-bit outputs."""
+    d = 80
+    g = torch.Generator().manual_seed(8)
+    probs = torch.softmax(torch.randn((N, H, T_dst, T_M), generator=g), -1)
+    q = (torch.randn((N, H, T_dst, d), generator=g) * d ** -0.5).to(dtype)
+    kk, v = torch.randn((N, H, T_src, d), generator=g).to(dtype), torch.randn((N, H, T_src, d), generator=g).to(dtype)
+    rs = torch.sigmoid(torch.randn((N, H, T_dst), generator=g))
+    mx = torch.sigmoid(torch.randn((N, H, T_dst), generator=g))
+    avg = torch.randn((N, H, T_dst, d), generator=g).to(dtype)
+    keep = O.keep_counts_module(H, T_src, T_M, k)[-T_dst:].contiguous()
+    mask = O.grouped_topk_mask(probs, keep)
+    crow, col = O.resize_m_to_t_csr(mask, k, T_src, True)
+    sparse = O.sparse_attention(q.float(), kk.float(), v.float(), crow, col, rs)
+    ref = sparse * mx.unsqueeze(-1) + (1.0 - mx.unsqueeze(-1)) * avg.float()
+    csr, _ = ops.topk_to_csr(probs.to(DEV), keep.to(torch.int32).to(DEV), k, target_width=T_src)
+    out32 = ops.sparse_attention(q.to(DEV), kk.to(DEV), v.to(DEV), csr, row_scale=rs.to(DEV), avg=avg.to(DEV), mix=mx.to(DEV))
+    assert out32.dtype == torch.float32
+    torch.testing.assert_close(out32.cpu(), ref, atol=2e-4, rtol=1e-3)          # fp32 accumulation on exact 16-bit inputs
+    out16 = torch.empty((N, T_dst, H * d), dtype=dtype, device=DEV)               # the layer's (N, T, H*d) layout
+    ops.sparse_attention(q.to(DEV), kk.to(DEV), v.to(DEV), csr, row_scale=rs.to(DEV), avg=avg.to(DEV), mix=mx.to(DEV),
+                         out=out16.view(N, T_dst, H, d).permute(0, 2, 1, 3))
+    got = out16.view(N, T_dst, H, d).permute(0, 2, 1, 3).float().cpu()
+    torch.testing.assert_close(got, ref, atol=tol, rtol=tol)
+    plain = ops.sparse_attention(q.to(DEV), kk.to(DEV), v.to(DEV), csr)           # no epilogue inputs at all
+    torch.testing.assert_close(plain.cpu(), O.sparse_attention(q.float(), kk.float(), v.float(), crow, col, None), atol=2e-4, rtol=1e-3)
