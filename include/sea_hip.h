@@ -156,6 +156,36 @@ int sea_sparse_attention(const void* q, const void* k, const void* v, int dtype,
                          void* out, int out_dtype, const int64_t* out_strides,
                          sea_stream_t stream);
 
+/* The same operator with two more knobs.
+ *
+ * flags, low byte = kernel path:
+ *   SEA_ATTN_AUTO    the library picks (today: the tile kernel where it applies, else the gather kernels);
+ *   SEA_ATTN_GATHER  row-indexed gather kernels (sea_attn.hip): one lane group per (n,h,t) row walks the row's entries,
+ *                    every K / V row is fetched per entry (L2-served); any dtype, any D <= 64*vec, duplicates counted;
+ *   SEA_ATTN_TILE    MFMA tile kernel (sea_attn_tile.hip): a wave owns 16 or 32 consecutive query rows of one (n,h),
+ *                    turns their entries into a key bitmap in LDS, and for every 16-key tile that holds a kept key
+ *                    runs K.Q^T, the masked online softmax and V^T.P^T on v_mfma_f32_16x16x32 with K/V rows fetched
+ *                    once per tile -- the shape of the reference's flat_csr_sdbmm.py:141-313.  16-bit data,
+ *                    D in {64, 80, 128}, no duplicate (row, column) pairs.  SEA_EUNSUPPORTED otherwise.
+ *   bits 8..11: row tiles per wave for the tile kernel (1 or 2; 0 = default for the head size);
+ *   bits 12..15: log2 of its key window (6..12; 0 = default 2048).
+ *
+ * probs_out (optional): fp32, laid out like `col` (row n at probs_out + n*probs_stride_n): entry e receives
+ *   rs * softmax_e -- the values of `partial_attention_probs` after flat_csr_softmax + flat_csr_elmul
+ *   (attention.py:1162-1171).  Served by the gather kernels (SEA_ATTN_TILE + probs_out is SEA_EUNSUPPORTED;
+ *   SEA_ATTN_AUTO falls back to them). */
+enum sea_attn_path { SEA_ATTN_AUTO = 0, SEA_ATTN_GATHER = 1, SEA_ATTN_TILE = 2 };
+int sea_sparse_attention_ex(const void* q, const void* k, const void* v, int dtype,
+                            int64_t N, int64_t H, int64_t T_dst, int64_t T_src, int64_t D,
+                            const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                            const int32_t* crow, const int32_t* col, int64_t col_stride_n,
+                            const int32_t* head_off,
+                            const float* row_scale, const void* avg, const int64_t* avg_strides,
+                            const float* mix,
+                            void* out, int out_dtype, const int64_t* out_strides,
+                            float* probs_out, int64_t probs_stride_n, int flags,
+                            sea_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Bandwidth-bound estimator / epilogue pieces (the callers either side of the hot kernels).
  */
@@ -272,6 +302,9 @@ int sea_performer_causal(const void* q, const void* k, const void* v, const void
  * sea_performer_plan proposes n_segments for a shape (1 when N*H already fills the chip) and the workspace size;
  * the caller owns the workspace (16-byte aligned, no initialisation needed).  n_segments = 1 is
  * sea_performer_causal (workspace may be NULL).  Same role in the reference as sea_performer_causal. */
+/* 1 when sea_performer_causal* can also write `avg_out` (the cumulative average of v) for this head size, feature
+ * count and dtype, else 0 -- the one predicate both sides of the ABI use (host arithmetic only). */
+int sea_performer_avg_supported(int64_t D, int64_t nb, int dtype);
 int sea_performer_plan(int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb, int dtype,
                        int64_t* n_segments, int64_t* workspace_bytes);
 int sea_performer_causal_segmented(const void* q, const void* k, const void* v, const void* pos, int dtype,

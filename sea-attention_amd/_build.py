@@ -1,13 +1,29 @@
 """Build libsea_hip.so (gfx950) in-tree with hipcc.  No torch extension machinery: the library is a
-plain C-ABI shared object (include/sea_hip.h) loaded through ctypes."""
+plain C-ABI shared object (include/sea_hip.h) loaded through ctypes.
+
+One object per source (compiled in parallel, content-addressed: rebuilt only when the source, a header or the
+flags changed), one link."""
+import hashlib
 import os
 import subprocess
+from concurrent.futures import ThreadPoolExecutor
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
+OBJ_DIR = os.path.join(PKG_DIR, "build")
 LIB_PATH = os.path.join(PKG_DIR, "libsea_hip.so")
-SOURCES = ["sea_topk.hip", "sea_attn.hip", "sea_csr_ops.hip", "sea_predictor.hip", "sea_performer.hip", "sea_conv.hip", "sea_mlp.hip"]
-HEADERS = [os.path.join(CSRC, "sea_common.hpp"), os.path.join(CSRC, "sea_tail.hpp"), os.path.join(os.path.dirname(PKG_DIR), "include", "sea_hip.h")]
+SOURCES = ["sea_topk.hip", "sea_attn.hip", "sea_attn_tile.hip", "sea_attn_bwd.hip", "sea_csr_ops.hip", "sea_predictor.hip",
+           "sea_performer.hip", "sea_conv.hip", "sea_mlp.hip"]
+HEADERS = [os.path.join(CSRC, "sea_common.hpp"), os.path.join(CSRC, "sea_attn.hpp"), os.path.join(CSRC, "sea_tail.hpp"),
+           os.path.join(os.path.dirname(PKG_DIR), "include", "sea_hip.h")]
+# -fno-slp-vectorize: the SLP pass packs adjacent scalar f32 adds/muls into v_pk_* pairs plus the v_mov traffic
+# to form the register pairs; on gfx950 that is a net loss in these VALU-issue-bound kernels (A/B: -1.5 % step)
+COMMON_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
+# per-file flags.  The MFMA tile attention keeps its accumulators in VGPRs (gfx950's register file is unified): with the
+# default AGPR form every rescale of the output accumulators costs a v_accvgpr_read + write around the multiply, and
+# the VGPR + AGPR split costs a wave of occupancy (171 -> 166 registers, 2 -> 3 waves per SIMD).
+FILE_FLAGS = {"sea_attn_tile.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+              "sea_attn_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc():
@@ -17,28 +33,71 @@ def _hipcc():
     return "hipcc"
 
 
+def _sources():
+    return [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
+
+
+def source_hash():
+    """sha256 over everything the library is made from (sources, headers, flags): survives copies of the tree
+    (a gpurun snapshot keeps no useful mtimes), unlike a timestamp comparison."""
+    h = hashlib.sha256()
+    for f in [os.path.join(CSRC, s) for s in _sources()] + HEADERS:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    h.update(repr((COMMON_FLAGS, sorted(FILE_FLAGS.items()))).encode())
+    return h.hexdigest()
+
+
 def is_stale():
-    if not os.path.exists(LIB_PATH):
+    """True when libsea_hip.so is missing or was built from other sources than the ones in the tree now."""
+    if not os.path.exists(LIB_PATH) or not os.path.exists(LIB_PATH + ".sha256"):
         return True
-    t = os.path.getmtime(LIB_PATH)
-    deps = [os.path.join(CSRC, s) for s in SOURCES] + HEADERS
-    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+    return open(LIB_PATH + ".sha256").read().strip() != source_hash()
 
 
 def build_library(force=False, extra_flags=(), out=None, verbose=False):
-    """hipcc --offload-arch=gfx950 -O3 -shared -fPIC csrc/*.hip -o libsea_hip.so"""
+    """hipcc --offload-arch=gfx950 -O3 -c csrc/X.hip (per file) ; hipcc -shared *.o -o libsea_hip.so"""
     out = out or LIB_PATH
     if not force and out == LIB_PATH and not is_stale():
         return out
-    # -fno-slp-vectorize: the SLP pass packs adjacent scalar f32 adds/muls into v_pk_* pairs plus the v_mov traffic
-    # to form the register pairs; on gfx950 that is a net loss in these VALU-issue-bound kernels (A/B: -1.5 % step)
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-fno-slp-vectorize",
-           "-Wall", "-Wno-unused-function", *extra_flags,
-           *[os.path.join(CSRC, s) for s in SOURCES], "-o", out + f".tmp.{os.getpid()}"]
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    cc = _hipcc()
+    custom = bool(extra_flags) or out != LIB_PATH          # A/B builds keep the product's objects
+
+    hdr_bytes = b"".join(open(h, "rb").read() for h in HEADERS)
+
+    def compile_one(src):
+        flags = [*COMMON_FLAGS, *FILE_FLAGS.get(src, []), *extra_flags]
+        key = hashlib.sha256(open(os.path.join(CSRC, src), "rb").read() + hdr_bytes + repr(flags).encode()).hexdigest()[:16]
+        stem = os.path.splitext(src)[0]
+        obj = os.path.join(OBJ_DIR, f"{stem}.{key}.o")      # content-addressed: a reused object IS this source + flags
+        if os.path.exists(obj) and not force:
+            return obj
+        tmp_o = obj + f".tmp.{os.getpid()}"
+        cmd = [cc, *flags, "-c", os.path.join(CSRC, src), "-o", tmp_o]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+        os.replace(tmp_o, obj)
+        for f in os.listdir(OBJ_DIR):                       # drop this source's older objects
+            if f.startswith(stem + ".") and f.endswith(".o") and f != os.path.basename(obj) and not custom:
+                try:
+                    os.remove(os.path.join(OBJ_DIR, f))
+                except OSError:
+                    pass
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, os.cpu_count() or 1)) as ex:
+        objs = list(ex.map(compile_one, _sources()))
+    tmp = out + f".tmp.{os.getpid()}"
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", tmp]
     if verbose:
-        print(" ".join(cmd))
+        print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    os.replace(out + f".tmp.{os.getpid()}", out)     # atomic: concurrent ranks building at once cannot tear the file
+    os.replace(tmp, out)                                   # atomic: concurrent ranks building at once cannot tear the file
+    if out == LIB_PATH and not extra_flags:
+        with open(LIB_PATH + ".sha256", "w") as f:
+            f.write(source_hash())
     return out
 
 

@@ -33,6 +33,8 @@ _SIGNATURES = {
     "sea_csr_spmm": ([ptr, ptr, c_int, i64, i64, i64, i64, i64, _i64p, ptr, ptr, c_int, i64, ptr, ptr, ptr], c_int),
     "sea_sparse_attention": ([ptr, ptr, ptr, c_int, i64, i64, i64, i64, i64, _i64p, _i64p, _i64p,
                               ptr, ptr, i64, ptr, ptr, ptr, _i64p, ptr, ptr, c_int, _i64p, ptr], c_int),
+    "sea_sparse_attention_ex": ([ptr, ptr, ptr, c_int, i64, i64, i64, i64, i64, _i64p, _i64p, _i64p,
+                                 ptr, ptr, i64, ptr, ptr, ptr, _i64p, ptr, ptr, c_int, _i64p, ptr, i64, c_int, ptr], c_int),
     "sea_sparse_attention_bytes": ([i64, i64, i64, i64, i64, c_int], i64),
     "sea_split_layernorm": ([ptr, c_int, i64, i64, i64, i64, i64, ptr, ptr, ctypes.c_float, c_int, ptr, ptr], c_int),
     "sea_predictor_tail": ([ptr, c_int, i64, i64, i64, i64, i64, i64, i64, _i64p, ptr, ptr, ptr, i64, ptr, ptr,
@@ -49,6 +51,7 @@ _SIGNATURES = {
     "sea_performer_state_bytes": ([i64, i64, i64, i64, c_int], i64),
     "sea_performer_causal_step": ([ptr, ptr, ptr, ptr, c_int, ptr, i64, i64, i64, i64, i64, _i64p, _i64p, _i64p, i64, ptr, ptr,
                                    ptr, ptr, i64, i64, i64, ptr, i64, ptr], c_int),
+    "sea_performer_avg_supported": ([i64, i64, c_int], c_int),
     "sea_performer_plan": ([i64, i64, i64, i64, i64, c_int, _i64p, _i64p], c_int),
     "sea_performer_causal_segmented": ([ptr, ptr, ptr, ptr, c_int, ptr, i64, i64, i64, i64, i64, _i64p, _i64p, _i64p, i64, ptr, ptr,
                                         i64, ptr, i64, ptr], c_int),
@@ -61,21 +64,34 @@ def library_path():
     return _build.LIB_PATH
 
 
+SEA_ATTN_AUTO, SEA_ATTN_GATHER, SEA_ATTN_TILE = 0, 1, 2
+
+
 def load(build_if_missing=True):
-    """Load (building first if the .so is absent and hipcc is available).  Raises if impossible."""
+    """Load libsea_hip.so, (re)building it first when it is missing or was built from other sources than the tree
+    holds now (content hash, `_build.is_stale`).  `SEA_HIP_LIB=<path>` loads that file as is (A/B builds of the same
+    ABI) and fails if it does not exist.  Raises if the library cannot be had: there is no other path."""
     global _lib
     if _lib is not None:
         return _lib
-    path = os.environ.get("SEA_HIP_LIB") or _build.LIB_PATH       # override: A/B builds of the same ABI
-    if not os.path.exists(path):
-        if not build_if_missing:
-            raise RuntimeError(f"{path} not built; run `python -c 'import __graft_entry__ as g; g.build()'`")
-        _build.build_library()
+    override = os.environ.get("SEA_HIP_LIB")
+    if override:
+        if not os.path.exists(override):
+            raise RuntimeError(f"SEA_HIP_LIB={override} does not exist")
+        path = override
+    else:
+        path = _build.LIB_PATH
+        if _build.is_stale():
+            if not build_if_missing:
+                raise RuntimeError(f"{path} is missing or stale; run `python -c 'import __graft_entry__ as g; g.build()'`")
+            _build.build_library()
     lib = ctypes.CDLL(path)
     for name, (argtypes, restype) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = restype
+    if lib.sea_version() != 1:
+        raise RuntimeError(f"{path}: ABI version {lib.sea_version()}, this binding speaks 1")
     _lib = lib
     return lib
 
@@ -108,7 +124,36 @@ def strides5_blocked(t):
 
 
 def stream_ptr():
+    """hipStream_t of the CURRENT device's current stream (operators run under `device_guarded`, which makes the
+    tensors' device current first)."""
     return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def device_guarded(fn):
+    """Operator decorator: run `fn` with the device of its first device-tensor argument current, so that the stream
+    handed to the library and the launch itself belong to the tensors' device (a tensor on cuda:1 called while cuda:0
+    is current would otherwise be launched on cuda:0's stream).  No cost beyond an argument scan when it already is."""
+    import functools
+
+    def _first_cuda(args, kwargs):
+        for a in list(args) + list(kwargs.values()):
+            if isinstance(a, torch.Tensor):
+                if a.is_cuda:
+                    return a
+            else:
+                t = getattr(a, "crow", None)              # FlatCSR handle
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    return t
+        return None
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        t = _first_cuda(args, kwargs)
+        if t is None or t.device.index == torch.cuda.current_device():
+            return fn(*args, **kwargs)
+        with torch.cuda.device(t.device):
+            return fn(*args, **kwargs)
+    return wrapper
 
 
 def check(rc, what):

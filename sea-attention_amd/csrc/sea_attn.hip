@@ -17,8 +17,7 @@
 // HBM / L2: K and V of one (n, h) are T_src*D*2*s bytes (1 MiB at OPT-1.3B T=4096 bf16), so the
 // gathers are served by L2 when the workgroups of a head run on one XCD: blockIdx is remapped so
 // that the (n, h) pair index is congruent to the XCD label blockIdx % 8 (speed only).
-#include "sea_common.hpp"
-#include <stdlib.h>
+#include "sea_attn.hpp"
 
 namespace sea {
 
@@ -28,17 +27,10 @@ template <int CTRL> __device__ inline float dpp_f(float x) {
 
 // sum over the LPR lanes of an aligned group; result in every lane of the group
 template <int LPR> __device__ inline float group_sum(float x) {
-#ifndef SEA_NO_DPP
   if (LPR >= 2) x += dpp_f<0xB1>(x);    // quad_perm [1,0,3,2]
   if (LPR >= 4) x += dpp_f<0x4E>(x);    // quad_perm [2,3,0,1]
   if (LPR >= 8) x += dpp_f<0x141>(x);   // row_half_mirror (values are quad-uniform here)
   if (LPR >= 16) x += dpp_f<0x140>(x);  // row_mirror      (values are 8-uniform here)
-#else
-  if (LPR >= 2) x += __shfl_xor(x, 1);
-  if (LPR >= 4) x += __shfl_xor(x, 2);
-  if (LPR >= 8) x += __shfl_xor(x, 4);
-  if (LPR >= 16) x += __shfl_xor(x, 8);
-#endif
   if (LPR >= 32) x += __shfl_xor(x, 16);
   if (LPR >= 64) x += __shfl_xor(x, 32);
   return x;
@@ -68,68 +60,10 @@ template <> __device__ inline float frag_dot<__half>(const uint4& q, const uint4
   return __builtin_amdgcn_fdot2(__builtin_bit_cast(sea_h2, q.w), __builtin_bit_cast(sea_h2, k.w), d, false);
 }
 
-struct AttnParams {
-  const void *q, *k, *v;
-  int64_t qs[3], ks[3], vs[3];
-  int N, H, T_dst, T_src, D;
-  const int32_t* crow;
-  const int32_t* col;
-  int64_t col_stride_n;
-  const int32_t* head_off;
-  const float* row_scale;
-  const void* avg;
-  int64_t as[3];
-  const float* mix;
-  void* out;
-  int64_t os[3];
-  int TB;  // row blocks per (n, h): ceil(T_dst / 4)
-};
-
-template <typename TO, int VEC> __device__ inline void store_frag(TO* dst, const float* f);
-template <> __device__ inline void store_frag<float, 4>(float* dst, const float* f) {
-  *reinterpret_cast<float4*>(dst) = make_float4(f[0], f[1], f[2], f[3]);
-}
-template <> __device__ inline void store_frag<float, 8>(float* dst, const float* f) {
-  *reinterpret_cast<float4*>(dst) = make_float4(f[0], f[1], f[2], f[3]);
-  *reinterpret_cast<float4*>(dst + 4) = make_float4(f[4], f[5], f[6], f[7]);
-}
-template <> __device__ inline void store_frag<__hip_bfloat16, 8>(__hip_bfloat16* dst, const float* f) {
-  union { uint4 u; __hip_bfloat16 h[8]; } r;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) r.h[i] = __float2bfloat16(f[i]);
-  *reinterpret_cast<uint4*>(dst) = r.u;
-}
-template <> __device__ inline void store_frag<__half, 8>(__half* dst, const float* f) {
-  union { uint4 u; __half h[8]; } r;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) r.h[i] = __float2half(f[i]);
-  *reinterpret_cast<uint4*>(dst) = r.u;
-}
-template <> __device__ inline void store_frag<__hip_bfloat16, 4>(__hip_bfloat16* dst, const float* f) {
-  union { uint2 u; __hip_bfloat16 h[4]; } r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r.h[i] = __float2bfloat16(f[i]);
-  *reinterpret_cast<uint2*>(dst) = r.u;
-}
-template <> __device__ inline void store_frag<__half, 4>(__half* dst, const float* f) {
-  union { uint2 u; __half h[4]; } r;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) r.h[i] = __float2half(f[i]);
-  *reinterpret_cast<uint2*>(dst) = r.u;
-}
-
-// (n, h, row-block) from blockIdx, XCD-aware: blocks b and b+8 share an XCD (observed dispatch
-// order; only affects L2 locality).  Returns false if this block has no work.
-__device__ inline bool map_block(int NH, int TB, int* pair, int* tb) {
-  const int bid = blockIdx.x;
-  const int xcd = bid & 7, slot = bid >> 3;
-  const int pl = slot / TB;
-  *tb = slot - pl * TB;
-  *pair = pl * 8 + xcd;
-  return *pair < NH;
-}
-
-template <typename T, typename TO, int LPR, int U>
+// WP: also write the per-entry values rs * softmax to p.probs (`partial_attention_probs`, attention.py:1162-1171).  Pass 1
+// leaves the raw score at the entry's slot, a second walk turns it into the probability once (m, l) are final; every slot
+// is re-read by the lane that wrote it (a thread sees its own stores), so no fence is needed.
+template <typename T, typename TO, int LPR, int U, bool WP>
 __global__ __launch_bounds__(256) void sparse_attn_kernel(AttnParams p) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr int KPI = 64 / LPR;  // keys per wave-instruction
@@ -166,7 +100,7 @@ __global__ __launch_bounds__(256) void sparse_attn_kernel(AttnParams p) {
     for (int u = 0; u < U; ++u) {
       const int e = e0 + u * KPI + grp;
       ok[u] = e < end;
-      const int key = ok[u] ? (col[e] - hcol) : 0;
+      const int key = col[ok[u] ? e : end - 1] - hcol;      // masked groups re-read the row's last entry (a finite V row)
       kr[u] = make_uint4(0, 0, 0, 0);
       vr[u] = make_uint4(0, 0, 0, 0);
       if (dact) {
@@ -182,6 +116,7 @@ __global__ __launch_bounds__(256) void sparse_attn_kernel(AttnParams p) {
       d = group_sum<LPR>(d);
       s[u] = ok[u] ? d : -INFINITY;
       mnew = fmaxf(mnew, s[u]);
+      if (WP && ok[u] && sub == 0) p.probs[n * p.probs_stride_n + e0 + u * KPI + grp] = d;
     }
     if (mnew == -INFINITY) continue;  // this group has seen no entry yet
     const float alpha = __expf(m - mnew);
@@ -217,13 +152,20 @@ __global__ __launch_bounds__(256) void sparse_attn_kernel(AttnParams p) {
     m = M;
   }
 
+  if (WP && sub == 0) {                                    // every group: the entries it scored in pass 1
+    const int64_t ridx = ((int64_t)n * p.H + h) * p.T_dst + t;
+    float c = (l > 0.f) ? (1.0f / l) : 0.f;
+    if (p.row_scale) c *= p.row_scale[ridx];
+    float* pr = p.probs + n * p.probs_stride_n;
+    for (int e = beg + grp; e < end; e += KPI) pr[e] = __expf(pr[e] - m) * c;
+  }
   if (grp == 0 && dact) {
     const int64_t ridx = ((int64_t)n * p.H + h) * p.T_dst + t;
     float scale = (l > 0.f) ? (1.0f / l) : 0.f;
     if (p.row_scale) scale *= p.row_scale[ridx];
     float o[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) o[j] = acc[j] * scale;
+    for (int j = 0; j < VEC; ++j) o[j] = (l > 0.f) ? acc[j] * scale : 0.f;   // empty row: 0 even if the clamped key's V is not finite
     if (p.mix) {
       const float a = p.mix[ridx];
       const T* ap = reinterpret_cast<const T*>(p.avg) + n * p.as[0] + h * p.as[1] + t * p.as[2] + sub * VEC;
@@ -242,7 +184,7 @@ __global__ __launch_bounds__(256) void sparse_attn_kernel(AttnParams p) {
 // softmax; nothing is merged across groups.  A wave therefore has 64/LPR independent
 // (offsets -> col -> K/V) load chains in flight instead of one, which is what the wave-per-row mapping lacks.
 // Workgroup = 4 waves = 256/LPR consecutive query rows of one (n, h).
-template <typename T, typename TO, int LPR, int U, int NWB = 4>
+template <typename T, typename TO, int LPR, int U, bool WP, int NWB = 4>
 __global__ __launch_bounds__(NWB * 64) void sparse_attn_rows_kernel(AttnParams p) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr int RPW = 64 / LPR;       // rows per wave
@@ -315,6 +257,7 @@ __global__ __launch_bounds__(NWB * 64) void sparse_attn_rows_kernel(AttnParams p
           d = group_sum<LPR>(d);
           s[u] = ok[u] ? d : -INFINITY;
           mnew = fmaxf(mnew, s[u]);
+          if (WP && ok[u] && sub == u0 + u) p.probs[n * p.probs_stride_n + beg + i0 + u0 + u] = d;   // entry j by lane j % LPR
         }
         const float msafe = (mnew == -INFINITY) ? 0.f : mnew;     // rows that have seen nothing yet: exp(-inf - 0) = 0
         const float alpha = __expf(m - msafe);
@@ -335,13 +278,20 @@ __global__ __launch_bounds__(NWB * 64) void sparse_attn_rows_kernel(AttnParams p
     }
   }
 
+  if (WP && rowok) {
+    const int64_t ridx = ((int64_t)n * p.H + h) * p.T_dst + t;
+    float c = (l > 0.f) ? (1.0f / l) : 0.f;
+    if (p.row_scale) c *= p.row_scale[ridx];
+    float* pr = p.probs + n * p.probs_stride_n;
+    for (int e = beg + sub; e < end; e += LPR) pr[e] = __expf(pr[e] - m) * c;
+  }
   if (rowok && dact) {
     const int64_t ridx = ((int64_t)n * p.H + h) * p.T_dst + t;
     float scale = (l > 0.f) ? (1.0f / l) : 0.f;
     if (p.row_scale) scale *= p.row_scale[ridx];
     float o[VEC];
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) o[j] = acc[j] * scale;
+    for (int j = 0; j < VEC; ++j) o[j] = (l > 0.f) ? acc[j] * scale : 0.f;   // empty row: 0 even if the clamped key's V is not finite
     if (p.mix) {
       const float a = p.mix[ridx];
       const T* ap = reinterpret_cast<const T*>(p.avg) + n * p.as[0] + h * p.as[1] + (int64_t)t * p.as[2] + sub * VEC;
@@ -377,7 +327,7 @@ template <> __device__ inline void unpack2<__half>(uint32_t r, float* f) {
 template <typename TO> __device__ inline void store2(TO* dst, float a, float b) { *reinterpret_cast<uint32_t*>(dst) = pack2<TO>(a, b); }
 template <> __device__ inline void store2<float>(float* dst, float a, float b) { *reinterpret_cast<float2*>(dst) = make_float2(a, b); }
 
-template <typename T, typename TO, int U, int NWB = 4>
+template <typename T, typename TO, int U, bool WP, int NWB = 4>
 __global__ __launch_bounds__(NWB * 64) void sparse_attn_rows80_kernel(AttnParams p) {
   constexpr int LPR = 8, VEC = 8, XT = 2, DM = LPR * VEC;     // DM = 64 elements in the 16-byte fragments
   constexpr int RPW = 64 / LPR, RPB = NWB * RPW;
@@ -447,6 +397,7 @@ __global__ __launch_bounds__(NWB * 64) void sparse_attn_rows80_kernel(AttnParams
           d = group_sum<LPR>(d);
           s[u] = ok[u] ? d : -INFINITY;
           mnew = fmaxf(mnew, s[u]);
+          if (WP && ok[u] && sub == u0 + u) p.probs[n * p.probs_stride_n + beg + i0 + u0 + u] = d;
         }
         const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
         const float alpha = __expf(m - msafe);
@@ -468,13 +419,20 @@ __global__ __launch_bounds__(NWB * 64) void sparse_attn_rows80_kernel(AttnParams
     }
   }
 
+  if (WP && rowok) {
+    const int64_t ridx = ((int64_t)n * p.H + h) * p.T_dst + t;
+    float c = (l > 0.f) ? (1.0f / l) : 0.f;
+    if (p.row_scale) c *= p.row_scale[ridx];
+    float* pr = p.probs + n * p.probs_stride_n;
+    for (int e = beg + sub; e < end; e += LPR) pr[e] = __expf(pr[e] - m) * c;
+  }
   if (rowok) {
     const int64_t ridx = ((int64_t)n * p.H + h) * p.T_dst + t;
     float scale = (l > 0.f) ? (1.0f / l) : 0.f;
     if (p.row_scale) scale *= p.row_scale[ridx];
     float o[VEC + XT];
 #pragma unroll
-    for (int j = 0; j < VEC + XT; ++j) o[j] = acc[j] * scale;
+    for (int j = 0; j < VEC + XT; ++j) o[j] = (l > 0.f) ? acc[j] * scale : 0.f;
     if (p.mix) {
       const float a = p.mix[ridx];
       const T* ap = reinterpret_cast<const T*>(p.avg) + n * p.as[0] + h * p.as[1] + (int64_t)t * p.as[2];
@@ -609,76 +567,53 @@ static int lanes_per_row(int D, int vec) {
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 static bool strides_ok(const int64_t* s, int vec) { return s[0] % vec == 0 && s[1] % vec == 0 && s[2] % vec == 0; }
 
-static int attn_variant() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("SEA_ATTN_VARIANT");      // 0 = wave per row, 1 = lane-group per row (default)
-    v = e ? atoi(e) : 1;
-  }
-  return v;
-}
-
-template <typename T, typename TO>
-static int launch_attn(AttnParams p, hipStream_t s) {
+template <typename T, typename TO, bool WP>
+static int launch_attn_wp(AttnParams p, hipStream_t s) {
   constexpr int VEC = Elem<T>::VEC;
   const int lpr = lanes_per_row(p.D, VEC);
   const int NH = p.N * p.H;
   const int esz = (int)sizeof(T);
   const bool small = p.T_src < (1 << 24) && p.ks[2] * esz < (1 << 24) && p.vs[2] * esz < (1 << 24) &&
                      (int64_t)p.T_src * p.ks[2] * esz < (1ll << 31) && (int64_t)p.T_src * p.vs[2] * esz < (1ll << 31);
-  static const int nwb_env = [] { const char* e = getenv("SEA_ATTN_WAVES"); return e ? atoi(e) : 4; }();
-  if (attn_variant() == 1 && lpr == 8 && small && nwb_env != 4) {   // experiment: larger workgroups (same-pair rows share a CU)
-    const int nwb = nwb_env >= 16 ? 16 : 8;
-    const int rpb = nwb * 8;
-    p.TB = (p.T_dst + rpb - 1) / rpb;
-    const int64_t blocks = (int64_t)8 * ((NH + 7) / 8) * p.TB;
-    dim3 grid((unsigned)blocks), block(nwb * 64);
-    if (nwb == 16) hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 8, 4, 16>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 8, 4, 8>), grid, block, 0, s, p);
-    return SEA_OK;
-  }
   if constexpr (sizeof(T) == 2) {
-    static const bool no80 = [] { const char* e = getenv("SEA_ATTN_NO80"); return e && e[0] == '1'; }();   // A/B hook
-    if (attn_variant() == 1 && p.D == 80 && small && !no80) {      // d = 80: 8 lanes x (8 + 2) elements per row
+    if (p.D == 80 && small) {                          // d = 80: 8 lanes x (8 + 2) elements per row
       const int rpb = 4 * 8;
       p.TB = (p.T_dst + rpb - 1) / rpb;
       const int64_t blocks = (int64_t)8 * ((NH + 7) / 8) * p.TB;
-      static const int u80 = [] { const char* e = getenv("SEA_ATTN_U"); return e ? atoi(e) : 4; }();       // A/B hook
-      if (u80 == 2) hipLaunchKernelGGL((sparse_attn_rows80_kernel<T, TO, 2>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-      else if (u80 == 8) hipLaunchKernelGGL((sparse_attn_rows80_kernel<T, TO, 8>), dim3((unsigned)blocks), dim3(256), 0, s, p);
-      else hipLaunchKernelGGL((sparse_attn_rows80_kernel<T, TO, 4>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+      hipLaunchKernelGGL((sparse_attn_rows80_kernel<T, TO, 4, WP>), dim3((unsigned)blocks), dim3(256), 0, s, p);
       return SEA_OK;
     }
   }
-  if (attn_variant() == 1 && lpr <= 16 && small) {
+  if (lpr <= 16 && small) {
     const int rpb = 4 * (64 / lpr);
     p.TB = (p.T_dst + rpb - 1) / rpb;
     const int64_t blocks = (int64_t)8 * ((NH + 7) / 8) * p.TB;
     dim3 grid((unsigned)blocks), block(256);
     switch (lpr) {
-      case 4: hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 4, 4>), grid, block, 0, s, p); break;
-      case 8: {
-        static const int u_env = [] { const char* e = getenv("SEA_ATTN_U"); return e ? atoi(e) : 4; }();   // A/B hook
-        if (u_env == 2) hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 8, 2>), grid, block, 0, s, p);
-        else if (u_env == 8) hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 8, 8>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 8, 4>), grid, block, 0, s, p);
-        break;
-      }
-      default: hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 16, 4>), grid, block, 0, s, p); break;
+      case 4: hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 4, 4, WP>), grid, block, 0, s, p); break;
+      case 8: hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 8, 4, WP>), grid, block, 0, s, p); break;
+      default: hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 16, 4, WP>), grid, block, 0, s, p); break;
     }
     return SEA_OK;
   }
   const int64_t blocks = (int64_t)8 * ((NH + 7) / 8) * p.TB;
   dim3 grid((unsigned)blocks), block(256);
   switch (lpr) {
-    case 4: hipLaunchKernelGGL((sparse_attn_kernel<T, TO, 4, 2>), grid, block, 0, s, p); break;
-    case 8: hipLaunchKernelGGL((sparse_attn_kernel<T, TO, 8, 4>), grid, block, 0, s, p); break;
-    case 16: hipLaunchKernelGGL((sparse_attn_kernel<T, TO, 16, 4>), grid, block, 0, s, p); break;
-    case 32: hipLaunchKernelGGL((sparse_attn_kernel<T, TO, 32, 4>), grid, block, 0, s, p); break;
-    case 64: hipLaunchKernelGGL((sparse_attn_kernel<T, TO, 64, 4>), grid, block, 0, s, p); break;
+    case 4: hipLaunchKernelGGL((sparse_attn_kernel<T, TO, 4, 2, WP>), grid, block, 0, s, p); break;
+    case 8: hipLaunchKernelGGL((sparse_attn_kernel<T, TO, 8, 4, WP>), grid, block, 0, s, p); break;
+    case 16: hipLaunchKernelGGL((sparse_attn_kernel<T, TO, 16, 4, WP>), grid, block, 0, s, p); break;
+    case 32: hipLaunchKernelGGL((sparse_attn_kernel<T, TO, 32, 4, WP>), grid, block, 0, s, p); break;
+    case 64: hipLaunchKernelGGL((sparse_attn_kernel<T, TO, 64, 4, WP>), grid, block, 0, s, p); break;
     default: return SEA_EUNSUPPORTED;
   }
   return SEA_OK;
+}
+
+// Kernel choice (fixed, no run-time switches): 16-bit d = 80 -> rows80; rows of <= 16 lanes with 32-bit byte offsets ->
+// lane-group-per-row kernel; anything else (fp32 d >= 128, huge strides) -> wave-per-row kernel.
+template <typename T, typename TO>
+static int launch_attn(const AttnParams& p, hipStream_t s) {
+  return p.probs ? launch_attn_wp<T, TO, true>(p, s) : launch_attn_wp<T, TO, false>(p, s);
 }
 
 template <typename T, typename I>
@@ -723,13 +658,13 @@ static int check_dtype(const char* name, int dtype) {
   return SEA_OK;
 }
 
-extern "C" int sea_sparse_attention(const void* q, const void* k, const void* v, int dtype, int64_t N, int64_t H,
-                                    int64_t T_dst, int64_t T_src, int64_t D, const int64_t* q_strides,
-                                    const int64_t* k_strides, const int64_t* v_strides, const int32_t* crow,
-                                    const int32_t* col, int64_t col_stride_n, const int32_t* head_off,
-                                    const float* row_scale, const void* avg, const int64_t* avg_strides,
-                                    const float* mix, void* out, int out_dtype, const int64_t* out_strides,
-                                    sea_stream_t stream) {
+extern "C" int sea_sparse_attention_ex(const void* q, const void* k, const void* v, int dtype, int64_t N, int64_t H,
+                                       int64_t T_dst, int64_t T_src, int64_t D, const int64_t* q_strides,
+                                       const int64_t* k_strides, const int64_t* v_strides, const int32_t* crow,
+                                       const int32_t* col, int64_t col_stride_n, const int32_t* head_off,
+                                       const float* row_scale, const void* avg, const int64_t* avg_strides,
+                                       const float* mix, void* out, int out_dtype, const int64_t* out_strides,
+                                       float* probs_out, int64_t probs_stride_n, int flags, sea_stream_t stream) {
   const char* nm = "sea_sparse_attention";
   SEA_REQUIRE(q && k && v && crow && col && head_off && out && q_strides && k_strides && v_strides && out_strides,
               SEA_EINVAL, "%s: null pointer", nm);
@@ -738,6 +673,8 @@ extern "C" int sea_sparse_attention(const void* q, const void* k, const void* v,
   SEA_REQUIRE((mix == nullptr) == (avg == nullptr), SEA_EINVAL, "%s: avg and mix go together", nm);
   SEA_REQUIRE(!avg || avg_strides, SEA_EINVAL, "%s: avg_strides is null", nm);
   SEA_REQUIRE(N > 0 && H > 0 && T_dst > 0 && T_src > 0 && D > 0, SEA_EINVAL, "%s: bad shape", nm);
+  const int path = flags & 0xff;
+  SEA_REQUIRE(path == SEA_ATTN_AUTO || path == SEA_ATTN_GATHER || path == SEA_ATTN_TILE, SEA_EINVAL, "%s: bad path %d", nm, path);
   const int vec = dtype == SEA_F32 ? 4 : 8;
   SEA_REQUIRE(D % vec == 0 && D <= 64 * vec, SEA_EUNSUPPORTED, "%s: D=%lld must be a multiple of %d and <= %d", nm,
               (long long)D, vec, 64 * vec);
@@ -756,15 +693,38 @@ extern "C" int sea_sparse_attention(const void* q, const void* k, const void* v,
   p.N = (int)N; p.H = (int)H; p.T_dst = (int)T_dst; p.T_src = (int)T_src; p.D = (int)D;
   p.crow = crow; p.col = col; p.col_stride_n = col_stride_n; p.head_off = head_off;
   p.row_scale = row_scale; p.avg = avg; p.mix = mix; p.out = out;
+  p.probs = probs_out; p.probs_stride_n = probs_stride_n;
   p.TB = (int)((T_dst + 3) / 4);
   hipStream_t s = (hipStream_t)stream;
+  const bool tile_ok = attn_tile_supported(dtype, (int)D, (int)T_src, p) && probs_out == nullptr;
+  if (path == SEA_ATTN_TILE) {
+    SEA_REQUIRE(tile_ok, SEA_EUNSUPPORTED, "%s: the tile kernel takes 16-bit data with D in {64, 80, 128} and no probs_out", nm);
+  }
   int rc;
+  if (path == SEA_ATTN_TILE || (path == SEA_ATTN_AUTO && tile_ok)) {
+    rc = launch_attn_tile(p, dtype, out_dtype, flags, s);
+    SEA_REQUIRE(rc == SEA_OK, rc, "%s: tile kernel launch parameters rejected (flags 0x%x)", nm, flags);
+    SEA_CHECK_LAUNCH(nm);
+    return SEA_OK;
+  }
   if (dtype == SEA_F32) rc = launch_attn<float, float>(p, s);
   else if (dtype == SEA_F16) rc = out_dtype == SEA_F32 ? launch_attn<__half, float>(p, s) : launch_attn<__half, __half>(p, s);
   else rc = out_dtype == SEA_F32 ? launch_attn<__hip_bfloat16, float>(p, s) : launch_attn<__hip_bfloat16, __hip_bfloat16>(p, s);
   SEA_REQUIRE(rc == SEA_OK, rc, "%s: unsupported head size %lld", nm, (long long)D);
   SEA_CHECK_LAUNCH(nm);
   return SEA_OK;
+}
+
+extern "C" int sea_sparse_attention(const void* q, const void* k, const void* v, int dtype, int64_t N, int64_t H,
+                                    int64_t T_dst, int64_t T_src, int64_t D, const int64_t* q_strides,
+                                    const int64_t* k_strides, const int64_t* v_strides, const int32_t* crow,
+                                    const int32_t* col, int64_t col_stride_n, const int32_t* head_off,
+                                    const float* row_scale, const void* avg, const int64_t* avg_strides,
+                                    const float* mix, void* out, int out_dtype, const int64_t* out_strides,
+                                    sea_stream_t stream) {
+  return sea_sparse_attention_ex(q, k, v, dtype, N, H, T_dst, T_src, D, q_strides, k_strides, v_strides, crow, col,
+                                 col_stride_n, head_off, row_scale, avg, avg_strides, mix, out, out_dtype, out_strides,
+                                 nullptr, 0, SEA_ATTN_AUTO, stream);
 }
 
 extern "C" int64_t sea_sparse_attention_bytes(int64_t Z, int64_t N, int64_t H, int64_t T_dst, int64_t D, int elem_bytes) {

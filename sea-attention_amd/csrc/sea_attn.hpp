@@ -1,0 +1,74 @@
+// Shared declarations of the fused sparse-attention kernels (sea_attn.hip: gather kernels; sea_attn_tile.hip: MFMA tile kernel).
+#pragma once
+#include "sea_common.hpp"
+
+namespace sea {
+
+struct AttnParams {
+  const void *q, *k, *v;
+  int64_t qs[3], ks[3], vs[3];
+  int N, H, T_dst, T_src, D;
+  const int32_t* crow;
+  const int32_t* col;
+  int64_t col_stride_n;
+  const int32_t* head_off;
+  const float* row_scale;
+  const void* avg;
+  int64_t as[3];
+  const float* mix;
+  void* out;
+  int64_t os[3];
+  float* probs;            // optional (N, probs_stride_n): rs * softmax per entry (gather kernels only)
+  int64_t probs_stride_n;
+  int TB;  // row blocks per (n, h): ceil(T_dst / 4)
+};
+
+template <typename TO, int VEC> __device__ inline void store_frag(TO* dst, const float* f);
+template <> __device__ inline void store_frag<float, 4>(float* dst, const float* f) {
+  *reinterpret_cast<float4*>(dst) = make_float4(f[0], f[1], f[2], f[3]);
+}
+template <> __device__ inline void store_frag<float, 8>(float* dst, const float* f) {
+  *reinterpret_cast<float4*>(dst) = make_float4(f[0], f[1], f[2], f[3]);
+  *reinterpret_cast<float4*>(dst + 4) = make_float4(f[4], f[5], f[6], f[7]);
+}
+template <> __device__ inline void store_frag<__hip_bfloat16, 8>(__hip_bfloat16* dst, const float* f) {
+  union { uint4 u; __hip_bfloat16 h[8]; } r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.h[i] = __float2bfloat16(f[i]);
+  *reinterpret_cast<uint4*>(dst) = r.u;
+}
+template <> __device__ inline void store_frag<__half, 8>(__half* dst, const float* f) {
+  union { uint4 u; __half h[8]; } r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.h[i] = __float2half(f[i]);
+  *reinterpret_cast<uint4*>(dst) = r.u;
+}
+template <> __device__ inline void store_frag<__hip_bfloat16, 4>(__hip_bfloat16* dst, const float* f) {
+  union { uint2 u; __hip_bfloat16 h[4]; } r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.h[i] = __float2bfloat16(f[i]);
+  *reinterpret_cast<uint2*>(dst) = r.u;
+}
+template <> __device__ inline void store_frag<__half, 4>(__half* dst, const float* f) {
+  union { uint2 u; __half h[4]; } r;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) r.h[i] = __float2half(f[i]);
+  *reinterpret_cast<uint2*>(dst) = r.u;
+}
+
+// (n, h, row-block) from blockIdx, XCD-aware: blocks b and b+8 share an XCD (observed dispatch
+// order; only affects L2 locality).  Returns false if this block has no work.
+__device__ inline bool map_block(int NH, int TB, int* pair, int* tb) {
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int pl = slot / TB;
+  *tb = slot - pl * TB;
+  *pair = pl * 8 + xcd;
+  return *pair < NH;
+}
+
+// launchers of the MFMA tile kernel (sea_attn_tile.hip); `flags`: see SEA_ATTN_* in sea_hip.h
+bool attn_tile_supported(int dtype, int D, int T_src, const AttnParams& p);
+int launch_attn_tile(const AttnParams& p, int dtype, int out_dtype, int flags, hipStream_t s);
+
+}  // namespace sea

@@ -959,16 +959,10 @@ static int launch_perf_bf16(const PerfParams& p, hipStream_t s) {
 template <int NBT>
 constexpr int64_t perf_bf16_carry_floats() { return (int64_t)NBT * 4 * 512 + ((NBT + 1) / 2) * 32 + 512; }
 
-// SEA_PERFORMER_FP32=1 keeps bf16 data on the fp32-MFMA kernel (A/B timing, parity debugging)
-static bool perf_force_fp32() {
-  static const bool v = [] { const char* e = getenv("SEA_PERFORMER_FP32"); return e && e[0] == '1'; }();
-  return v;
-}
-
 template <typename T>
 static int dispatch_perf(const PerfParams& p, int D, int nbt, hipStream_t s) {
   if constexpr (!std::is_same<T, float>::value) {           // 16-bit data, d = 64: split-operand 16-bit MFMA kernel
-    if (D == 64 && !perf_force_fp32()) {
+    if (D == 64) {
       if (nbt <= 3) return launch_perf_bf16<T, 3>(p, s);
       if (nbt <= 5) return launch_perf_bf16<T, 5>(p, s);
     }
@@ -992,7 +986,7 @@ extern "C" int sea_debug_perf_stamps(unsigned long long* host8) {
 
 // carry floats per (n, h, segment) of the kernel dispatch_perf picks (0: unsupported shape)
 static int64_t perf_carry_floats_for(int dtype, int D, int nbt) {
-  if (dtype != SEA_F32 && D == 64 && !perf_force_fp32()) {
+  if (dtype != SEA_F32 && D == 64) {
     if (nbt <= 3) return perf_bf16_carry_floats<3>();
     if (nbt <= 5) return perf_bf16_carry_floats<5>();
   }
@@ -1008,6 +1002,11 @@ static int64_t perf_carry_floats_for(int dtype, int D, int nbt) {
 static int64_t perf_seg_len(int64_t T, int64_t nseg) {
   const int64_t chunks = (T + 63) / 64;
   return ((chunks + nseg - 1) / nseg) * 64;
+}
+
+// avg_out comes from the 16-bit MFMA kernel only (16-bit data, d = 64, up to 80 features)
+extern "C" int sea_performer_avg_supported(int64_t D, int64_t nb, int dtype) {
+  return (dtype == SEA_BF16 || dtype == SEA_F16) && D == 64 && nb > 0 && nb <= 80;
 }
 
 extern "C" int sea_performer_plan(int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb, int dtype,
@@ -1049,7 +1048,7 @@ static int perf_entry(const char* nm, const void* q, const void* k, const void* 
               SEA_EUNSUPPORTED, "%s: rows must be 16-byte aligned", nm);
   PerfParams p;
   p.q = q; p.k = k; p.v = v; p.pos = pos; p.W = proj; p.out = out; p.avg = avg_out;
-  SEA_REQUIRE(avg_out == nullptr || ((dtype == SEA_BF16 || dtype == SEA_F16) && D == 64 && nb <= 80 && !perf_force_fp32() && ((uintptr_t)avg_out & 15) == 0),
+  SEA_REQUIRE(avg_out == nullptr || (sea_performer_avg_supported(D, nb, dtype) && ((uintptr_t)avg_out & 15) == 0),
               SEA_EUNSUPPORTED, "%s: avg_out needs the 16-bit MFMA kernel (bf16 / fp16 data, D = 64)", nm);
   for (int i = 0; i < 3; ++i) { p.qs[i] = q_strides[i]; p.ks[i] = k_strides[i]; p.vs[i] = v_strides[i]; }
   p.pos_stride = pos_stride;

@@ -100,6 +100,7 @@ def z_capacity(keep_cpu: torch.Tensor, H, T_dst, T_src, T_m, max_k, is_causal=Tr
 # ------------------------------------------------------------------------------------------------
 # fused path: probs -> FlatCSR
 # ------------------------------------------------------------------------------------------------
+@_lib.device_guarded
 def topk_to_csr(probs: torch.Tensor, keep: torch.Tensor, k: int, target_width: Optional[int] = None,
                 is_causal: bool = True, z_cap: Optional[int] = None, want_mask: bool = False):
     """Grouped top-k + nearest-neighbour interpolation to a FlatCSR in three launches, no host sync.
@@ -132,6 +133,7 @@ def topk_to_csr(probs: torch.Tensor, keep: torch.Tensor, k: int, target_width: O
     return csr_from_selection(bits, row_nnz, head_off, H, T_m, T_src, int(k), is_causal, z_cap, keep), mask
 
 
+@_lib.device_guarded
 def csr_from_selection(bits: torch.Tensor, row_nnz: torch.Tensor, head_off: torch.Tensor, H: int, T_m: int, T_src: int,
                        k: int, is_causal: bool = True, z_cap: Optional[int] = None, keep: Optional[torch.Tensor] = None):
     """Row scan + emit: the (bits, row_nnz, head_off) of a selection launch (sea_topk_select or the fused
@@ -151,6 +153,7 @@ def csr_from_selection(bits: torch.Tensor, row_nnz: torch.Tensor, head_off: torc
     return FlatCSR(crow, col, head_off, H, T_src, bits=bits, row_nnz=row_nnz)
 
 
+@_lib.device_guarded
 def topk_mask(probs: torch.Tensor, keep: torch.Tensor, k: int, target_width=None, is_causal=True) -> torch.Tensor:
     """a6 alone: 0/1 fp32 compressed mask (N,H,T_dst,T_m)."""
     lib = _lib.load()
@@ -172,17 +175,25 @@ def topk_mask(probs: torch.Tensor, keep: torch.Tensor, k: int, target_width=None
     return mask
 
 
+_PATHS = {"auto": _lib.SEA_ATTN_AUTO, "gather": _lib.SEA_ATTN_GATHER, "tile": _lib.SEA_ATTN_TILE}
+
+
+@_lib.device_guarded
 def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = None,
                      avg: Optional[torch.Tensor] = None, mix: Optional[torch.Tensor] = None,
-                     out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
-    """Fused SDDMM + per-(row,head) softmax + row scale + SpMM (+ mix), one wave per (n,h,t).
+                     out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None,
+                     path: str = "auto", want_probs: bool = False, row_tiles: int = 0, key_window: int = 0):
+    """Fused SDDMM + per-(row,head) softmax + row scale + SpMM (+ mix) over the flat CSR (`sea_sparse_attention_ex`).
 
     q (N,H,T_dst,D), k/v (N,H,T_src,D), any [n,h,t] strides, feature stride 1.
     row_scale, mix: fp32 (N,H,T_dst) contiguous (already passed through sigmoid); avg like v.
     out: optional preallocated tensor viewed as (N,H,T_dst,D) with arbitrary strides -- pass a
     permuted view of an (N,T_dst,H*D) buffer to get the layout of attention.py:1279-1282 directly.
     Default output: fp32 (N,H,T_dst,D) (flat_csr_sdbmm.py:347 returns fp32).
-    """
+    path: "auto" | "gather" (row-indexed gather kernels) | "tile" (MFMA tile kernel: 16-bit data, D in {64,80,128});
+    row_tiles / key_window tune the tile kernel (0 = defaults).
+    want_probs: also return the per-entry values rs * softmax (fp32, laid out like csr.col) -- what the reference
+    hands out as `partial_attention_probs` (attention.py:1162-1171); returns (out, probs)."""
     lib = _lib.load()
     _lib.require_gpu(q, k, v, csr.crow)
     N, H, T_dst, D = q.shape
@@ -198,13 +209,19 @@ def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = 
     if mix is not None:
         assert avg is not None and avg.shape == (N, H, T_dst, D) and avg.dtype == q.dtype
         assert mix.dtype == torch.float32 and mix.shape == (N, H, T_dst) and mix.is_contiguous()
-    _lib.check(lib.sea_sparse_attention(
+    probs = torch.zeros(csr.col.shape, dtype=torch.float32, device=q.device) if want_probs else None
+    flags = _PATHS[path] | ((int(row_tiles) & 0xf) << 8)
+    if key_window:
+        assert key_window & (key_window - 1) == 0, "key_window is a power of two"
+        flags |= (int(key_window).bit_length() - 1) << 12
+    _lib.check(lib.sea_sparse_attention_ex(
         _p(q), _p(k), _p(v), _lib.dtype_code(q.dtype), N, H, T_dst, T_src, D,
         _lib.strides3(q), _lib.strides3(k), _lib.strides3(v),
         _p(csr.crow), _p(csr.col), csr.col.stride(0), _p(csr.head_off),
         _p(row_scale), _p(avg), _lib.strides3(avg) if avg is not None else None, _p(mix),
-        _p(out), _lib.dtype_code(out.dtype), _lib.strides3(out), _lib.stream_ptr()), "sea_sparse_attention")
-    return out
+        _p(out), _lib.dtype_code(out.dtype), _lib.strides3(out),
+        _p(probs), probs.stride(0) if probs is not None else 0, flags, _lib.stream_ptr()), "sea_sparse_attention")
+    return (out, probs) if want_probs else out
 
 
 def sparse_attention_bytes(Z: int, N: int, H: int, T_dst: int, D: int, elem_bytes: int) -> int:
@@ -222,6 +239,7 @@ def _csr_parts(t: torch.Tensor):
     return crow.contiguous(), col.contiguous(), val
 
 
+@_lib.device_guarded
 def resize_from_m_to_t_csr(x, masked_fill_value, k, target_width=None, training=False, need_assert=False,
                            is_causal=True, max_col_z=None, benchmarking=False, oversampled=None):
     """Drop-in for ops/kernels/causal_resize_m_to_t.py:910-1007 (METHOD 1, scan_col :631-762).
@@ -258,6 +276,7 @@ def resize_from_m_to_t_csr(x, masked_fill_value, k, target_width=None, training=
     return torch.sparse_csr_tensor(crow, col, values, size=(N, T_dst, H * T_src))
 
 
+@_lib.device_guarded
 def flat_csr_masked_bmm(a: torch.Tensor, b: torch.Tensor, mask: torch.Tensor, max_z_per_row: int = None):
     """Drop-in for flat_csr_masked_bmm.py:137-195 (SDDMM).  max_z_per_row is accepted and unused:
     the HIP kernel walks each row's own length, so the reference's `.item()` sync (:162-164) is gone."""
@@ -287,6 +306,7 @@ def flat_csr_masked_bmm(a: torch.Tensor, b: torch.Tensor, mask: torch.Tensor, ma
     return torch.sparse_csr_tensor(crow, col, out_values, size=mask.shape)
 
 
+@_lib.device_guarded
 def flat_csr_softmax(scores: torch.Tensor, H: int, T_SRC: int, max_z_per_row: int = None):
     """Drop-in for flat_csr_softmax.py:127-176."""
     assert scores.is_sparse_csr
@@ -303,6 +323,7 @@ def flat_csr_softmax(scores: torch.Tensor, H: int, T_SRC: int, max_z_per_row: in
     return torch.sparse_csr_tensor(crow, col, out_values, size=scores.shape)
 
 
+@_lib.device_guarded
 def flat_csr_elmul(probs: torch.Tensor, dense: torch.Tensor, max_z_per_row: int = None):
     """Drop-in for flat_csr_elmul.py:110-162.  `dense` may be a stride-0 expanded view
     (the module passes one, attention.py:1170-1171)."""
@@ -324,6 +345,7 @@ def flat_csr_elmul(probs: torch.Tensor, dense: torch.Tensor, max_z_per_row: int 
     return torch.sparse_csr_tensor(crow, col, out_values, size=probs.shape)
 
 
+@_lib.device_guarded
 def flat_csr_sdbmm(scores: torch.Tensor, value_layer: torch.Tensor, T_M: int, max_z_per_row: int = None,
                    benchmarking: bool = False):
     """Drop-in for flat_csr_sdbmm.py:323-439 (SpMM).  Output fp32 (N,H,T_dst,D) like the reference

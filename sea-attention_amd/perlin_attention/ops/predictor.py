@@ -18,12 +18,22 @@ def _p(t):
 _prep_cache = {}
 
 
+def clear_prep_cache():
+    """Drop every cached re-layout of constant weights.  The cache notices new tensors, `.to(device)` moves,
+    storage swaps and in-place autograd-visible edits by itself; an edit made behind autograd's back
+    (`param.data.mul_()`, `param.data.copy_()`: EMA swaps, pruning) bumps no version counter, so whoever does
+    that calls this afterwards.  `PerlinAttention.load_state_dict / train / _apply` call it (attention.py)."""
+    _prep_cache.clear()
+
+
 def _cached(tag, tensors, dtype, build):
     """Small re-layouts of constant weights (inference), cached per source tensor.  An entry is valid only while
-    the very same tensor objects (weak references to the view bases) are alive and unmodified (`_version`): a freed
-    tensor whose address is handed to a new one of the same shape must not hit."""
+    the very same tensor objects (weak references to the view bases) are alive, unmodified (`_version`) and still
+    sit at the same address on the same device: a freed tensor whose address is handed to a new one of the same
+    shape must not hit, and neither may a parameter after `module.to(device)` / `param.data = other`."""
     bases = [t._base if t._base is not None else t for t in tensors]
-    key = (tag, dtype) + tuple((id(b), t.storage_offset(), tuple(t.shape), tuple(t.stride())) for b, t in zip(bases, tensors))
+    key = (tag, dtype) + tuple((id(b), t.storage_offset(), tuple(t.shape), tuple(t.stride()), t.data_ptr(), str(t.device))
+                               for b, t in zip(bases, tensors))
     hit = _prep_cache.get(key)
     if hit is not None:
         refs, versions, value = hit
@@ -36,6 +46,7 @@ def _cached(tag, tensors, dtype, build):
     return value
 
 
+@_lib.device_guarded
 def split_layernorm(x: torch.Tensor, splits: int, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5,
                     gelu: bool = False):
     """ChannelSplit(splits) followed by LayerNorm over the new (narrower) last dim, optionally followed by
@@ -53,6 +64,7 @@ def split_layernorm(x: torch.Tensor, splits: int, weight: torch.Tensor, bias: to
     return out
 
 
+@_lib.device_guarded
 def predictor_tail(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor,
                    up: int, T_m: int, eps: float = 1e-5, want_scores: bool = False):
     """upsample(1,up) -> 1x1 conv (pad 1 on width) -> area resize to T_m -> LayerNorm(T_m) -> softmax.
@@ -99,6 +111,7 @@ def predictor_tail_select_supported(y: torch.Tensor, H: int, T_m: int) -> bool:
             and (y.dim() == 5 or y.stride(1) == 1))
 
 
+@_lib.device_guarded
 def predictor_tail_select(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor,
                           up: int, T_m: int, keep: torch.Tensor, k: int, T_src: int, is_causal: bool = True,
                           eps: float = 1e-5, want_scores: bool = False):
@@ -142,6 +155,7 @@ def predictor_tail_select(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.T
     return probs, scores, (bits, row_nnz, head_off)
 
 
+@_lib.device_guarded
 def cumavg(v: torch.Tensor, out: Optional[torch.Tensor] = None, n_slices: int = None) -> torch.Tensor:
     """Causal cumulative average over the time axis of (N,H,T,D), fp32 accumulation, dtype preserved.
     `out`: optional preallocated contiguous (N,H,T,D) result (lets a caller launch this on a side stream)."""
@@ -174,8 +188,11 @@ def performer_supported(D: int, nb: int) -> bool:
 
 
 def performer_avg_supported(q: torch.Tensor, nb: int) -> bool:
-    """The bf16 Performer kernel (bf16 data, d = 64) can emit the cumulative average of v in the same launch."""
-    return q.dtype in (torch.bfloat16, torch.float16) and q.shape[-1] == 64 and (nb + 15) // 16 <= 5
+    """Can the Performer launch also emit the cumulative average of v?  Asked of the library (one predicate on both
+    sides of the ABI: `sea_performer_avg_supported`)."""
+    if q.dtype not in (torch.bfloat16, torch.float16):
+        return False
+    return bool(_lib.load().sea_performer_avg_supported(int(q.shape[-1]), int(nb), _lib.dtype_code(q.dtype)))
 
 
 _PLAN_CACHE = {}
@@ -193,6 +210,7 @@ def performer_plan(N: int, H: int, T: int, D: int, nb: int, dtype) -> tuple:
     return _PLAN_CACHE[key]
 
 
+@_lib.device_guarded
 def performer_value(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torch.Tensor,
                     projection: torch.Tensor, want_avg: bool = False, n_segments: int = None):
     """Causal Performer estimator + both concatenations (one launch; two when the rows are cut into segments).
@@ -230,6 +248,7 @@ def performer_value(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torc
     return (out, avg) if want_avg else out
 
 
+@_lib.device_guarded
 def performer_step(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torch.Tensor, projection: torch.Tensor,
                    state_in: torch.Tensor = None, t_base: int = 0, want_avg: bool = True, n_segments: int = 1):
     """Stateful causal Performer (`sea_performer_causal_step`): q,k,v (N,H,T_new,D) are the NEW rows of sequences
@@ -289,6 +308,7 @@ def _pack_a_fragments(w: torch.Tensor, kperm=None) -> torch.Tensor:
     return w[(16 * tile + li).expand(K // 32, M // 16, 4, 16, 8), k.expand(K // 32, M // 16, 4, 16, 8)].contiguous()
 
 
+@_lib.device_guarded
 def predictor_mlp(x: torch.Tensor, enc_lin, enc_ln, dec_lin, ln1, scaler_lin, want_tpred: bool = False):
     """Fused predictor MLP (csrc/sea_mlp.hip): x (N,H,T,Din) -> (x_c8 (N,T,H*2/8,Wd,8), t_pred or None,
     row_scale (N,H,T) fp32, avg_scale (N,H,T) fp32).  enc_lin/dec_lin/scaler_lin: nn.Linear; enc_ln/ln1: nn.LayerNorm."""
@@ -341,6 +361,7 @@ def from_c8(y: torch.Tensor) -> torch.Tensor:
     return y.permute(0, 2, 4, 1, 3).reshape(N, C8 * 8, T, W).contiguous()
 
 
+@_lib.device_guarded
 def split_layernorm_c8(x: torch.Tensor, splits: int, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5):
     """ChannelSplit + LayerNorm writing the C8 layout: (N, C, T, splits*W) -> (N, T, C*splits/8, W, 8).  16-bit only."""
     lib = _lib.load()
@@ -366,6 +387,7 @@ def pack_conv_weight(weight: torch.Tensor, ksize: int, dtype: torch.dtype):
     return packed.reshape(Cout, ksize * ksize * CinP).contiguous(), CinP
 
 
+@_lib.device_guarded
 def causal_conv_c8(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, ksize: int, dilation: int, pad_w: int,
                    relu: bool = True) -> torch.Tensor:
     """Causal (along T) dilated conv + bias (+ReLU) on a C8 activation (N, T, Cin/8, W, 8).

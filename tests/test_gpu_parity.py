@@ -148,6 +148,8 @@ def test_unfused_chain_equals_fused(ops):
     (2, 12, 2048, 256, 64, 64, torch.float32),       # cfg 2  synthetic (2 of the 8 batch items)
     (1, 32, 8192, 256, 64, 80, torch.bfloat16),      # cfg 4  OPT-2.7B shape, one item
     (1, 40, 4096, 256, 64, 128, torch.bfloat16),     # cfg 5  LLaMA-13B shape
+    (8, 12, 2048, 256, 64, 64, torch.float32),       # cfg 2 exactly as BASELINE.json writes it (B = 8)
+    (8, 32, 4096, 256, 64, 64, torch.bfloat16),      # cfg 3 at the batch bench.py times (8 sequences per GPU)
 ])
 def test_full_size_properties(ops, N, H, T, T_M, k, d, dtype):
     g = torch.Generator(device=DEV).manual_seed(42)
@@ -205,6 +207,19 @@ def test_full_size_properties(ops, N, H, T, T_M, k, d, dtype):
     assert (o12 - (0.5 * o1 + o2)).abs().max().item() < tol
     # (5) determinism: two launches are bit-identical
     assert torch.equal(o1, ops.sparse_attention(q, kk, v1, csr))
+    # (5b) batch independence: item n of the batched launch == the same item run alone, bit for bit; and for 16-bit data
+    #      the two kernel paths (MFMA tile / row gather) agree to rounding on the whole output
+    if N > 1:
+        from sea_attention_amd.perlin_attention.ops.flat_csr import FlatCSR
+        for n in (0, N - 1):
+            one = FlatCSR(csr.crow[n:n + 1], csr.col[n:n + 1], csr.head_off[n:n + 1], H, T)
+            alone = ops.sparse_attention(q[n:n + 1], kk[n:n + 1], v1[n:n + 1], one)
+            assert torch.equal(alone, o1[n:n + 1])
+    if dtype != torch.float32:
+        og = ops.sparse_attention(q, kk, v1, csr, path="gather")
+        ot = ops.sparse_attention(q, kk, v1, csr, path="tile")
+        assert (og - ot).abs().max().item() < 2e-3
+        assert ((og - ot).norm() / og.norm()).item() < 1e-3
     # (6) rows 0..k-1 keep everything: full causal attention for the first k queries
     sc = torch.matmul(q[:, :, :k].float(), kk[:, :, :k].float().transpose(-1, -2))
     sc = sc.masked_fill(torch.arange(k, device=DEV).view(1, k) > torch.arange(k, device=DEV).view(k, 1), float("-inf"))
