@@ -168,7 +168,9 @@ int sea_sparse_attention(const void* q, const void* k, const void* v, int dtype,
  *                    once per tile -- the shape of the reference's flat_csr_sdbmm.py:141-313.  16-bit data,
  *                    D in {64, 80, 128}, no duplicate (row, column) pairs.  SEA_EUNSUPPORTED otherwise.
  *   bits 8..11: row tiles per wave for the tile kernel (1 or 2; 0 = default for the head size);
- *   bits 12..15: log2 of its key window (6..12; 0 = default 2048).
+ *   bits 12..15: log2 of its key window (6..12; 0 = default 2048);
+ *   bits 16..19: its form -- 0 / 2: workgroup-cooperative (four waves = 64 or 128 query rows share every staged
+ *                K / V row through an LDS ring), 1: wave-independent (a wave fetches its own rows' tiles).
  *
  * probs_out (optional): fp32, laid out like `col` (row n at probs_out + n*probs_stride_n): entry e receives
  *   rs * softmax_e -- the values of `partial_attention_probs` after flat_csr_softmax + flat_csr_elmul

@@ -182,7 +182,8 @@ _PATHS = {"auto": _lib.SEA_ATTN_AUTO, "gather": _lib.SEA_ATTN_GATHER, "tile": _l
 def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = None,
                      avg: Optional[torch.Tensor] = None, mix: Optional[torch.Tensor] = None,
                      out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None,
-                     path: str = "auto", want_probs: bool = False, row_tiles: int = 0, key_window: int = 0):
+                     path: str = "auto", want_probs: bool = False, row_tiles: int = 0, key_window: int = 0,
+                     tile_form: int = 0):
     """Fused SDDMM + per-(row,head) softmax + row scale + SpMM (+ mix) over the flat CSR (`sea_sparse_attention_ex`).
 
     q (N,H,T_dst,D), k/v (N,H,T_src,D), any [n,h,t] strides, feature stride 1.
@@ -191,7 +192,8 @@ def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = 
     permuted view of an (N,T_dst,H*D) buffer to get the layout of attention.py:1279-1282 directly.
     Default output: fp32 (N,H,T_dst,D) (flat_csr_sdbmm.py:347 returns fp32).
     path: "auto" | "gather" (row-indexed gather kernels) | "tile" (MFMA tile kernel: 16-bit data, D in {64,80,128});
-    row_tiles / key_window tune the tile kernel (0 = defaults).
+    row_tiles / key_window tune the tile kernel (0 = defaults); tile_form 1 = its wave-independent form (one wave
+    owns its rows' tiles end to end), 0 / 2 = the workgroup-cooperative form (four waves share every staged K/V row).
     want_probs: also return the per-entry values rs * softmax (fp32, laid out like csr.col) -- what the reference
     hands out as `partial_attention_probs` (attention.py:1162-1171); returns (out, probs)."""
     lib = _lib.load()
@@ -210,7 +212,7 @@ def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = 
         assert avg is not None and avg.shape == (N, H, T_dst, D) and avg.dtype == q.dtype
         assert mix.dtype == torch.float32 and mix.shape == (N, H, T_dst) and mix.is_contiguous()
     probs = torch.zeros(csr.col.shape, dtype=torch.float32, device=q.device) if want_probs else None
-    flags = _PATHS[path] | ((int(row_tiles) & 0xf) << 8)
+    flags = _PATHS[path] | ((int(row_tiles) & 0xf) << 8) | ((int(tile_form) & 0xf) << 16)
     if key_window:
         assert key_window & (key_window - 1) == 0, "key_window is a power of two"
         flags |= (int(key_window).bit_length() - 1) << 12
