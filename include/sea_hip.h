@@ -159,18 +159,18 @@ int sea_sparse_attention(const void* q, const void* k, const void* v, int dtype,
 /* The same operator with two more knobs.
  *
  * flags, low byte = kernel path:
- *   SEA_ATTN_AUTO    the library picks (today: the tile kernel where it applies, else the gather kernels);
+ *   SEA_ATTN_AUTO    the library picks (today: the gather kernels -- the tile kernel pays off only when neighbouring
+ *                    query rows share most of their keys, which the library cannot know without reading the CSR;
+ *                    measured cross-over: >= ~22 entries per 16-row x 16-key tile);
  *   SEA_ATTN_GATHER  row-indexed gather kernels (sea_attn.hip): one lane group per (n,h,t) row walks the row's entries,
  *                    every K / V row is fetched per entry (L2-served); any dtype, any D <= 64*vec, duplicates counted;
- *   SEA_ATTN_TILE    MFMA tile kernel (sea_attn_tile.hip): a wave owns 16 or 32 consecutive query rows of one (n,h),
+ *   SEA_ATTN_TILE    MFMA tile kernel (sea_attn_tile.hip): a wave owns 16 (or 32) consecutive query rows of one (n,h),
  *                    turns their entries into a key bitmap in LDS, and for every 16-key tile that holds a kept key
  *                    runs K.Q^T, the masked online softmax and V^T.P^T on v_mfma_f32_16x16x32 with K/V rows fetched
  *                    once per tile -- the shape of the reference's flat_csr_sdbmm.py:141-313.  16-bit data,
  *                    D in {64, 80, 128}, no duplicate (row, column) pairs.  SEA_EUNSUPPORTED otherwise.
  *   bits 8..11: row tiles per wave for the tile kernel (1 or 2; 0 = default for the head size);
- *   bits 12..15: log2 of its key window (6..12; 0 = default 2048);
- *   bits 16..19: its form -- 0 / 2: workgroup-cooperative (four waves = 64 or 128 query rows share every staged
- *                K / V row through an LDS ring), 1: wave-independent (a wave fetches its own rows' tiles).
+ *   bits 12..15: log2 of its key window (6..12; 0 = default 2048).
  *
  * probs_out (optional): fp32, laid out like `col` (row n at probs_out + n*probs_stride_n): entry e receives
  *   rs * softmax_e -- the values of `partial_attention_probs` after flat_csr_softmax + flat_csr_elmul

@@ -1,31 +1,43 @@
 #!/usr/bin/env python3
-"""Turn the three rocprofv3 --pmc passes of scripts/gpu_pmc.sh into profiles/<tag>_pmc_traffic.json (+ traffic_latest.json).
+"""Turn the rocprofv3 --pmc passes of scripts/gpu_pmc.sh (taken on bench.py's own in-layer launches) into
+profiles/<tag>_pmc_traffic.json (+ traffic_latest.json, stamped with the attention kernel's source hash: bench.py reports
+`roofline.traffic` only when the stamp matches the sources it runs).
 HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 on gfx950 for 16 B/lane loads (MI355X_MICROARCH.md, HBM section).
 usage: pmc_to_traffic.py <tag> [build note]"""
 import csv, json, os, shutil, sys, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import _attn_source_sha
 tag = sys.argv[1]; note = sys.argv[2] if len(sys.argv) > 2 else ""
 src = os.path.join(ROOT, "gpurun_out", f"pmc_{tag}")
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
-for sub in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum_TCC_MISS_sum"):
+for sub in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum_TCC_MISS_sum_TCC_REQ_sum"):
     f = os.path.join(src, sub, "pmc_counter_collection.csv")
-    shutil.copy(f, os.path.join(ROOT, "profiles", f"{tag}_pmc_{sub}.csv"))
-    for r in csv.DictReader(open(f)):
+    keep = []
+    rd = csv.DictReader(open(f))
+    for r in rd:
         if r["Kernel_Name"].startswith(("void sea::", "sea::")):
+            keep.append(r)
             name = r["Kernel_Name"].replace("void ", "").split("(")[0]
             acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
-log = [l for l in open(os.path.join(src, "FETCH_SIZE.log")).read().splitlines() if l.startswith("{")][-1]
-out = {"round": 1, "build": note,
-       "command": "rocprofv3 --kernel-trace --pmc <C> -- python3 scripts/kernel_path.py --iters 3  (opt-1.3b, batch 8, bf16; one pass per counter set)",
+    with open(os.path.join(ROOT, "profiles", f"{tag}_pmc_{sub}.csv"), "w", newline="") as fo:   # the library's kernels only
+        w = csv.DictWriter(fo, fieldnames=rd.fieldnames); w.writeheader(); w.writerows(keep)
+log = [l for l in open(os.path.join(src, "FETCH_SIZE.log")).read().splitlines() if l.startswith("{")]
+bench_line = json.loads(log[-1]) if log else {}
+out = {"round": 2, "build": note, "kernel_source_sha256": _attn_source_sha(),
+       "command": "rocprofv3 --kernel-trace --pmc <C> -- python3 bench.py --steps 3 --warmup 1 --prewarm 2 --no-cpu-baseline "
+                  "--kernel-iters 0 --no-output-check  (opt-1.3b, batch 8, bf16; one pass per counter set; in-layer launches)",
+       "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the bench command itself (in-layer launches), gfx950 correction applied",
        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for 16 B/lane loads -> hbm = (2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md, HBM)",
-       "workload": json.loads(log), "kernels": {}}
+       "workload": bench_line.get("config", {}).get("workload"), "nnz": (bench_line.get("roofline") or {}).get("nnz"), "kernels": {}}
 for name, c in acc.items():
     mean = lambda k: sum(c[k]) / len(c[k]) if c[k] else 0.0
-    fs, ws, hit, miss = mean("FETCH_SIZE"), mean("WRITE_SIZE"), mean("TCC_HIT_sum"), mean("TCC_MISS_sum")
-    out["kernels"][name] = {"FETCH_SIZE_KB": fs, "WRITE_SIZE_KB": ws, "hbm_bytes_per_launch_corrected": int((2 * fs + ws) * 1024),
-                            "l2_hit_rate": round(hit / (hit + miss), 4) if hit + miss else None}
+    fs, ws, hit, miss, req = mean("FETCH_SIZE"), mean("WRITE_SIZE"), mean("TCC_HIT_sum"), mean("TCC_MISS_sum"), mean("TCC_REQ_sum")
+    out["kernels"][name] = {"launches": len(c["FETCH_SIZE"]), "FETCH_SIZE_KB": fs, "WRITE_SIZE_KB": ws,
+                            "hbm_bytes_per_launch_corrected": int((2 * fs + ws) * 1024),
+                            "l2_requests_per_launch": int(req), "l2_hit_rate": round(hit / (hit + miss), 4) if hit + miss else None}
     if "sparse_attn" in name:
         out["sea_sparse_attention_hbm_bytes_per_launch"] = int((2 * fs + ws) * 1024)
 for dst in (f"{tag}_pmc_traffic.json", "traffic_latest.json"):
     json.dump(out, open(os.path.join(ROOT, "profiles", dst), "w"), indent=1)
-print(json.dumps({k: (v["hbm_bytes_per_launch_corrected"], v["l2_hit_rate"]) for k, v in out["kernels"].items()}, indent=1))
+print(json.dumps({k: (v["hbm_bytes_per_launch_corrected"], v["l2_requests_per_launch"], v["l2_hit_rate"]) for k, v in out["kernels"].items()}, indent=1))

@@ -20,7 +20,7 @@ ap.add_argument("--workload", default="opt-1.3b")
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--maps", default="layer,random,structured")
-ap.add_argument("--variants", default="gather,tile:1:0:1,tile:1:0:2,tile:2:0:2,tile:1:1024:2,tile:2:1024:2,tile:2:4096:2")
+ap.add_argument("--variants", default="gather,tile:1:0,tile:2:0")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 w = WORKLOADS[a.workload]
@@ -74,7 +74,7 @@ for name in a.maps.split(","):
         parts = var.split(":")
         kw = dict(path=parts[0])
         if parts[0] == "tile":
-            kw.update(row_tiles=int(parts[1]), key_window=int(parts[2]), tile_form=int(parts[3]) if len(parts) > 3 else 0)
+            kw.update(row_tiles=int(parts[1]), key_window=int(parts[2]))
         try:
             for _ in range(2):
                 ops.sparse_attention(q, kk, v, csr, row_scale=rs, avg=avg, mix=mx, out=ctx.view(NB, T, H, d).permute(0, 2, 1, 3), **kw)

@@ -701,7 +701,7 @@ extern "C" int sea_sparse_attention_ex(const void* q, const void* k, const void*
     SEA_REQUIRE(tile_ok, SEA_EUNSUPPORTED, "%s: the tile kernel takes 16-bit data with D in {64, 80, 128} and no probs_out", nm);
   }
   int rc;
-  if (path == SEA_ATTN_TILE || (path == SEA_ATTN_AUTO && tile_ok)) {
+  if (path == SEA_ATTN_TILE) {
     rc = launch_attn_tile(p, dtype, out_dtype, flags, s);
     SEA_REQUIRE(rc == SEA_OK, rc, "%s: tile kernel launch parameters rejected (flags 0x%x)", nm, flags);
     SEA_CHECK_LAUNCH(nm);

@@ -385,349 +385,6 @@ __global__ __launch_bounds__(NW * 64) void sparse_attn_tile_kernel(AttnParams p,
   }
 }
 
-// ======================================================================================================================
-// Workgroup-cooperative form: 4 waves = 64 * RT consecutive query rows of one (n, h) share every staged K / V row.
-//
-// The wave-independent kernel above fetches a tile's K and V rows once per 16 * RT query rows and has one tile pair in
-// flight per wave: it runs at the latency of its own load -> MFMA -> softmax -> MFMA chain (rocprofv3: waves parked on
-// s_waitcnt 53 % of their lifetime).  Here the workgroup builds ONE tile list over all its rows (with, per tile, the
-// (wave, row tile) pairs that hold a kept key in it), streams the listed tiles' K and V rows through a two-slot LDS
-// ring -- every thread moves two 16-byte chunks of K and two of V per stage, so a stage in flight costs four registers
-// instead of a whole tile pair's fragments -- and each wave runs the pair body only on the tiles its own rows use.
-// One workgroup barrier per stage: a slot is rewritten two stages later, after the barrier every reader has passed.
-template <int D> struct WgGeom {
-  static constexpr int RS = (D == 128) ? 288 : 160;       // LDS row stride of staged K / V rows: 40 (8) words mod 64 ->
-                                                          // b128 row reads and transposing b64 reads are conflict-free
-  static constexpr int TPS = (D == 128) ? 2 : 4;          // 16-key tiles per stage
-  static constexpr int CH = D / 8;                        // 16-byte chunks per row
-  static constexpr int CPT = TPS * 16 * CH;               // chunks per tensor and stage
-  static constexpr int NLD = (CPT + 255) / 256;           // chunks per thread, tensor and stage
-  static constexpr int SLOT = 2 * TPS * 16 * RS;          // bytes per ring slot: K rows, then V rows
-};
-
-__host__ __device__ inline int wg_meta_bytes(int RT, int KW) {
-  const int rows = 64 * RT, wpr = KW / 32;
-  return ((rows * (wpr + 1) + 4 * RT * wpr + KW / 16 + 16) * 4 + 15) & ~15;
-}
-
-template <typename T, typename TO, int D, int RT>
-__global__ __launch_bounds__(256) void sparse_attn_wgtile_kernel(AttnParams p, int KW) {
-  using G = TileGeom<D>;
-  using W = WgGeom<D>;
-  using X = TileT<T>;
-  constexpr int ROWS = 16 * RT, KK = G::KK, MT = G::MT, CH = W::CH, RS = W::RS, TPS = W::TPS, NLD = W::NLD, SLOT = W::SLOT;
-  extern __shared__ __attribute__((aligned(16))) char at_smem[];
-  int pair, tb;
-  if (!map_block(p.N * p.H, p.TB, &pair, &tb)) return;     // workgroup-uniform
-  const int n = pair / p.H, h = pair - n * p.H;
-  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int t0 = (tb * 4 + wave) * ROWS;                   // this wave's first query row (may lie past T_dst: no entries)
-
-  const int WPR = KW >> 5, BST = WPR + 1;
-  uint32_t* bm = reinterpret_cast<uint32_t*>(at_smem);     // [4 * ROWS][BST]   key bitmap, one row per query row
-  uint32_t* wu = bm + 4 * ROWS * BST;                      // [4][RT][WPR]      OR of a (wave, row tile)'s sixteen rows
-  uint32_t* tl = wu + 4 * RT * WPR;                        // [KW / 16]         tile list: tile | users << 9
-  int* misc = reinterpret_cast<int*>(tl + KW / 16);        // [0..3] largest key per wave, [4] tiles listed
-  char* ring = at_smem + wg_meta_bytes(RT, KW);            // [2][SLOT]
-  uint32_t* mybm = bm + wave * ROWS * BST;
-
-  const char* kbase = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.k) + n * p.ks[0] + h * p.ks[1]);
-  const char* vbase = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.v) + n * p.vs[0] + h * p.vs[1]);
-  const uint32_t kst = (uint32_t)p.ks[2] * 2u, vst = (uint32_t)p.vs[2] * 2u;
-  const int32_t* col = p.col + n * p.col_stride_n;
-  const int hcol = h * p.T_src;
-  const int klast = p.T_src - 1;
-
-  uint4 qf[RT][KK];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    const int t = min(t0 + 16 * rt + li, p.T_dst - 1);
-    const T* qrow = reinterpret_cast<const T*>(p.q) + n * p.qs[0] + h * p.qs[1] + (int64_t)t * p.qs[2];
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-      const int d0 = 32 * kk + 8 * g;
-      qf[rt][kk] = (d0 < D) ? *reinterpret_cast<const uint4*>(qrow + d0) : make_uint4(0, 0, 0, 0);
-    }
-  }
-  int rbeg = 0, rend = 0;
-  if (lane < ROWS && t0 + lane < p.T_dst) {
-    const int t = t0 + lane;
-    const int row_beg = p.crow[(int64_t)n * (p.T_dst + 1) + t];
-    const int32_t* ho = p.head_off + ((int64_t)n * p.T_dst + t) * (p.H + 1);
-    rbeg = row_beg + ho[h];
-    rend = row_beg + ho[h + 1];
-  }
-  // staging duty of this thread: chunk idx = tid + 256 u of a stage -> (tile slot j, key, 16-byte chunk)
-  int sj[NLD], skey[NLD], sdst[NLD], sch[NLD];
-#pragma unroll
-  for (int u = 0; u < NLD; ++u) {
-    const int idx = min(tid + 256 * u, W::CPT - 1);
-    const int j = idx / (16 * CH), rem = idx - j * 16 * CH, key = rem / CH, ch = rem - key * CH;
-    sj[u] = j; skey[u] = key; sch[u] = ch * 16;
-    sdst[u] = (j * 16 + key) * RS + ch * 16;
-  }
-
-  float m[RT], l[RT];
-  at_f4 acc[RT][MT];
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    m[rt] = -INFINITY; l[rt] = 0.f;
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[rt][mt] = at_f4{0.f, 0.f, 0.f, 0.f};
-  }
-  const int lk = li * RS + g * 16;                                   // lane part of a K fragment address
-  const int lv = (4 * g + (li >> 2)) * RS + (li & 3) * 8;            // lane part of a transposing V read
-
-  int kmax = -1;
-  for (int W0 = 0; W0 == 0 || W0 <= kmax; W0 += KW) {
-    // ---- 1. this wave's rows: key bitmap of the window, OR per row tile ------------------------------------------------
-    for (int i = lane; i < ROWS * BST; i += 64) mybm[i] = 0u;
-    int kmx = -1;
-#pragma unroll
-    for (int r0 = 0; r0 < ROWS; r0 += 8) {
-      int cv[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int b = __builtin_amdgcn_readlane(rbeg, r0 + u), e = __builtin_amdgcn_readlane(rend, r0 + u);
-        const int i = b + lane;
-        cv[u] = i < e ? col[i] - hcol : -1;
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int b = __builtin_amdgcn_readlane(rbeg, r0 + u), e = __builtin_amdgcn_readlane(rend, r0 + u);
-        uint32_t* row = mybm + (r0 + u) * BST;
-        int c = cv[u];
-        for (int i = b + lane;;) {
-          if (c >= 0) {
-            kmx = max(kmx, c);
-            const uint32_t kw = (uint32_t)(c - W0);
-            if (kw < (uint32_t)KW) atomicOr(row + (kw >> 5), 1u << (kw & 31));
-          }
-          i += 64;
-          if (!__builtin_amdgcn_readfirstlane((int)(__ballot(i < e) != 0ull))) break;
-          c = i < e ? col[i] - hcol : -1;
-        }
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-    for (int w = lane; w < WPR; w += 64) {
-#pragma unroll
-      for (int rt = 0; rt < RT; ++rt) {
-        uint32_t u = 0u;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) u |= mybm[(16 * rt + r) * BST + w];
-        wu[(wave * RT + rt) * WPR + w] = u;
-      }
-    }
-    if (W0 == 0) {
-      const int km = wave_max(kmx);
-      if (lane == 0) misc[wave] = km;
-    }
-    __syncthreads();
-    // ---- 2. wave 0: ascending list of the tiles any row of the workgroup uses, with their users ---------------------------
-    if (wave == 0) {
-      int nt = 0;
-      for (int w0 = 0; w0 < WPR; w0 += 64) {
-        const int w = w0 + lane;
-        uint32_t ml = 0u, mh = 0u;
-        if (w < WPR) {
-#pragma unroll
-          for (int x = 0; x < 4 * RT; ++x) {
-            const uint32_t u = wu[x * WPR + w];
-            ml |= (uint32_t)((u & 0xffffu) != 0u) << x;
-            mh |= (uint32_t)((u >> 16) != 0u) << x;
-          }
-        }
-        const bool lo = ml != 0u, hi = mh != 0u;
-        const uint64_t blo = __ballot(lo), bhi = __ballot(hi);
-        const uint64_t lt = (1ull << lane) - 1ull;
-        const int pos = nt + __popcll(blo & lt) + __popcll(bhi & lt);
-        if (lo) tl[pos] = (uint32_t)(2 * w) | (ml << 9);
-        if (hi) tl[pos + (lo ? 1 : 0)] = (uint32_t)(2 * w + 1) | (mh << 9);
-        nt += __popcll(blo) + __popcll(bhi);
-      }
-      if (lane == 0) misc[4] = nt;
-    }
-    __syncthreads();
-    const int NT = __builtin_amdgcn_readfirstlane(misc[4]);
-    if (W0 == 0) kmax = __builtin_amdgcn_readfirstlane(max(max(misc[0], misc[1]), max(misc[2], misc[3])));
-    if (NT == 0) continue;                                 // workgroup-uniform
-
-    // ---- 3. stages of TPS tiles through the ring ------------------------------------------------------------------------
-    struct StageRegs { uint4 k[NLD], v[NLD]; };
-    auto load_stage = [&](int s) -> StageRegs {
-      StageRegs r;
-#pragma unroll
-      for (int u = 0; u < NLD; ++u) {
-        const int c = (int)(tl[min(s * TPS + sj[u], NT - 1)] & 0x1ffu);
-        const uint32_t key = (uint32_t)min(W0 + 16 * c + skey[u], klast);
-        r.k[u] = *reinterpret_cast<const uint4*>(kbase + (key * kst + (uint32_t)sch[u]));
-        r.v[u] = *reinterpret_cast<const uint4*>(vbase + (key * vst + (uint32_t)sch[u]));
-      }
-      return r;
-    };
-    const int NS = (NT + TPS - 1) / TPS;
-    StageRegs cur = load_stage(0);
-    for (int s = 0; s < NS; ++s) {
-      char* slot = ring + (s & 1) * SLOT;
-#pragma unroll
-      for (int u = 0; u < NLD; ++u) {
-        if (tid + 256 * u < W::CPT) {
-          *reinterpret_cast<uint4*>(slot + sdst[u]) = cur.k[u];
-          *reinterpret_cast<uint4*>(slot + TPS * 16 * RS + sdst[u]) = cur.v[u];
-        }
-      }
-      if (s + 1 < NS) cur = load_stage(s + 1);             // the next stage's loads fly under this stage's compute
-      __syncthreads();
-
-      // this wave's tiles of the stage, packed as 16-bit fields: slot position j << 11 | users of my rows << 9 | tile
-      uint64_t actv = 0ull;
-      int na = 0;
-#pragma unroll
-      for (int j = 0; j < TPS; ++j) {
-        if (s * TPS + j < NT) {
-          const uint32_t e = (uint32_t)__builtin_amdgcn_readfirstlane((int)tl[s * TPS + j]);
-          const uint32_t my = (e >> (9 + wave * RT)) & ((1u << RT) - 1u);
-          if (my) {
-            actv |= (uint64_t)((uint32_t)(j << 11) | (my << 9) | (e & 0x1ffu)) << (16 * na);
-            ++na;
-          }
-        }
-      }
-      for (int qi = 0; qi < na; qi += 2) {
-        const bool has_b = qi + 1 < na;
-        const uint32_t fa = (uint32_t)(actv >> (16 * qi)) & 0xffffu;
-        const uint32_t fb = has_b ? ((uint32_t)(actv >> (16 * (qi + 1))) & 0xffffu) : fa;
-        const int ja = (int)(fa >> 11), jb = (int)(fb >> 11);
-        const int ca = (int)(fa & 0x1ffu), cb = (int)(fb & 0x1ffu);
-        const uint32_t ma = (fa >> 9) & 3u, mb = has_b ? ((fb >> 9) & 3u) : 0u;
-        const char* ka = slot + ja * 16 * RS + lk;
-        const char* kb = slot + jb * 16 * RS + lk;
-        uint4 kfa[KK], kfb[KK];
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-          if (32 * kk + 8 * g < D) {
-            kfa[kk] = *reinterpret_cast<const uint4*>(ka + kk * 64);
-            kfb[kk] = *reinterpret_cast<const uint4*>(kb + kk * 64);
-          } else {
-            kfa[kk] = make_uint4(0, 0, 0, 0);
-            kfb[kk] = make_uint4(0, 0, 0, 0);
-          }
-        }
-        at_f4 sc[RT][2];
-        float pmax[RT];
-        bool grow = false;
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          pmax[rt] = -INFINITY;
-          if (((ma | mb) >> rt) & 1u) {                    // wave-uniform: this row tile uses the pair
-            at_f4 a = {0.f, 0.f, 0.f, 0.f}, b = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < KK; ++kk) {
-              a = X::mfma(kfa[kk], qf[rt][kk], a);
-              b = X::mfma(kfb[kk], qf[rt][kk], b);
-            }
-            const uint32_t* row = mybm + (16 * rt + li) * BST;
-            const uint32_t na_ = (row[ca >> 1] >> (16 * (ca & 1) + 4 * g)) & 0xfu;
-            const uint32_t nb_ = has_b ? ((row[cb >> 1] >> (16 * (cb & 1) + 4 * g)) & 0xfu) : 0u;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              a[j] = (na_ >> j) & 1u ? a[j] : -INFINITY;
-              b[j] = (nb_ >> j) & 1u ? b[j] : -INFINITY;
-            }
-            float mx = fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])));
-            mx = xor16_max(mx);
-            mx = xor32_max(mx);
-            pmax[rt] = mx;
-            grow = grow || (mx > m[rt]);
-            sc[rt][0] = a; sc[rt][1] = b;
-          }
-        }
-        if (__ballot(grow) != 0ull) {
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt) {
-            const float mn = fmaxf(m[rt], pmax[rt]);
-            const float alpha = (mn == -INFINITY) ? 1.f : __expf(m[rt] - mn);
-            l[rt] *= alpha;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-              acc[rt][mt][0] *= alpha; acc[rt][mt][1] *= alpha; acc[rt][mt][2] *= alpha; acc[rt][mt][3] *= alpha;
-            }
-            m[rt] = mn;
-          }
-        }
-        uint4 ph[RT], pl[RT];
-#pragma unroll
-        for (int rt = 0; rt < RT; ++rt) {
-          if (((ma | mb) >> rt) & 1u) {
-            const float ms = (m[rt] == -INFINITY) ? 0.f : m[rt];
-            float pv[8];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              pv[j] = __expf(sc[rt][0][j] - ms);
-              pv[4 + j] = __expf(sc[rt][1][j] - ms);
-            }
-            l[rt] += ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
-            ph[rt] = make_uint4(X::pack(pv[0], pv[1]), X::pack(pv[2], pv[3]), X::pack(pv[4], pv[5]), X::pack(pv[6], pv[7]));
-            if (X::SPLIT) {
-              pl[rt] = make_uint4(X::pack(pv[0] - X::lo_val(ph[rt].x), pv[1] - X::hi_val(ph[rt].x)),
-                                  X::pack(pv[2] - X::lo_val(ph[rt].y), pv[3] - X::hi_val(ph[rt].y)),
-                                  X::pack(pv[4] - X::lo_val(ph[rt].z), pv[5] - X::hi_val(ph[rt].z)),
-                                  X::pack(pv[6] - X::lo_val(ph[rt].w), pv[7] - X::hi_val(ph[rt].w)));
-            }
-          }
-        }
-        const char* va = slot + TPS * 16 * RS + ja * 16 * RS + lv;
-        const char* vb = slot + TPS * 16 * RS + jb * 16 * RS + lv;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const at_s4 xa = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_s4 __attribute__((address_space(3)))*)(va + mt * 32));
-          const at_s4 xb = __builtin_amdgcn_ds_read_tr16_b64_v4i16((at_s4 __attribute__((address_space(3)))*)(vb + mt * 32));
-          const uint2 ua2 = __builtin_bit_cast(uint2, xa), ub2 = __builtin_bit_cast(uint2, xb);
-          const uint4 vf = make_uint4(ua2.x, ua2.y, ub2.x, ub2.y);
-#pragma unroll
-          for (int rt = 0; rt < RT; ++rt) {
-            if (((ma | mb) >> rt) & 1u) {
-              acc[rt][mt] = X::mfma(vf, ph[rt], acc[rt][mt]);
-              if (X::SPLIT) acc[rt][mt] = X::mfma(vf, pl[rt], acc[rt][mt]);
-            }
-          }
-        }
-      }
-    }
-  }
-
-  // ---- epilogue (as above) -------------------------------------------------------------------------------------------------
-#pragma unroll
-  for (int rt = 0; rt < RT; ++rt) {
-    const float ls = xor32_sum(xor16_sum(l[rt]));
-    const int t = t0 + 16 * rt + li;
-    if (t < p.T_dst) {
-      const int64_t ridx = ((int64_t)n * p.H + h) * p.T_dst + t;
-      float scale = (ls > 0.f) ? (1.0f / ls) : 0.f;
-      if (p.row_scale) scale *= p.row_scale[ridx];
-      const float a = p.mix ? p.mix[ridx] : 1.f;
-      const T* ap = reinterpret_cast<const T*>(p.avg) + n * p.as[0] + h * p.as[1] + (int64_t)t * p.as[2];
-      TO* op = reinterpret_cast<TO*>(p.out) + n * p.os[0] + h * p.os[1] + (int64_t)t * p.os[2];
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int d0 = 16 * mt + 4 * g;
-        float o[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) o[j] = (ls > 0.f) ? acc[rt][mt][j] * scale : 0.f;
-        if (p.mix) {
-          float af[4];
-          unpack4<T>(*reinterpret_cast<const uint2*>(ap + d0), af);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = o[j] * a + (1.0f - a) * af[j];
-        }
-        store4<T, TO>(op + d0, o);
-      }
-    }
-  }
-}
-
 // ---- host side ---------------------------------------------------------------------------------------------------
 bool attn_tile_supported(int dtype, int D, int T_src, const AttnParams& p) {
   if (dtype != SEA_F16 && dtype != SEA_BF16) return false;
@@ -753,60 +410,35 @@ static int launch_tile_inst(AttnParams p, int KW, hipStream_t s) {
   return SEA_OK;
 }
 
-template <typename T, typename TO, int D, int RT>
-static int launch_wgtile_inst(AttnParams p, int KW, hipStream_t s) {
-  const int lds = wg_meta_bytes(RT, KW) + 2 * WgGeom<D>::SLOT;
-  static int lds_set = 0;
-  if (lds > lds_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_attn_wgtile_kernel<T, TO, D, RT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return SEA_ELAUNCH;
-    lds_set = lds;
-  }
-  const int rpb = 64 * RT;
-  p.TB = (p.T_dst + rpb - 1) / rpb;
-  const int64_t blocks = (int64_t)8 * ((p.N * p.H + 7) / 8) * p.TB;
-  if (blocks >= (1ll << 31)) return SEA_EUNSUPPORTED;
-  hipLaunchKernelGGL((sparse_attn_wgtile_kernel<T, TO, D, RT>), dim3((unsigned)blocks), dim3(256), lds, s, p, KW);
-  return SEA_OK;
-}
-
 template <typename T, typename TO, int D>
-static int launch_tile_d(const AttnParams& p, int variant, int rt, int KW, hipStream_t s) {
-  if (variant == 1) {                                      // wave-independent form
-    if (rt == 2) return launch_tile_inst<T, TO, D, 2, 2>(p, KW, s);
-    return launch_tile_inst<T, TO, D, 1, 2>(p, KW, s);
-  }
-  if (rt == 2) return launch_wgtile_inst<T, TO, D, 2>(p, KW, s);
-  return launch_wgtile_inst<T, TO, D, 1>(p, KW, s);
+static int launch_tile_d(const AttnParams& p, int rt, int KW, hipStream_t s) {
+  if (rt == 2) return launch_tile_inst<T, TO, D, 2, 2>(p, KW, s);
+  return launch_tile_inst<T, TO, D, 1, 2>(p, KW, s);
 }
 
 template <typename T, typename TO>
-static int launch_tile_t(const AttnParams& p, int variant, int rt, int KW, hipStream_t s) {
+static int launch_tile_t(const AttnParams& p, int rt, int KW, hipStream_t s) {
   switch (p.D) {
-    case 64: return launch_tile_d<T, TO, 64>(p, variant, rt, KW, s);
-    case 80: return launch_tile_d<T, TO, 80>(p, variant, rt, KW, s);
-    case 128: return launch_tile_d<T, TO, 128>(p, variant, rt, KW, s);
+    case 64: return launch_tile_d<T, TO, 64>(p, rt, KW, s);
+    case 80: return launch_tile_d<T, TO, 80>(p, rt, KW, s);
+    case 128: return launch_tile_d<T, TO, 128>(p, rt, KW, s);
     default: return SEA_EUNSUPPORTED;
   }
 }
 
 int launch_attn_tile(const AttnParams& p, int dtype, int out_dtype, int flags, hipStream_t s) {
-  // flags (SEA_ATTN_* in sea_hip.h): bits 8..11 = row tiles per wave (0: default for the head size),
-  // bits 12..15 = log2 of the key window (0: default), bits 16..19 = form (0 / 2: workgroup-cooperative, 1: per wave)
+  // flags (SEA_ATTN_* in sea_hip.h): bits 8..11 = row tiles per wave (0: default), bits 12..15 = log2 of the key window
   int rt = (flags >> 8) & 0xf;
-  if (rt == 0) rt = p.D <= 80 ? 2 : 1;
+  if (rt == 0) rt = 1;
   if (rt != 1 && rt != 2) return SEA_EINVAL;
-  const int variant = (flags >> 16) & 0xf;
-  if (variant > 2) return SEA_EINVAL;
   const int kwl = (flags >> 12) & 0xf;
   int KW = kwl ? (1 << kwl) : 2048;
   if (KW < 64 || KW > 4096) return SEA_EINVAL;
   while (KW / 2 >= 64 && KW / 2 >= p.T_src) KW /= 2;       // short sequences: no wider than needed
   if (dtype == SEA_BF16)
-    return out_dtype == SEA_F32 ? launch_tile_t<__hip_bfloat16, float>(p, variant, rt, KW, s)
-                                : launch_tile_t<__hip_bfloat16, __hip_bfloat16>(p, variant, rt, KW, s);
-  return out_dtype == SEA_F32 ? launch_tile_t<__half, float>(p, variant, rt, KW, s)
-                              : launch_tile_t<__half, __half>(p, variant, rt, KW, s);
+    return out_dtype == SEA_F32 ? launch_tile_t<__hip_bfloat16, float>(p, rt, KW, s)
+                                : launch_tile_t<__hip_bfloat16, __hip_bfloat16>(p, rt, KW, s);
+  return out_dtype == SEA_F32 ? launch_tile_t<__half, float>(p, rt, KW, s) : launch_tile_t<__half, __half>(p, rt, KW, s);
 }
 
 }  // namespace sea

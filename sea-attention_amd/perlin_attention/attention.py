@@ -119,6 +119,17 @@ class PerlinAttention(nn.Module):
         # sparse mode: return the mask as a torch.sparse_csr_tensor (int64, one host sync for Z) instead of
         # the internal int32 FlatCSR handle
         self.materialize_csr = False
+        # sparse mode: also produce `partial_attention_probs` (per-entry rs * softmax on the mask's CSR, what the reference
+        # returns at :1162-1171); costs one extra 4-byte store + reload per entry, so it is on only when somebody reads it:
+        # PerlinSelfAttention.checkout_last_attention_probs sets it, so does probing through get_bench()
+        self.return_attention_probs = False
+        # sparse mode: kernel of steps J-L: "gather" (row-indexed gathers), "tile" (MFMA tile kernel, 16-bit data,
+        # d in {64, 80, 128}; wins when neighbouring query rows keep mostly the same keys -- trained predictors), "auto"
+        self.sparse_kernel = "auto"
+        # HIP Performer: None = the library's plan for the shape (it cuts ONE long sequence into segments so that all CUs
+        # work: another fp32 summation order than the one-pass kernel a full batch takes), 1 = always the one-pass kernel
+        # (bench.py's self-check runs a batch item alone with it, so that the item reproduces its batched rows bit for bit)
+        self.performer_segments = None
         # debugging / parity: run the estimator's LayerNorm / conv tail through the torch modules even on GPU
         self.force_torch_estimator = False
         self._fused_gates = None            # (row_scale, average_scale) when the fused predictor MLP produced them
@@ -192,6 +203,17 @@ class PerlinAttention(nn.Module):
         self.v_eye_learned_causal = nn.Parameter(torch.randn((1, 1, max_pos, d)))
 
         self._keep_cache = {}
+        # packed / re-laid-out copies of the predictor's weights are cached per tensor (ops.predictor._cached); a loaded
+        # state dict, a device move or a train/eval switch may come with weight edits the cache cannot see
+        self.register_load_state_dict_post_hook(lambda module, incompatible: ops.clear_prep_cache())
+
+    def _apply(self, fn, *args, **kwargs):
+        ops.clear_prep_cache()
+        return super()._apply(fn, *args, **kwargs)
+
+    def train(self, mode: bool = True):
+        ops.clear_prep_cache()
+        return super().train(mode)
 
     # ------------------------------------------------------------------------------------------------
     def _keep_table(self, H, T_dst, T_src, T_M, device):
@@ -278,7 +300,8 @@ class PerlinAttention(nn.Module):
                 # (only when the estimator's value tensor IS the layer's value tensor, i.e. no separate LoRA branch)
                 avg_too = (self.benchmarking and v_for_atten is v and ops.performer_avg_supported(q_for_atten, self.performer_nb_features))
                 performer_value = ops.performer_value(q_for_atten, k_for_atten, v_for_atten, pos,
-                                                      self.performer.projection_matrix, want_avg=avg_too)
+                                                      self.performer.projection_matrix, want_avg=avg_too,
+                                                      n_segments=self.performer_segments)
                 if avg_too:
                     performer_value, self._avg_ahead = performer_value
                 D_ = q.shape[-1]
@@ -568,7 +591,7 @@ class PerlinAttention(nn.Module):
         `attention_mask` is the (N,1,T_DST,T_SRC) tail of the causal mask.  Returns the rows a stateless forward over
         T_SRC tokens would produce for the last T_DST positions, plus the new state.  The estimator (a handful of
         rows per call) runs on the torch modules; steps H..L run on the HIP kernels with T_dst < T_src."""
-        from .attention_state import PerlinAttentionState, PerformerState, CnnWindowState, CumAvgState
+        from .attention_state import PerlinAttentionState, PerformerState, CnnWindowState, CumAvgState, cnn_lookback
         if not self.pconfig.causal:
             raise NotImplementedError("kv-cache decoding is defined for the causal configuration only")
         if torch.is_grad_enabled() and any(t.requires_grad for t in (q, k, v)):
@@ -581,9 +604,10 @@ class PerlinAttention(nn.Module):
         assert seen + T_DST == T_SRC, f"state has seen {seen} tokens, call brings {T_DST} new of {T_SRC}"
         bench = get_bench()
         T_M = self.pconfig.attention_predictor_length
-        LB = CnnWindowState.LOOKBACK
+        LB = cnn_lookback(self.attention_predictor_cnn)          # 8 rows for two dilated convs, 12 with the deeper hotfix
         ps = state.get(PerlinAttentionState.PERFORMER, PerformerState)
-        cs = state.get(PerlinAttentionState.CNN, CnnWindowState)
+        cs = state.get(PerlinAttentionState.CNN, lambda: CnnWindowState(LB))
+        assert cs.lookback >= LB, "state was built for a shallower predictor CNN"
         cav = state.get(PerlinAttentionState.CUMAVG, CumAvgState)
         # 16-bit inference, d = 64: the whole estimator stays on the stateless path's kernels.  The Performer continues
         # its own fp32 sums from a state image (`sea_performer_causal_step`), which also carries the column sums of v
@@ -722,12 +746,16 @@ class PerlinAttention(nn.Module):
                 ks, vs = ks.to(qs.dtype), vs.to(qs.dtype)
                 out_dtype = self.context_layer_dtype or torch.float32
                 ctx = torch.empty((N, T_DST, H * HID), dtype=out_dtype, device=q.device)
-                ops.sparse_attention(qs, ks, vs, csr, row_scale=row_scale, avg=average_context_layer.to(qs.dtype).contiguous(),
-                                     mix=average_scale, out=ctx.view(N, T_DST, H, HID).permute(0, 2, 1, 3))
+                res = ops.sparse_attention(qs, ks, vs, csr, row_scale=row_scale, avg=average_context_layer.to(qs.dtype).contiguous(),
+                                           mix=average_scale, out=ctx.view(N, T_DST, H, HID).permute(0, 2, 1, 3),
+                                           want_probs=self.return_attention_probs)
+                probs_csr = csr.with_values(res[1]) if self.return_attention_probs else None
         bench.register_temp_buffer('estimated_attention_probs', estimated_attention_probs)
         mask_out = csr.to_sparse_csr() if self.materialize_csr else csr
+        if probs_csr is not None and self.materialize_csr:
+            probs_csr = probs_csr.to_sparse_csr()
         return PerlinAttentionOutput(
-            loss=0, context_layer=ctx, partial_attention_probs=mask_out, partial_attention_mask=mask_out,
+            loss=0, context_layer=ctx, partial_attention_probs=probs_csr, partial_attention_mask=mask_out,
             estimated_attention_probs_m=estimated_attention_probs, estimated_attention_probs=estimated_attention_probs,
             dense_attention_probs=None, key_for_score=k_for_score, state=state)
 
@@ -792,9 +820,12 @@ class PerlinAttention(nn.Module):
                 vs = vs.to(qs.dtype)
             if average_context_layer.dtype != qs.dtype:
                 average_context_layer = average_context_layer.to(qs.dtype)
+            want_probs = self.return_attention_probs or probing
+            probs_csr = None
             with timer('attention.sparse.fused'):
                 if probing:
-                    p1 = ops.sparse_attention(qs, ks, vs, csr, row_scale=row_scale)               # fp32 (N,H,T,D)
+                    p1, pvals = ops.sparse_attention(qs, ks, vs, csr, row_scale=row_scale, want_probs=True)   # fp32 (N,H,T,D)
+                    probs_csr = csr.with_values(pvals)
                     bench.register_temp_buffer('partial_context_layer_1', p1)
                     a = average_scale.unsqueeze(-1)
                     p2 = p1 * a + (1 - a) * average_context_layer
@@ -807,10 +838,16 @@ class PerlinAttention(nn.Module):
                 else:
                     # write straight into the (N, T, H*D) layout of :1279-1282
                     ctx = torch.empty((N, T, H * HID), dtype=out_dtype, device=q.device)
-                    ops.sparse_attention(qs, ks, vs, csr, row_scale=row_scale, avg=average_context_layer,
-                                         mix=average_scale, out=ctx.view(N, T, H, HID).permute(0, 2, 1, 3))
-        csr_out = csr.to_sparse_csr() if self.materialize_csr else csr
-        return ctx, None, csr_out
+                    res = ops.sparse_attention(qs, ks, vs, csr, row_scale=row_scale, avg=average_context_layer,
+                                               mix=average_scale, out=ctx.view(N, T, H, HID).permute(0, 2, 1, 3),
+                                               want_probs=want_probs, path="gather" if want_probs else self.sparse_kernel)
+                    if want_probs:
+                        probs_csr = csr.with_values(res[1])
+        if probs_csr is not None:
+            bench.register_temp_buffer('partial_attention_probs', None, lazy=lambda: ops.flat_csr_to_dense(probs_csr, T_SRC, H))
+        if self.materialize_csr:
+            return ctx, (probs_csr.to_sparse_csr() if probs_csr is not None else None), csr.to_sparse_csr()
+        return ctx, probs_csr, csr
 
     # ------------------------------------------------------------------------------------------------
     def _forward_dense(self, q, v, q_for_score, k_for_score, t_attention_predictor, probs, causal_attention_mask,

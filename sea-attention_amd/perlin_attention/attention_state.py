@@ -51,8 +51,21 @@ class PerformerState:
         return new, (num / den.unsqueeze(-1)).float()
 
 
+def cnn_lookback(cnn) -> int:
+    """Rows the predictor CNN reaches back along the sequence: sum of dilation * (kernel_size - 1) over the causal
+    convolutions of its KeepRes body -- 2 convs * 2 * (3 - 1) = 8 for the standard predictor, 12 with
+    PERLIN_HOTFIX_OPT_DEEPER=1 (three convs; attention.py:266-281).  The reference keeps a fixed 24-row window (:146-147)."""
+    from .modules import CausalConv2d
+    reach = 0
+    for m in cnn.modules():
+        if isinstance(m, CausalConv2d) and m.causal:
+            dil = m.dilation if isinstance(m.dilation, int) else m.dilation[0]
+            reach += dil * (m.kernel_size - 1)
+    return max(reach, 1)
+
+
 class CnnWindowState:
-    LOOKBACK = 8          # rows the two dilated (2) causal 3-tap convolutions reach back: 2 convs * 2 * (3 - 1)
+    LOOKBACK = 8          # the standard predictor's reach (see cnn_lookback); states are built with the real one
 
     def __init__(self, lookback: int = LOOKBACK):
         self.lookback = lookback

@@ -33,13 +33,20 @@ class FlatCSR:
     crow     (N, T_dst+1) int32   row starts inside `col[n]`
     col      (N, z_cap)   int32   head*T_src + key; entries >= crow[n,-1] are undefined
     head_off (N, T_dst, H+1) int32
-    """
+    vals     (N, z_cap)   fp32 or None   per-entry values (None = ones): `partial_attention_probs` carries the
+                                         rs * softmax values here (attention.py:1162-1171)
 
-    def __init__(self, crow, col, head_off, H, T_src, bits=None, row_nnz=None):
+    Code written against the reference's `torch.sparse_csr_tensor` reads `.crow_indices() / .col_indices() / .values()`,
+    `.shape`, `.is_sparse_csr`: those work on this handle too (int64, trimmed to Z = max nnz and zero padded exactly like
+    the wire format; the first such call costs the one host sync the reference pays at causal_resize_m_to_t.py:667)."""
+
+    def __init__(self, crow, col, head_off, H, T_src, bits=None, row_nnz=None, vals=None):
         self.crow, self.col, self.head_off = crow, col, head_off
         self.H, self.T_src = H, T_src
         self.bits, self.row_nnz = bits, row_nnz
+        self.vals = vals
         self.N, self.T_dst = crow.shape[0], crow.shape[1] - 1
+        self._wire = None
 
     @property
     def shape(self):
@@ -49,9 +56,17 @@ class FlatCSR:
     def is_sparse_csr(self):  # duck-typing for callers that only branch on the layout
         return True
 
+    @property
+    def device(self):
+        return self.crow.device
+
     def nnz(self) -> torch.Tensor:
         """device tensor (N,) of valid entries per batch item (no host sync)."""
         return self.crow[:, -1]
+
+    def with_values(self, vals: torch.Tensor) -> "FlatCSR":
+        """Same structure (shared index tensors), other values."""
+        return FlatCSR(self.crow, self.col, self.head_off, self.H, self.T_src, self.bits, self.row_nnz, vals)
 
     def to_sparse_csr(self, values: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Materialise the reference's wire format: int64 indices, trimmed to Z = max nnz
@@ -61,11 +76,32 @@ class FlatCSR:
         col = self.col[:, :Z].to(torch.int64)
         valid = torch.arange(Z, device=col.device).view(1, -1) < crow[:, -1:]
         col = col * valid                                   # the reference zero-fills the padding
+        values = values if values is not None else self.vals
         if values is None:
             values = torch.ones((self.N, Z), dtype=torch.float32, device=col.device)
         else:
-            values = values[:, :Z]
+            values = values[:, :Z] * valid
         return torch.sparse_csr_tensor(crow, col, values, size=self.shape)
+
+    def _wire_format(self):
+        if self._wire is None:
+            self._wire = self.to_sparse_csr()
+        return self._wire
+
+    def crow_indices(self):
+        return self._wire_format().crow_indices()
+
+    def col_indices(self):
+        return self._wire_format().col_indices()
+
+    def values(self):
+        return self._wire_format().values()
+
+    def to(self, device):
+        """PerlinAttentionOutput.to(device) moves every field (attention.py:95-106)."""
+        mv = lambda t: t.to(device) if t is not None else None
+        return FlatCSR(mv(self.crow), mv(self.col), mv(self.head_off), self.H, self.T_src, mv(self.bits), mv(self.row_nnz),
+                       mv(self.vals))
 
 
 def keep_table_causal(H, T_dst, T_m, k, k_oversample=1.0, device=None) -> torch.Tensor:
@@ -182,8 +218,7 @@ _PATHS = {"auto": _lib.SEA_ATTN_AUTO, "gather": _lib.SEA_ATTN_GATHER, "tile": _l
 def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = None,
                      avg: Optional[torch.Tensor] = None, mix: Optional[torch.Tensor] = None,
                      out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None,
-                     path: str = "auto", want_probs: bool = False, row_tiles: int = 0, key_window: int = 0,
-                     tile_form: int = 0):
+                     path: str = "auto", want_probs: bool = False, row_tiles: int = 0, key_window: int = 0):
     """Fused SDDMM + per-(row,head) softmax + row scale + SpMM (+ mix) over the flat CSR (`sea_sparse_attention_ex`).
 
     q (N,H,T_dst,D), k/v (N,H,T_src,D), any [n,h,t] strides, feature stride 1.
@@ -192,8 +227,7 @@ def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = 
     permuted view of an (N,T_dst,H*D) buffer to get the layout of attention.py:1279-1282 directly.
     Default output: fp32 (N,H,T_dst,D) (flat_csr_sdbmm.py:347 returns fp32).
     path: "auto" | "gather" (row-indexed gather kernels) | "tile" (MFMA tile kernel: 16-bit data, D in {64,80,128});
-    row_tiles / key_window tune the tile kernel (0 = defaults); tile_form 1 = its wave-independent form (one wave
-    owns its rows' tiles end to end), 0 / 2 = the workgroup-cooperative form (four waves share every staged K/V row).
+    row_tiles / key_window tune the tile kernel (0 = defaults).
     want_probs: also return the per-entry values rs * softmax (fp32, laid out like csr.col) -- what the reference
     hands out as `partial_attention_probs` (attention.py:1162-1171); returns (out, probs)."""
     lib = _lib.load()
@@ -212,7 +246,7 @@ def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = 
         assert avg is not None and avg.shape == (N, H, T_dst, D) and avg.dtype == q.dtype
         assert mix.dtype == torch.float32 and mix.shape == (N, H, T_dst) and mix.is_contiguous()
     probs = torch.zeros(csr.col.shape, dtype=torch.float32, device=q.device) if want_probs else None
-    flags = _PATHS[path] | ((int(row_tiles) & 0xf) << 8) | ((int(tile_form) & 0xf) << 16)
+    flags = _PATHS[path] | ((int(row_tiles) & 0xf) << 8)
     if key_window:
         assert key_window & (key_window - 1) == 0, "key_window is a power of two"
         flags |= (int(key_window).bit_length() - 1) << 12

@@ -102,6 +102,8 @@ class PerlinSelfAttention(nn.Module):
                 query_layer_for_atten, key_layer_for_atten, value_layer_for_atten,
                 query_layer_for_score, key_layer_for_score,
                 attention_mask, attention_scores_truth, context_layer_truth, last_state)
+        if self.checkout_last_attention_probs:                  # sparse mode computes the CSR probabilities only on request
+            self.attention.return_attention_probs = True
         if self._gradient_checkpointing and self.training:
             def run(*a):
                 return tuple(self.attention(*a))

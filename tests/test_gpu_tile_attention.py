@@ -39,7 +39,6 @@ def _case(N, H, T_dst, T_src, T_M, k, d, dtype, seed=7, structured=False):
     return probs, q, kk, v, rs, mx, avg, keep, crow, col
 
 
-@pytest.mark.parametrize("form", [2, 1])
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,H,T_dst,T_src,T_M,k,d,rt,kw", [
     (2, 12, 1024, 1024, 256, 64, 64, 0, 0),        # defaults
@@ -53,12 +52,12 @@ def _case(N, H, T_dst, T_src, T_M, k, d, dtype, seed=7, structured=False):
     (1, 6, 9, 500, 64, 16, 128, 0, 0),
     (1, 2, 70, 4100, 256, 64, 64, 2, 4096),        # keys beyond one 4096-key window
 ])
-def test_tile_path_vs_oracle(ops, form, dtype, N, H, T_dst, T_src, T_M, k, d, rt, kw):
+def test_tile_path_vs_oracle(ops, dtype, N, H, T_dst, T_src, T_M, k, d, rt, kw):
     probs, q, kk, v, rs, mx, avg, keep, crow, col = _case(N, H, T_dst, T_src, T_M, k, d, dtype)
     sparse = O.sparse_attention(q.float(), kk.float(), v.float(), crow, col, rs)
     csr, _ = ops.topk_to_csr(probs.to(DEV), keep.to(torch.int32).to(DEV), k, target_width=T_src)
     qd, kd, vd = q.to(DEV), kk.to(DEV), v.to(DEV)
-    out = ops.sparse_attention(qd, kd, vd, csr, row_scale=rs.to(DEV), path="tile", row_tiles=rt, key_window=kw, tile_form=form)
+    out = ops.sparse_attention(qd, kd, vd, csr, row_scale=rs.to(DEV), path="tile", row_tiles=rt, key_window=kw)
     assert out.dtype == torch.float32
     err = (out.cpu() - sparse).abs().max().item()
     rel = ((out.cpu() - sparse).norm() / sparse.norm()).item()
@@ -70,12 +69,12 @@ def test_tile_path_vs_oracle(ops, form, dtype, N, H, T_dst, T_src, T_M, k, d, rt
     ref = sparse * mx.unsqueeze(-1) + (1.0 - mx.unsqueeze(-1)) * avg.float()
     ctx = torch.empty((N, T_dst, H * d), dtype=dtype, device=DEV)
     ops.sparse_attention(qd, kd, vd, csr, row_scale=rs.to(DEV), avg=avg.to(DEV), mix=mx.to(DEV),
-                         out=ctx.view(N, T_dst, H, d).permute(0, 2, 1, 3), path="tile", row_tiles=rt, key_window=kw, tile_form=form)
+                         out=ctx.view(N, T_dst, H, d).permute(0, 2, 1, 3), path="tile", row_tiles=rt, key_window=kw)
     got = ctx.view(N, T_dst, H, d).permute(0, 2, 1, 3).float().cpu()
     tol = 1e-2 if dtype == torch.bfloat16 else 2e-3
     torch.testing.assert_close(got, ref, atol=tol, rtol=tol)
     # determinism
-    again = ops.sparse_attention(qd, kd, vd, csr, row_scale=rs.to(DEV), path="tile", row_tiles=rt, key_window=kw, tile_form=form)
+    again = ops.sparse_attention(qd, kd, vd, csr, row_scale=rs.to(DEV), path="tile", row_tiles=rt, key_window=kw)
     assert torch.equal(out, again)
 
 
@@ -90,13 +89,11 @@ def test_tile_path_strided_inputs_and_window_choice_agree(ops):
     big[:, :, 0] = q.permute(0, 2, 1, 3); big[:, :, 1] = kk.permute(0, 2, 1, 3); big[:, :, 2] = v.permute(0, 2, 1, 3)
     bd = big.to(DEV)
     qv, kv, vv = (bd[:, :, i].permute(0, 2, 1, 3) for i in range(3))
-    for form in (1, 2):
-        for rt in (1, 2):
-            for kw in (64, 512, 2048):
-                out = ops.sparse_attention(qv, kv, vv, csr, row_scale=rs.to(DEV), path="tile", row_tiles=rt, key_window=kw,
-                                           tile_form=form)
-                assert ((out.cpu() - ref).norm() / ref.norm()).item() < 1e-3, (form, rt, kw)
-                assert (out.cpu() - ref).abs().max().item() < 2e-3, (form, rt, kw)
+    for rt in (1, 2):
+        for kw in (64, 512, 2048):
+            out = ops.sparse_attention(qv, kv, vv, csr, row_scale=rs.to(DEV), path="tile", row_tiles=rt, key_window=kw)
+            assert ((out.cpu() - ref).norm() / ref.norm()).item() < 1e-3, (rt, kw)
+            assert (out.cpu() - ref).abs().max().item() < 2e-3, (rt, kw)
 
 
 def test_tile_path_rejects_what_it_cannot_do(ops):

@@ -285,3 +285,42 @@ def test_decoding_sub_states_match_one_shot_computation():
             ws, o = ws.step(cnn, x[..., pos:pos + step, :]); outs.append(o); pos += step
     torch.testing.assert_close(torch.cat(outs, -2), full, atol=1e-5, rtol=1e-5)
     assert ws.rows.shape[-2] == CnnWindowState.LOOKBACK
+
+
+def test_cnn_lookback_follows_the_conv_stack(monkeypatch):
+    """The kv-cache CNN window is derived from the predictor's causal convolutions: 8 rows for the standard
+    two dilated 3-tap convs, 12 with PERLIN_HOTFIX_OPT_DEEPER=1."""
+    from sea_attention_amd.perlin_attention import PerlinAttentionConfig, PerlinSelfAttention
+    from sea_attention_amd.perlin_attention.attention_state import cnn_lookback
+
+    class Cfg:
+        hidden_size, num_attention_heads, max_position_embeddings = 64, 4, 128
+    pc = PerlinAttentionConfig(k=8, attention_predictor_length=32, performer_nb_factor=8, causal=True, k_flatten=True,
+                               k_flatten_dim='causal_batch', context_output_method='mix')
+    assert cnn_lookback(PerlinSelfAttention(Cfg(), pc).attention.attention_predictor_cnn) == 8
+    monkeypatch.setenv("PERLIN_HOTFIX_OPT_DEEPER", "1")
+    assert cnn_lookback(PerlinSelfAttention(Cfg(), pc).attention.attention_predictor_cnn) == 12
+
+
+def test_prep_cache_key_sees_storage_swaps_and_device_tags():
+    """ops.predictor._cached: a parameter whose storage was swapped (`param.data = other`) or that moved must miss; an
+    untouched one must hit; clear_prep_cache() empties it."""
+    import torch
+    from sea_attention_amd.perlin_attention.ops import predictor as P
+    P.clear_prep_cache()
+    w = torch.nn.Parameter(torch.randn(4, 4))
+    calls = []
+    build = lambda: calls.append(1) or w.detach().clone()
+    a = P._cached("t", (w,), torch.float32, build)
+    b = P._cached("t", (w,), torch.float32, build)
+    assert a is b and len(calls) == 1
+    w.data = torch.randn(4, 4)                                   # same Parameter object, same _version, new storage
+    c = P._cached("t", (w,), torch.float32, build)
+    assert c is not a and len(calls) == 2
+    with torch.no_grad():
+        w.add_(1.0)                                              # autograd-visible in-place edit: version bump
+    P._cached("t", (w,), torch.float32, build)
+    assert len(calls) == 3
+    P.clear_prep_cache()
+    P._cached("t", (w,), torch.float32, build)
+    assert len(calls) == 4

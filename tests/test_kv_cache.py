@@ -75,6 +75,48 @@ def test_cached_decoding_matches_stateless(dtype, tol, N, H, T, d, T_M, k, T0, c
         assert rel < 0.2 and bad < 0.35, (bad, rel, err.max().item())
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_cached_decoding_with_the_deeper_predictor_cnn(monkeypatch, dtype):
+    """PERLIN_HOTFIX_OPT_DEEPER=1 builds three dilated causal convolutions (attention.py:266-281): they reach back
+    3 * 2 * (3 - 1) = 12 rows, so the carried CNN window must be 12 rows, not the standard predictor's 8.  fp32 runs the
+    torch-module estimator with the reference's kind of state, bf16 the HIP estimator (C8 window + state image)."""
+    from sea_attention_amd.perlin_attention.attention_state import cnn_lookback
+    monkeypatch.setenv("PERLIN_HOTFIX_OPT_DEEPER", "1")
+    N, H, T, d, T_M, k, T0, chunks = 1, 4, 160, 64, 256, 16, 64, (1, 1, 5, 25, 64)
+    full = _layer(H, d, T_M, k, T, dtype, use_cache=False)
+    cached = _layer(H, d, T_M, k, T, dtype, use_cache=True)
+    cached.load_state_dict(full.state_dict())
+    if dtype != torch.float32:
+        full.attention.force_torch_estimator = False
+        cached.attention.force_torch_estimator = False
+    assert cnn_lookback(cached.attention.attention_predictor_cnn) == 12
+    S.seed(9)
+    x = torch.randn((N, H, T, d), device=DEV).to(dtype)
+    q = (x.float() * d ** -0.5).to(dtype)
+    with torch.no_grad():
+        ref_out = full(None, None, None, query_layer=q, key_layer=x, value_layer=x, attention_mask=_mask(N, T, T, dtype))
+        ref, ref_map = ref_out.context_layer.float(), ref_out.estimated_attention_probs_m.float()
+        state, got, maps, pos = None, [], [], 0
+        for step in (T0,) + tuple(chunks):
+            hi = pos + step
+            out = cached(None, None, None, query_layer=q[:, :, pos:hi], key_layer=x[:, :, :hi], value_layer=x[:, :, :hi],
+                         attention_mask=_mask(N, step, hi, dtype), last_state=state)
+            state = out.state
+            win = state.states[PerlinAttentionState.CNN]
+            assert win.lookback == 12
+            got.append(out.context_layer.float()); maps.append(out.estimated_attention_probs_m.float())
+            pos = hi
+    got, maps = torch.cat(got, dim=1), torch.cat(maps, dim=2)
+    if dtype == torch.float32:
+        assert (maps - ref_map).abs().max().item() < 1e-5             # an 8-row window would differ at 1e-2 .. 1e-1 here
+        assert ((got - ref).norm() / ref.norm()).item() < 1e-4
+    else:
+        # whole 64-row chunks reproduce the stateless map bit for bit (T0 = 64 and the last chunk); ragged pieces regroup
+        # fp32 sums inside a Performer chunk, so their maps agree to bf16 rounding
+        assert torch.equal(maps[:, :, :64], ref_map[:, :, :64])
+        assert (maps - ref_map).abs().max().item() < 2e-2
+
+
 def test_state_is_copy_on_write_and_cnn_window_is_enough():
     N, H, T, d, T_M, k = 1, 4, 48, 32, 32, 8
     cached = _layer(H, d, T_M, k, T, torch.float32, use_cache=True)
@@ -119,8 +161,9 @@ def test_cached_decoding_on_the_hip_estimator(dtype, N, H, T, T_M, k, T0, chunks
     x = torch.randn((N, H, T, d), device=DEV).to(dtype)
     q = (x.float() * d ** -0.5).to(dtype)
     with torch.no_grad():
-        ref = full(None, None, None, query_layer=q, key_layer=x, value_layer=x, attention_mask=_mask(N, T, T, dtype)).context_layer.float()
-        state, got, pos = None, [], 0
+        ref_out = full(None, None, None, query_layer=q, key_layer=x, value_layer=x, attention_mask=_mask(N, T, T, dtype))
+        ref, ref_bits = ref_out.context_layer.float(), ref_out.partial_attention_mask.bits
+        state, got, bits, pos = None, [], [], 0
         for step in (T0,) + tuple(chunks):
             hi = pos + step
             out = cached(None, None, None, query_layer=q[:, :, pos:hi], key_layer=x[:, :, :hi], value_layer=x[:, :, :hi],
@@ -129,18 +172,29 @@ def test_cached_decoding_on_the_hip_estimator(dtype, N, H, T, T_M, k, T0, chunks
             win = state.states[PerlinAttentionState.CNN]
             assert win.rows is None and win.rows_c8 is not None and win.rows_c8.shape[1] == min(hi, CnnWindowState.LOOKBACK)
             assert win.rows_c8.shape[2:] == (2 * H // 8, T_M // 4, 8)
-            got.append(out.context_layer.float())
+            got.append(out.context_layer.float()); bits.append(out.partial_attention_mask.bits)
             pos = hi
-    got = torch.cat(got, dim=1)
+    got, bits = torch.cat(got, dim=1), torch.cat(bits, dim=1)
+    # What separates cached from stateless rows is the TOP-K CHOICE, not arithmetic: the cached Performer regroups its
+    # fp32 sums inside a 64-row chunk, a map value lands on the neighbouring 16-bit number now and then, and where that
+    # value sat next to the K_t-th largest the kept pixel set changes.  So the comparison is split: (1) the share of rows
+    # whose kept set differs at all (the flip rate) is reported and bounded; (2) rows that kept the SAME set must agree
+    # to the 16-bit rounding of the context; (3) the whole context stays close.
+    same = (bits == ref_bits).all(-1)                                   # (N, T) kept-pixel set identical
+    flip_rate = 1.0 - same.float().mean().item()
     err = (got - ref).abs().amax(-1)
     scale = ref.abs().amax(-1).clamp_min(1.0)
-    bad = (err > 3e-2 * scale).float().mean().item()
+    row_tol = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -9       # two rounding steps of the 16-bit context
+    tight = (err[same] <= row_tol * scale[same]).float().mean().item() if same.any() else 1.0
+    rel_same = ((got[same] - ref[same]).norm() / ref[same].norm()).item() if same.any() else 0.0
     rel = ((got - ref).norm() / ref.norm()).item()
-    print(f"hip-estimator decode {dtype} T_M={T_M}: rows off {bad:.3f}, rel {rel:.4f}")
-    # measured: bf16 rel 0.017-0.032 / rows off <= 0.08, fp16 rel <= 0.004 / rows off <= 0.01 (the torch-estimator path
-    # in bf16 sits at rel ~0.1: there MLP / CNN round differently on the two sides as well)
-    lim_rel, lim_bad = (0.08, 0.2) if dtype == torch.bfloat16 else (0.03, 0.05)
-    assert rel < lim_rel and bad < lim_bad, (bad, rel, err.max().item())
+    print(f"hip-estimator decode {dtype} T_M={T_M}: top-k flip rate {flip_rate:.3f} of rows, rows with the same set: "
+          f"{tight:.4f} within {row_tol:.4f}, rel {rel_same:.5f}; all rows rel {rel:.4f}")
+    lim_flip = 0.30 if dtype == torch.bfloat16 else 0.08
+    assert flip_rate < lim_flip, flip_rate
+    assert tight > 0.995 and rel_same < 6e-3, (tight, rel_same)         # same keys -> same context up to 16-bit rounding
+    lim_rel = 0.08 if dtype == torch.bfloat16 else 0.03
+    assert rel < lim_rel, rel
     # a state written by the HIP estimator cannot continue on the torch estimator (different window contents)
     cached.attention.force_torch_estimator = True
     with torch.no_grad(), pytest.raises(AssertionError, match="HIP estimator"):
