@@ -159,9 +159,9 @@ int sea_sparse_attention(const void* q, const void* k, const void* v, int dtype,
 /* The same operator with two more knobs.
  *
  * flags, low byte = kernel path:
- *   SEA_ATTN_AUTO    the library picks (today: the gather kernels -- the tile kernel pays off only when neighbouring
- *                    query rows share most of their keys, which the library cannot know without reading the CSR;
- *                    measured cross-over: >= ~22 entries per 16-row x 16-key tile);
+ *   SEA_ATTN_AUTO    with a `block_path` plan (sea_attention_plan): per 16-row block, the kernel the plan names;
+ *                    without one: the gather kernels (the tile kernel pays off only where neighbouring query rows
+ *                    share most of their keys: >= ~30 entries per staged 16-key tile);
  *   SEA_ATTN_GATHER  row-indexed gather kernels (sea_attn.hip): one lane group per (n,h,t) row walks the row's entries,
  *                    every K / V row is fetched per entry (L2-served); any dtype, any D <= 64*vec, duplicates counted;
  *   SEA_ATTN_TILE    MFMA tile kernel (sea_attn_tile.hip): a wave owns 16 (or 32) consecutive query rows of one (n,h),
@@ -185,8 +185,20 @@ int sea_sparse_attention_ex(const void* q, const void* k, const void* v, int dty
                             const float* row_scale, const void* avg, const int64_t* avg_strides,
                             const float* mix,
                             void* out, int out_dtype, const int64_t* out_strides,
-                            float* probs_out, int64_t probs_stride_n, int flags,
-                            sea_stream_t stream);
+                            float* probs_out, int64_t probs_stride_n,
+                            const uint8_t* block_path, /* buffer filled by sea_attention_plan, or NULL */
+                            int flags, sea_stream_t stream);
+
+/* Per-block dispatch plan for SEA_ATTN_AUTO: one byte per (n, h, 16-row block), 1 = the tile kernel owns the block, 0 = the
+ * gather kernels do.  With a plan, sea_sparse_attention_ex launches BOTH kernels over all rows and every wave runs only the
+ * blocks its kernel owns (no host round trip, graph-capturable).  The plan is estimated from the kept-pixel bit masks of
+ * sea_topk_select / sea_predictor_tail_select (`bits`, (N,T_dst,ceil(H*T_m/32))): entries a block walks against the 16-key
+ * tiles it would stage; the tile kernel gets the block when entries >= entries_per_tile * tiles (<= 0: the measured
+ * cross-over, 30).  When the plan gives the tile kernel more than half of the blocks it gets all of them (two partly
+ * filled launches cost more than the remaining blocks win back): the count is kept in an int32 behind the bytes, so
+ * `block_path` must hold ((N*H*ceil(T_dst/16) + 3) & ~3) + 4 bytes.  T_m % 32 == 0, H <= 64. */
+int sea_attention_plan(const uint32_t* bits, int64_t N, int64_t H, int64_t T_dst, int64_t T_src, int64_t T_m,
+                       int is_causal, float entries_per_tile, uint8_t* block_path, sea_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Bandwidth-bound estimator / epilogue pieces (the callers either side of the hot kernels).

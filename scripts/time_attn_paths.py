@@ -20,7 +20,7 @@ ap.add_argument("--workload", default="opt-1.3b")
 ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--maps", default="layer,random,structured")
-ap.add_argument("--variants", default="gather,tile:1:0,tile:2:0")
+ap.add_argument("--variants", default="gather,tile:1:0,plan")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 w = WORKLOADS[a.workload]
@@ -73,6 +73,10 @@ for name in a.maps.split(","):
     for var in a.variants.split(","):
         parts = var.split(":")
         kw = dict(path=parts[0])
+        if parts[0] == "plan":                                # per-block dispatch, optional entries-per-tile threshold
+            pl = ops.attention_plan(csr, T_M, entries_per_tile=float(parts[1]) if len(parts) > 1 else 0.0)
+            kw = dict(path="auto", plan=pl)
+            share = float(ops.plan_blocks(pl, NB, H, T).float().mean().item())
         if parts[0] == "tile":
             kw.update(row_tiles=int(parts[1]), key_window=int(parts[2]))
         try:
@@ -87,7 +91,10 @@ for name in a.maps.split(","):
             torch.cuda.synchronize()
             ms = e0.elapsed_time(e1) / a.iters
             err = (ctx.float() - ctx_ref.float()).abs().max().item()
-            print(json.dumps({"map": name, "variant": var, "ms": round(ms, 4), "alg_TBs": round(alg / ms / 1e9, 2),
-                              "nnz": Z, "max_abs_diff_vs_gather": round(err, 5)}), flush=True)
+            rec = {"map": name, "variant": var, "ms": round(ms, 4), "alg_TBs": round(alg / ms / 1e9, 2),
+                   "nnz": Z, "max_abs_diff_vs_gather": round(err, 5)}
+            if parts[0] == "plan":
+                rec["blocks_on_tile_kernel"] = round(share, 4)
+            print(json.dumps(rec), flush=True)
         except Exception as ex:  # noqa: BLE001
             print(json.dumps({"map": name, "variant": var, "error": str(ex)[:200]}), flush=True)

@@ -72,6 +72,7 @@ __global__ __launch_bounds__(256) void sparse_attn_kernel(AttnParams p) {
   const int n = pair / p.H, h = pair - n * p.H;
   const int t = tb * 4 + (threadIdx.x >> 6);
   if (t >= p.T_dst) return;
+  if (block_is_foreign(p, n, h, t)) return;
   const int lane = threadIdx.x & 63;
   const int grp = lane / LPR, sub = lane - grp * LPR;
   const bool dact = sub * VEC < p.D;
@@ -195,6 +196,7 @@ __global__ __launch_bounds__(NWB * 64) void sparse_attn_rows_kernel(AttnParams p
   const int lane = threadIdx.x & 63;
   const int grp = lane / LPR, sub = lane - grp * LPR;
   const int t = tb * RPB + (threadIdx.x >> 6) * RPW + grp;
+  if (block_is_foreign(p, n, h, min(tb * RPB + (int)(threadIdx.x >> 6) * RPW, p.T_dst - 1))) return;   // RPW divides 16
   const bool rowok = t < p.T_dst;
   const bool dact = sub * VEC < p.D;
   const int tt = rowok ? t : p.T_dst - 1;
@@ -337,6 +339,7 @@ __global__ __launch_bounds__(NWB * 64) void sparse_attn_rows80_kernel(AttnParams
   const int lane = threadIdx.x & 63;
   const int grp = lane / LPR, sub = lane - grp * LPR;
   const int t = tb * RPB + (threadIdx.x >> 6) * RPW + grp;
+  if (block_is_foreign(p, n, h, min(tb * RPB + (int)(threadIdx.x >> 6) * RPW, p.T_dst - 1))) return;
   const bool rowok = t < p.T_dst;
   const int tt = rowok ? t : p.T_dst - 1;
 
@@ -664,7 +667,8 @@ extern "C" int sea_sparse_attention_ex(const void* q, const void* k, const void*
                                        const int32_t* col, int64_t col_stride_n, const int32_t* head_off,
                                        const float* row_scale, const void* avg, const int64_t* avg_strides,
                                        const float* mix, void* out, int out_dtype, const int64_t* out_strides,
-                                       float* probs_out, int64_t probs_stride_n, int flags, sea_stream_t stream) {
+                                       float* probs_out, int64_t probs_stride_n, const uint8_t* block_path, int flags,
+                                       sea_stream_t stream) {
   const char* nm = "sea_sparse_attention";
   SEA_REQUIRE(q && k && v && crow && col && head_off && out && q_strides && k_strides && v_strides && out_strides,
               SEA_EINVAL, "%s: null pointer", nm);
@@ -694,6 +698,8 @@ extern "C" int sea_sparse_attention_ex(const void* q, const void* k, const void*
   p.crow = crow; p.col = col; p.col_stride_n = col_stride_n; p.head_off = head_off;
   p.row_scale = row_scale; p.avg = avg; p.mix = mix; p.out = out;
   p.probs = probs_out; p.probs_stride_n = probs_stride_n;
+  p.sel = nullptr; p.sel_want = 0; p.TB16 = (int)((T_dst + 15) / 16);
+  p.sel_count = nullptr; p.sel_total = (int)(N * H * p.TB16);
   p.TB = (int)((T_dst + 3) / 4);
   hipStream_t s = (hipStream_t)stream;
   const bool tile_ok = attn_tile_supported(dtype, (int)D, (int)T_src, p) && probs_out == nullptr;
@@ -706,6 +712,15 @@ extern "C" int sea_sparse_attention_ex(const void* q, const void* k, const void*
     SEA_REQUIRE(rc == SEA_OK, rc, "%s: tile kernel launch parameters rejected (flags 0x%x)", nm, flags);
     SEA_CHECK_LAUNCH(nm);
     return SEA_OK;
+  }
+  if (path == SEA_ATTN_AUTO && block_path && tile_ok) {      // per-block dispatch: both kernels over the same rows, each
+    p.sel = block_path;                                     // wave runs only the 16-row blocks the plan gave its kernel
+    p.sel_count = reinterpret_cast<const int32_t*>(block_path + plan_count_offset(N, H, p.TB16));
+    p.sel_want = 1;
+    rc = launch_attn_tile(p, dtype, out_dtype, flags, s);
+    SEA_REQUIRE(rc == SEA_OK, rc, "%s: tile kernel launch parameters rejected (flags 0x%x)", nm, flags);
+    SEA_CHECK_LAUNCH(nm);
+    p.sel_want = 0;
   }
   if (dtype == SEA_F32) rc = launch_attn<float, float>(p, s);
   else if (dtype == SEA_F16) rc = out_dtype == SEA_F32 ? launch_attn<__half, float>(p, s) : launch_attn<__half, __half>(p, s);
@@ -724,7 +739,21 @@ extern "C" int sea_sparse_attention(const void* q, const void* k, const void* v,
                                     sea_stream_t stream) {
   return sea_sparse_attention_ex(q, k, v, dtype, N, H, T_dst, T_src, D, q_strides, k_strides, v_strides, crow, col,
                                  col_stride_n, head_off, row_scale, avg, avg_strides, mix, out, out_dtype, out_strides,
-                                 nullptr, 0, SEA_ATTN_AUTO, stream);
+                                 nullptr, 0, nullptr, SEA_ATTN_AUTO, stream);
+}
+
+extern "C" int sea_attention_plan(const uint32_t* bits, int64_t N, int64_t H, int64_t T_dst, int64_t T_src, int64_t T_m,
+                                  int is_causal, float entries_per_tile, uint8_t* block_path, sea_stream_t stream) {
+  const char* nm = "sea_attention_plan";
+  SEA_REQUIRE(bits && block_path, SEA_EINVAL, "%s: null pointer", nm);
+  SEA_REQUIRE(N > 0 && H > 0 && T_dst > 0 && T_src > 0 && T_m > 0, SEA_EINVAL, "%s: bad shape", nm);
+  SEA_REQUIRE(hipMemsetAsync(block_path + plan_count_offset(N, H, (T_dst + 15) / 16), 0, 4, (hipStream_t)stream) == hipSuccess,
+              SEA_ELAUNCH, "%s: memset failed", nm);
+  const int rc = launch_attn_plan(bits, (int)N, (int)H, (int)T_dst, (int)T_src, (int)T_m, is_causal,
+                                  entries_per_tile > 0.f ? entries_per_tile : 30.0f, block_path, (hipStream_t)stream);
+  SEA_REQUIRE(rc == SEA_OK, rc, "%s: needs T_m %% 32 == 0, H <= 64 and H * T_m <= 32768", nm);
+  SEA_CHECK_LAUNCH(nm);
+  return SEA_OK;
 }
 
 extern "C" int64_t sea_sparse_attention_bytes(int64_t Z, int64_t N, int64_t H, int64_t T_dst, int64_t D, int elem_bytes) {

@@ -20,6 +20,12 @@ struct AttnParams {
   int64_t os[3];
   float* probs;            // optional (N, probs_stride_n): rs * softmax per entry (gather kernels only)
   int64_t probs_stride_n;
+  // per-block dispatch (sea_attention_plan): sel[(n * H + h) * TB16 + t / 16] says which kernel owns the 16-row block; a
+  // wave whose block belongs to the other kernel exits at once (both kernels are launched over the same rows)
+  const uint8_t* sel;
+  int sel_want, TB16;
+  const int32_t* sel_count;  // blocks the plan gave the tile kernel; when that is most of them (sel_total / 2), ALL go there
+  int sel_total;
   int TB;  // row blocks per (n, h): ceil(T_dst / 4)
 };
 
@@ -67,8 +73,22 @@ __device__ inline bool map_block(int NH, int TB, int* pair, int* tb) {
   return *pair < NH;
 }
 
+// true when the 16-row block of query row t is NOT this kernel's (wave-uniform when the wave's rows share a block)
+__device__ inline bool block_is_foreign(const AttnParams& p, int n, int h, int t) {
+  if (p.sel == nullptr) return false;
+  // a map whose rows mostly share their keys runs best on the tile kernel alone (two partly filled launches cost more
+  // than the few blocks the gather kernels would win back): measured, scripts/sweep_plan_cut.py
+  if (2 * (int64_t)p.sel_count[0] > (int64_t)p.sel_total) return p.sel_want != 1;
+  return p.sel[((int64_t)n * p.H + h) * p.TB16 + (t >> 4)] != (uint8_t)p.sel_want;
+}
+
+// the tile-block counter sits behind the plan's bytes, 4-byte aligned
+__host__ __device__ inline int64_t plan_count_offset(int64_t N, int64_t H, int64_t TB16) { return (N * H * TB16 + 3) & ~(int64_t)3; }
+
 // launchers of the MFMA tile kernel (sea_attn_tile.hip); `flags`: see SEA_ATTN_* in sea_hip.h
 bool attn_tile_supported(int dtype, int D, int T_src, const AttnParams& p);
 int launch_attn_tile(const AttnParams& p, int dtype, int out_dtype, int flags, hipStream_t s);
+int launch_attn_plan(const uint32_t* bits, int N, int H, int T_dst, int T_src, int T_m, int causal, float entries_per_tile,
+                     uint8_t* sel, hipStream_t s);
 
 }  // namespace sea

@@ -120,6 +120,7 @@ __global__ __launch_bounds__(NW * 64) void sparse_attn_tile_kernel(AttnParams p,
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int t0 = (tb * NW + wave) * ROWS;
   if (t0 >= p.T_dst) return;                               // wave-uniform; the kernel has no workgroup barrier
+  if (RT == 1 && block_is_foreign(p, n, h, t0)) return;    // per-block dispatch (plans are per 16 rows: RT = 1 only)
 
   const int WPR = KW >> 5, BST = WPR + 1;                  // bitmap words per row, padded row stride (banks)
   char* wbase = at_smem + wave * wave_lds;
@@ -385,6 +386,82 @@ __global__ __launch_bounds__(NW * 64) void sparse_attn_tile_kernel(AttnParams p,
   }
 }
 
+// ---- per-block dispatch plan -----------------------------------------------------------------------------------------
+// Which kernel should own a 16-row block of one head?  The tile kernel's time goes with the 16-key tiles it stages, the
+// gather kernels' with the entries they walk; measured on MI355X (OPT-1.3B / 2.7B / LLaMA-13B shapes, three kinds of map,
+// scripts/time_attn_paths.py, scripts/sweep_plan_cut.py) the two cross at about 30 entries per staged tile.  Both figures are estimated from the
+// kept-PIXEL bit masks of the selection kernel (no CSR walk): entries = sum over rows of kept pixels x pixel width,
+// tiles = union pixels x width / 16 plus about two tiles of slack per run of adjacent union pixels (run ends are not
+// tile aligned and pixel boundaries drift by up to 15 keys over 16 rows), capped by the tiles a row can see.
+struct PlanParams {
+  const uint32_t* bits;    // (N, T_dst, W)
+  uint8_t* sel;            // (N, H, TB16)
+  int32_t* count;          // blocks given to the tile kernel (zeroed by the caller)
+  int N, H, T_dst, T_src, T_m, W, TB16, causal;
+  float entries_per_tile;
+};
+
+__global__ __launch_bounds__(256) void attn_plan_kernel(PlanParams p) {
+  __shared__ uint32_t s_or[1024];
+  __shared__ int s_cnt[3 * 64];                            // per head: union pixels, kept pixels over the rows, runs
+  const int blk = blockIdx.x;
+  const int n = blk / p.TB16, t16 = blk - n * p.TB16;
+  const int t0 = t16 * 16, rows = min(16, p.T_dst - t0);
+  const int WPH = p.T_m >> 5;                              // words per head
+  for (int i = threadIdx.x; i < 3 * p.H; i += 256) s_cnt[i] = 0;
+  const uint32_t* b0 = p.bits + ((int64_t)n * p.T_dst + t0) * p.W;
+  uint32_t orw[4];
+  int cnt[4];
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int w = threadIdx.x + 256 * u;
+    orw[u] = 0u; cnt[u] = 0;
+    if (w < p.W) {
+      for (int r = 0; r < rows; ++r) {
+        const uint32_t x = b0[(int64_t)r * p.W + w];
+        orw[u] |= x;
+        cnt[u] += __popc(x);
+      }
+      s_or[w] = orw[u];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    const int w = threadIdx.x + 256 * u;
+    if (w < p.W && orw[u] != 0u) {
+      const int hh = w / WPH, wi = w - hh * WPH;
+      const uint32_t carry = wi ? (s_or[w - 1] >> 31) : 0u;
+      const int runs = __popc(orw[u] & ~((orw[u] << 1) | carry));
+      atomicAdd(&s_cnt[3 * hh], __popc(orw[u]));
+      atomicAdd(&s_cnt[3 * hh + 1], cnt[u]);
+      atomicAdd(&s_cnt[3 * hh + 2], runs);
+    }
+  }
+  __syncthreads();
+  for (int hh = threadIdx.x; hh < p.H; hh += 256) {
+    const int w_last = p.causal ? (p.T_src - p.T_dst + t0 + rows) : p.T_src;      // keys the block's last row sees
+    const float pw = (float)w_last / (float)p.T_m;                                // keys per pixel
+    const float entries = (float)s_cnt[3 * hh + 1] * fminf(pw, 64.f);
+    float tiles = (float)s_cnt[3 * hh] * pw * (1.0f / 16.0f) + 2.0f * (float)s_cnt[3 * hh + 2];
+    tiles = fminf(tiles, (float)((w_last + 15) / 16 + 1));
+    const bool tile = entries >= p.entries_per_tile * tiles && tiles > 0.f;
+    p.sel[((int64_t)n * p.H + hh) * p.TB16 + t16] = tile ? 1 : 0;
+    if (tile) atomicAdd(p.count, 1);
+  }
+}
+
+int launch_attn_plan(const uint32_t* bits, int N, int H, int T_dst, int T_src, int T_m, int causal, float entries_per_tile,
+                     uint8_t* sel, hipStream_t s) {
+  PlanParams p;
+  p.bits = bits; p.sel = sel; p.count = reinterpret_cast<int32_t*>(sel + plan_count_offset(N, H, (T_dst + 15) / 16)); p.N = N; p.H = H; p.T_dst = T_dst; p.T_src = T_src; p.T_m = T_m;
+  p.W = (H * T_m + 31) / 32; p.TB16 = (T_dst + 15) / 16; p.causal = causal;
+  p.entries_per_tile = entries_per_tile;
+  if (T_m % 32 != 0 || p.W > 1024 || H > 64) return SEA_EUNSUPPORTED;
+  hipLaunchKernelGGL(attn_plan_kernel, dim3((unsigned)(N * p.TB16)), dim3(256), 0, s, p);
+  return SEA_OK;
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------------
 bool attn_tile_supported(int dtype, int D, int T_src, const AttnParams& p) {
   if (dtype != SEA_F16 && dtype != SEA_BF16) return false;
@@ -429,7 +506,7 @@ static int launch_tile_t(const AttnParams& p, int rt, int KW, hipStream_t s) {
 int launch_attn_tile(const AttnParams& p, int dtype, int out_dtype, int flags, hipStream_t s) {
   // flags (SEA_ATTN_* in sea_hip.h): bits 8..11 = row tiles per wave (0: default), bits 12..15 = log2 of the key window
   int rt = (flags >> 8) & 0xf;
-  if (rt == 0) rt = 1;
+  if (rt == 0 || p.sel) rt = 1;                            // a dispatch plan speaks of 16-row blocks
   if (rt != 1 && rt != 2) return SEA_EINVAL;
   const int kwl = (flags >> 12) & 0xf;
   int KW = kwl ? (1 << kwl) : 2048;

@@ -838,9 +838,16 @@ class PerlinAttention(nn.Module):
                 else:
                     # write straight into the (N, T, H*D) layout of :1279-1282
                     ctx = torch.empty((N, T, H * HID), dtype=out_dtype, device=q.device)
+                    plan = None
+                    if (self.sparse_kernel == "auto" and not want_probs and qs.dtype != torch.float32
+                            and HID in (64, 80, 128)):
+                        # per-block dispatch: 16-row blocks whose rows share most of their keys go to the MFMA tile
+                        # kernel, the rest to the gather kernels (one small launch over the selection's pixel masks)
+                        plan = ops.attention_plan(csr, T_M, is_causal=True)
                     res = ops.sparse_attention(qs, ks, vs, csr, row_scale=row_scale, avg=average_context_layer,
                                                mix=average_scale, out=ctx.view(N, T, H, HID).permute(0, 2, 1, 3),
-                                               want_probs=want_probs, path="gather" if want_probs else self.sparse_kernel)
+                                               want_probs=want_probs, path="gather" if want_probs else self.sparse_kernel,
+                                               plan=plan)
                     if want_probs:
                         probs_csr = csr.with_values(res[1])
         if probs_csr is not None:

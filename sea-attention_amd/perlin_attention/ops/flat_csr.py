@@ -215,10 +215,29 @@ _PATHS = {"auto": _lib.SEA_ATTN_AUTO, "gather": _lib.SEA_ATTN_GATHER, "tile": _l
 
 
 @_lib.device_guarded
+def attention_plan(csr: FlatCSR, T_m: int, is_causal: bool = True, entries_per_tile: float = 0.0):
+    """Per-block dispatch plan (`sea_attention_plan`): a flat uint8 buffer -- N*H*ceil(T_dst/16) bytes, 1 = the MFMA tile
+    kernel owns the 16-row block, 0 = the gather kernels, followed (4-byte aligned) by the int32 count of tile blocks
+    (`plan_blocks(plan, N, H, T_dst)` views the bytes as (N, H, blocks)).  Needs the kept-pixel bit masks of the selection (`csr.bits`); returns None
+    when there are none (a CSR that did not come from topk_to_csr / csr_from_selection) or the shape is outside the plan
+    kernel (T_m % 32, H <= 64)."""
+    if csr.bits is None or T_m % 32 != 0 or csr.H > 64 or csr.H * T_m > 32768:
+        return None
+    lib = _lib.load()
+    _lib.require_gpu(csr.bits)
+    nb = csr.N * csr.H * ((csr.T_dst + 15) // 16)
+    buf = torch.empty((((nb + 3) & ~3) + 4,), dtype=torch.uint8, device=csr.bits.device)   # bytes + the int32 tile-block count
+    _lib.check(lib.sea_attention_plan(_p(csr.bits), csr.N, csr.H, csr.T_dst, csr.T_src, int(T_m), int(is_causal),
+                                      float(entries_per_tile), _p(buf), _lib.stream_ptr()), "sea_attention_plan")
+    return buf
+
+
+@_lib.device_guarded
 def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = None,
                      avg: Optional[torch.Tensor] = None, mix: Optional[torch.Tensor] = None,
                      out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None,
-                     path: str = "auto", want_probs: bool = False, row_tiles: int = 0, key_window: int = 0):
+                     path: str = "auto", want_probs: bool = False, row_tiles: int = 0, key_window: int = 0,
+                     plan: Optional[torch.Tensor] = None):
     """Fused SDDMM + per-(row,head) softmax + row scale + SpMM (+ mix) over the flat CSR (`sea_sparse_attention_ex`).
 
     q (N,H,T_dst,D), k/v (N,H,T_src,D), any [n,h,t] strides, feature stride 1.
@@ -228,6 +247,8 @@ def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = 
     Default output: fp32 (N,H,T_dst,D) (flat_csr_sdbmm.py:347 returns fp32).
     path: "auto" | "gather" (row-indexed gather kernels) | "tile" (MFMA tile kernel: 16-bit data, D in {64,80,128});
     row_tiles / key_window tune the tile kernel (0 = defaults).
+    plan: with path="auto", the per-block dispatch of `attention_plan` (both kernels are launched, each wave runs the
+    16-row blocks its kernel owns); without it "auto" means the gather kernels.
     want_probs: also return the per-entry values rs * softmax (fp32, laid out like csr.col) -- what the reference
     hands out as `partial_attention_probs` (attention.py:1162-1171); returns (out, probs)."""
     lib = _lib.load()
@@ -246,6 +267,9 @@ def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = 
         assert avg is not None and avg.shape == (N, H, T_dst, D) and avg.dtype == q.dtype
         assert mix.dtype == torch.float32 and mix.shape == (N, H, T_dst) and mix.is_contiguous()
     probs = torch.zeros(csr.col.shape, dtype=torch.float32, device=q.device) if want_probs else None
+    if plan is not None:
+        nb_ = N * H * ((T_dst + 15) // 16)
+        assert plan.dtype == torch.uint8 and plan.numel() == ((nb_ + 3) & ~3) + 4 and plan.is_contiguous()
     flags = _PATHS[path] | ((int(row_tiles) & 0xf) << 8)
     if key_window:
         assert key_window & (key_window - 1) == 0, "key_window is a power of two"
@@ -256,8 +280,25 @@ def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = 
         _p(csr.crow), _p(csr.col), csr.col.stride(0), _p(csr.head_off),
         _p(row_scale), _p(avg), _lib.strides3(avg) if avg is not None else None, _p(mix),
         _p(out), _lib.dtype_code(out.dtype), _lib.strides3(out),
-        _p(probs), probs.stride(0) if probs is not None else 0, flags, _lib.stream_ptr()), "sea_sparse_attention")
+        _p(probs), probs.stride(0) if probs is not None else 0,
+        _p(plan) if (plan is not None and path == "auto" and not want_probs) else c_void_p(0), flags,
+        _lib.stream_ptr()), "sea_sparse_attention")
     return (out, probs) if want_probs else out
+
+
+def plan_blocks(plan: torch.Tensor, N: int, H: int, T_dst: int) -> torch.Tensor:
+    """(N, H, ceil(T_dst/16)) view of a dispatch plan's per-block bytes."""
+    tb = (T_dst + 15) // 16
+    return plan[:N * H * tb].view(N, H, tb)
+
+
+def make_plan(blocks: torch.Tensor) -> torch.Tensor:
+    """A dispatch plan buffer from explicit per-block choices (uint8 (N, H, blocks)); tests and experiments."""
+    nb = blocks.numel()
+    buf = torch.zeros((((nb + 3) & ~3) + 4,), dtype=torch.uint8, device=blocks.device)
+    buf[:nb] = blocks.reshape(-1)
+    buf[-4:].view(torch.int32)[0] = int(blocks.sum().item()) if blocks.device.type == "cpu" else blocks.sum().to(torch.int32)
+    return buf
 
 
 def sparse_attention_bytes(Z: int, N: int, H: int, T_dst: int, D: int, elem_bytes: int) -> int:

@@ -184,3 +184,49 @@ def test_probs_output_matches_golden_elmul(golden, ops):
         valid = np.arange(g["col"].shape[1])[None, :] < g["crow"][:, -1:]
         got = pv[:, :g["col"].shape[1]].cpu().numpy()
         np.testing.assert_allclose(got[valid], g["elmul"][valid], atol=1e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("dtype,d", [(torch.bfloat16, 64), (torch.float16, 80), (torch.bfloat16, 128)])
+def test_per_block_dispatch_any_plan_gives_the_same_answer(ops, dtype, d):
+    """path="auto" with a plan launches both kernels; each 16-row block of each head is computed by exactly one of them.
+    Whatever the plan says (all gather, all tile, random, the library's own estimate), the output is the oracle's."""
+    N, H, T_dst, T_src, T_M, k = 2, 6, 200, 333, 64, 16
+    probs, q, kk, v, rs, mx, avg, keep, crow, col = _case(N, H, T_dst, T_src, T_M, k, d, dtype, structured=True)
+    sparse = O.sparse_attention(q.float(), kk.float(), v.float(), crow, col, rs)
+    ref = sparse * mx.unsqueeze(-1) + (1.0 - mx.unsqueeze(-1)) * avg.float()
+    csr, _ = ops.topk_to_csr(probs.to(DEV), keep.to(torch.int32).to(DEV), k, target_width=T_src)
+    TB16 = (T_dst + 15) // 16
+    g = torch.Generator().manual_seed(3)
+    own = ops.attention_plan(csr, T_M)
+    assert own is not None and own.dtype == torch.uint8
+    ob = ops.plan_blocks(own, N, H, T_dst)
+    assert ob.shape == (N, H, TB16) and int(ob.max()) <= 1
+    assert int(own[-4:].view(torch.int32)[0]) == int(ob.sum())            # the count behind the bytes
+    half = torch.zeros((N, H, TB16), dtype=torch.uint8); half[:, :, : TB16 // 2 - 1] = 1   # < half: stays per block
+    plans = {"gather": ops.make_plan(torch.zeros((N, H, TB16), dtype=torch.uint8)),
+             "tile": ops.make_plan(torch.ones((N, H, TB16), dtype=torch.uint8)),
+             "random": ops.make_plan((torch.rand((N, H, TB16), generator=g) < 0.4).to(torch.uint8)),
+             "mostly tile": ops.make_plan((torch.rand((N, H, TB16), generator=g) < 0.8).to(torch.uint8)),
+             "first half": ops.make_plan(half), "own": own.cpu()}
+    for name, pl in plans.items():
+        out = torch.full((N, H, T_dst, d), float("nan"), device=DEV)            # every row must be written by someone
+        ops.sparse_attention(q.to(DEV), kk.to(DEV), v.to(DEV), csr, row_scale=rs.to(DEV), avg=avg.to(DEV), mix=mx.to(DEV),
+                             out=out, path="auto", plan=pl.to(DEV).contiguous())
+        assert torch.isfinite(out).all(), name
+        assert (out.cpu() - ref).abs().max().item() < 2e-3, name
+        assert ((out.cpu() - ref).norm() / ref.norm()).item() < 1e-3, name
+
+
+def test_plan_follows_the_structure_of_the_map(ops):
+    """Structured maps (rows share their keys) send most late blocks to the tile kernel, independent random rows almost none;
+    the first rows (t < k: every key kept, a dense triangle) go to the tile kernel in both."""
+    from sea_attention_amd import synthetic
+    N, H, T, T_M, k = 1, 8, 4096, 256, 64
+    keep = ops.keep_table_causal(H, T, T_M, k, device=DEV)
+    shares = {}
+    for name, gen in (("random", synthetic.random_probs), ("structured", synthetic.structured_probs)):
+        csr, _ = ops.topk_to_csr(gen(N, H, T, T_M, DEV, torch.bfloat16, seed=1), keep, k, target_width=T)
+        pl = ops.plan_blocks(ops.attention_plan(csr, T_M), N, H, T)
+        assert int(pl[:, :, :2].min()) == 1                              # rows 0..31: dense causal triangle
+        shares[name] = pl[:, :, 3 * T // 64:].float().mean().item()      # last quarter: K_t is down to the strong pixels
+    assert shares["structured"] > 0.5 > shares["random"], shares
