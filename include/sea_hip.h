@@ -189,6 +189,17 @@ int sea_sparse_attention_ex(const void* q, const void* k, const void* v, int dty
                             const uint8_t* block_path, /* buffer filled by sea_attention_plan, or NULL */
                             int flags, sea_stream_t stream);
 
+/* Backward of the fused operator WITHOUT its epilogue (o = sum_e softmax_e(q.k_e) v_e; the caller applies row scale and mix
+ * in its autograd framework): dQ, dK, dV from dO.  Reference shape: masked_mm.py:169-267 + the dense branch's autograd
+ * (attention.py:1061-1133).  probs = the forward's probs_out with row_scale = NULL; out / dout / dq fp32 (N,H,T_dst,D)
+ * contiguous; dk / dv fp32 (N,H,T_src,D) contiguous, ZEROED by the caller (rows are accumulated with fp32 atomics). */
+int sea_sparse_attention_bwd(const void* q, const void* k, const void* v, int dtype,
+                             int64_t N, int64_t H, int64_t T_dst, int64_t T_src, int64_t D,
+                             const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                             const int32_t* crow, const int32_t* col, int64_t col_stride_n, const int32_t* head_off,
+                             const float* probs, int64_t probs_stride_n, const float* out, const float* dout,
+                             float* dq, float* dk, float* dv, sea_stream_t stream);
+
 /* Per-block dispatch plan for SEA_ATTN_AUTO: one byte per (n, h, 16-row block), 1 = the tile kernel owns the block, 0 = the
  * gather kernels do.  With a plan, sea_sparse_attention_ex launches BOTH kernels over all rows and every wave runs only the
  * blocks its kernel owns (no host round trip, graph-capturable).  The plan is estimated from the kept-pixel bit masks of

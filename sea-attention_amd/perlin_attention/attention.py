@@ -809,7 +809,11 @@ class PerlinAttention(nn.Module):
                     average_context_layer, self._avg_ahead = self._avg_ahead, None
                 else:
                     avg_v = v if not_padded else v * (dst_attention_mask > -1)
-                    average_context_layer = ops.cumavg(avg_v)          # HIP scan, fp32 accumulation
+                    if torch.is_grad_enabled() and avg_v.requires_grad:   # training: the average carries gradient to v
+                        average_context_layer = (avg_v.float().cumsum(-2) / torch.arange(
+                            1, T + 1, device=v.device, dtype=torch.float32).view(1, 1, -1, 1)).to(v.dtype)
+                    else:
+                        average_context_layer = ops.cumavg(avg_v)      # HIP scan, fp32 accumulation
             out_dtype = self.context_layer_dtype or torch.float32
             qs = q_for_score if q_for_score.stride(-1) == 1 else q_for_score.contiguous()
             ks = k_for_score if k_for_score.stride(-1) == 1 else k_for_score.contiguous()
@@ -835,6 +839,13 @@ class PerlinAttention(nn.Module):
                     bench.register_temp_buffer('partial_context_layer_2', p2)
                     with timer("context_permute"):
                         ctx = p2.permute(0, 2, 1, 3).contiguous().view(N, T, H * HID).to(out_dtype)
+                elif torch.is_grad_enabled() and any(t_.requires_grad for t_ in (qs, ks, vs, average_scale, average_context_layer)
+                                                    + ((row_scale,) if row_scale is not None else ())):
+                    # training through the sparse branch: HIP forward + backward for the sparse product
+                    # (sea_sparse_attention_bwd), row scale and mix as torch ops so that autograd owns their gradients
+                    p2 = ops.sparse_attention_autograd(qs, ks, vs, csr, row_scale=row_scale, avg=average_context_layer,
+                                                       mix=average_scale)
+                    ctx = p2.permute(0, 2, 1, 3).reshape(N, T, H * HID).to(out_dtype)
                 else:
                     # write straight into the (N, T, H*D) layout of :1279-1282
                     ctx = torch.empty((N, T, H * HID), dtype=out_dtype, device=q.device)

@@ -214,6 +214,56 @@ def topk_mask(probs: torch.Tensor, keep: torch.Tensor, k: int, target_width=None
 _PATHS = {"auto": _lib.SEA_ATTN_AUTO, "gather": _lib.SEA_ATTN_GATHER, "tile": _lib.SEA_ATTN_TILE}
 
 
+class _SparseAttentionFn(torch.autograd.Function):
+    """o = sum_e softmax_e(q . k_e) v_e over the flat CSR, with a backward on the HIP kernels.
+
+    Forward: the gather kernels with the per-entry probabilities kept (they ARE the saved activations: one fp32 per entry
+    instead of the dense branch's (N,H,T,T) probability tensor, attention.py:1120-1128).  Backward:
+    `sea_sparse_attention_bwd` (csrc/sea_attn_bwd.hip) -- dQ by rows, dK / dV by fp32 atomics.  Row scale and the average
+    mix stay outside (plain torch ops on the result), so autograd owns their gradients."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, csr):
+        with torch.no_grad():
+            out, probs = sparse_attention(q.detach(), k.detach(), v.detach(), csr, want_probs=True, path="gather")
+        ctx.save_for_backward(q, k, v, probs, out)
+        ctx.csr = csr
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        q, k, v, probs, out = ctx.saved_tensors
+        csr = ctx.csr
+        lib = _lib.load()
+        N, H, T_dst, D = q.shape
+        T_src = k.shape[2]
+        qd, kd, vd = (t.detach() if t.stride(-1) == 1 else t.detach().contiguous() for t in (q, k, v))
+        dout = dout.to(torch.float32).contiguous()
+        dq = torch.empty((N, H, T_dst, D), dtype=torch.float32, device=q.device)
+        dk = torch.zeros((N, H, T_src, D), dtype=torch.float32, device=q.device)
+        dv = torch.zeros((N, H, T_src, D), dtype=torch.float32, device=q.device)
+        with torch.cuda.device(q.device):
+            _lib.check(lib.sea_sparse_attention_bwd(
+                _p(qd), _p(kd), _p(vd), _lib.dtype_code(q.dtype), N, H, T_dst, T_src, D,
+                _lib.strides3(qd), _lib.strides3(kd), _lib.strides3(vd),
+                _p(csr.crow), _p(csr.col), csr.col.stride(0), _p(csr.head_off),
+                _p(probs), probs.stride(0), _p(out), _p(dout), _p(dq), _p(dk), _p(dv), _lib.stream_ptr()),
+                "sea_sparse_attention_bwd")
+        return dq.to(q.dtype), dk.to(k.dtype), dv.to(v.dtype), None
+
+
+def sparse_attention_autograd(q, k, v, csr: FlatCSR, row_scale=None, avg=None, mix=None) -> torch.Tensor:
+    """Differentiable form of `sparse_attention` (fp32 (N,H,T_dst,D) result): the HIP forward + backward for the sparse
+    product, torch ops for `* row_scale` and the mix with `avg` (their gradients come from autograd)."""
+    o = _SparseAttentionFn.apply(q, k, v, csr)
+    if row_scale is not None:
+        o = o * row_scale.unsqueeze(-1)
+    if mix is not None:
+        a = mix.unsqueeze(-1)
+        o = o * a + (1.0 - a) * avg.to(o.dtype)
+    return o
+
+
 @_lib.device_guarded
 def attention_plan(csr: FlatCSR, T_m: int, is_causal: bool = True, entries_per_tile: float = 0.0):
     """Per-block dispatch plan (`sea_attention_plan`): a flat uint8 buffer -- N*H*ceil(T_dst/16) bytes, 1 = the MFMA tile
@@ -253,6 +303,9 @@ def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = 
     hands out as `partial_attention_probs` (attention.py:1162-1171); returns (out, probs)."""
     lib = _lib.load()
     _lib.require_gpu(q, k, v, csr.crow)
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (q, k, v, row_scale, avg, mix)):
+        assert out is None and not want_probs, "the differentiable form returns a new fp32 tensor"
+        return sparse_attention_autograd(q, k, v, csr, row_scale, avg, mix)
     N, H, T_dst, D = q.shape
     T_src = k.shape[2]
     assert k.shape == (N, H, T_src, D) and v.shape == (N, H, T_src, D)
