@@ -147,3 +147,132 @@ def all_gather_rows(local: torch.Tensor, bounds: List[Tuple[int, int]], group=No
     bufs = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(bufs, padded, group=group)
     return torch.cat([b[:, :s] for b, s in zip(bufs, sizes)], dim=1)
+
+
+# ---- N < G, whole layer: split the query rows of EVERY step, estimator included ------------------------------
+# A single long sequence (BASELINE config 4: one 8192-token sequence per GPU group) leaves batch sharding nothing to cut.
+# `sparse_rows` above splits steps H..L and replicates the estimator (A..G = 59 % of the step at the headline shape);
+# here the estimator is split too.  Rank r owns the rows [lo_r, hi_r) (equal cuts of whole 64-row Performer chunks) and
+# needs from the ranks before it exactly what kv-cache decoding carries from the tokens before it:
+#   * the causal Performer's running sums up to row lo_r.  They are linear in the rows, so every rank first runs the
+#     Performer over its own rows FROM ZERO (phase A: only the state image matters), the images are all-gathered
+#     (N*H x ~30 KB each) and rank r starts from inc_0 + ... + inc_{r-1}, added in rank order -- the same sum, in the same
+#     order, the one-GPU sequence-parallel Performer forms (sea_performer_causal_segmented);
+#   * the last 8 rows of the predictor CNN's input (two dilated causal 3-tap convolutions reach back 2*2*(3-1) rows):
+#     one point-to-point hand-off r -> r+1 of the channel-blocked rows the one-launch MLP has just produced (64 KB);
+#   * K and V of rows < hi_r: replicated (2*H*T*d elements).
+# Phase B is then `PerlinAttention._forward_cached` on the rank's rows -- the decode path, T_dst < T_src -- with a state built
+# from those two pieces, and one (ragged) all-gather of the context rows.  Nothing of the step is replicated except
+# phase A's state-only Performer pass over the rank's own rows (about a third of a Performer launch).
+def estimator_row_cuts(T: int, world: int, chunk: int = 64):
+    """Equal cuts of whole Performer chunks: the cuts `sea_performer_plan` would make for `world` segments."""
+    chunks = (T + chunk - 1) // chunk
+    seg = ((chunks + world - 1) // world) * chunk
+    return [(min(r * seg, T), min((r + 1) * seg, T)) for r in range(world)]
+
+
+def _prefix_in_rank_order(incs, rank):
+    """inc_0 + inc_1 + ... + inc_{rank-1}, added left to right (None for rank 0)."""
+    acc = None
+    for r2 in range(rank):
+        if incs[r2] is not None:
+            acc = incs[r2] if acc is None else acc + incs[r2]
+    return acc
+
+
+def run_row_split_local(phase_a, phase_b, cuts, lookback: int):
+    """The row-split schedule with all ranks run one after another in THIS process.
+    phase_a(lo, hi) -> additive state increment of the rows; phase_b(lo, hi, state_in, hook) -> (N, hi-lo, C) rows, calling
+    hook(x) once with its fresh window-carrying rows x (rows on dim 1) to obtain the previous rank's last `lookback` rows."""
+    incs = [phase_a(lo, hi) if hi > lo else None for lo, hi in cuts]
+    tails, rows = {}, []
+    for r, (lo, hi) in enumerate(cuts):
+        if hi <= lo:
+            continue
+
+        def hook(x, r=r):
+            tails[r] = x[:, -lookback:]
+            return tails.get(r - 1)
+        rows.append(phase_b(lo, hi, _prefix_in_rank_order(incs, r), hook))
+    return torch.cat(rows, dim=1)
+
+
+def run_row_split(phase_a, phase_b, cuts, lookback: int, group=None):
+    """The same schedule across the ranks of `group`: all-gather of the state increments, prefix sum in rank order, one
+    point-to-point hand-off r -> r+1 of the window rows, (ragged) all-gather of the result rows.  Every rank must own at
+    least `lookback` rows (or none)."""
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if any(hi_ - lo_ < lookback for lo_, hi_ in cuts):      # the same cuts on every rank: all of them raise together
+        raise ValueError(f"row split over {world} ranks needs at least {lookback} rows per rank, cuts are {cuts}")
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    lo, hi = cuts[rank]
+    inc = phase_a(lo, hi)
+    incs = [torch.empty_like(inc) for _ in range(world)]
+    dist.all_gather(incs, inc, group=group)
+
+    def hook(x):
+        tail = x[:, -lookback:].contiguous()
+        req = None
+        if rank + 1 < world:
+            req = dist.isend(tail, peer(rank + 1), group=group)
+        halo = None
+        if rank > 0:
+            halo = torch.empty_like(tail)
+            dist.recv(halo, peer(rank - 1), group=group)
+        if req is not None:
+            req.wait()
+        return halo
+    local = phase_b(lo, hi, _prefix_in_rank_order(incs, rank), hook)
+    return all_gather_rows(local.contiguous(), cuts, group=group)
+
+
+def _phase_a_increment(attention, q, k, v, lo, hi):
+    """State image of the Performer over rows [lo, hi) started from zero (phase A)."""
+    from .perlin_attention import ops
+    pos = attention.v_eye_learned_causal[0, 0, lo:, :]
+    _pv, _avg, image = ops.performer_step(q[:, :, lo:hi], k[:, :, lo:hi], v[:, :, lo:hi], pos,
+                                          attention.performer.projection_matrix, state_in=None, t_base=0,
+                                          n_segments=attention.performer_segments or 1)
+    return image
+
+
+def _phase_b_rows(layer, q, k, v, mask_rows, lo, hi, image_in, window):
+    """The rank's rows through the whole layer (decode path) from the handed-over state; `window` is a hook called with the
+    rank's fresh CNN input rows (channel-blocked, rows on dim 1) that returns the previous rank's last rows, or None."""
+    from .perlin_attention.attention_state import (PerlinAttentionState, PerformerState, CnnWindowState, CumAvgState,
+                                                   cnn_lookback)
+    att = layer.attention
+    st = PerlinAttentionState(att)
+    if lo > 0:
+        ps = PerformerState(); ps.image, ps.seq_index = image_in, lo
+        cav = CumAvgState(); cav.prev_len, cav.in_image = lo, True
+        st.states[PerlinAttentionState.PERFORMER] = ps
+        st.states[PerlinAttentionState.CUMAVG] = cav
+    cs = CnnWindowState(cnn_lookback(att.attention_predictor_cnn))
+    cs.rows_c8 = window
+    st.states[PerlinAttentionState.CNN] = cs
+    out = layer(None, None, None, query_layer=q[:, :, lo:hi], key_layer=k[:, :, :hi], value_layer=v[:, :, :hi],
+                attention_mask=mask_rows, last_state=st)
+    return out.context_layer
+
+
+def _layer_phases(layer, q, k, v, causal_mask_fn):
+    from .perlin_attention.attention_state import cnn_lookback
+    pa = lambda lo, hi: _phase_a_increment(layer.attention, q, k, v, lo, hi)
+    pb = lambda lo, hi, st, hook: _phase_b_rows(layer, q, k, v, causal_mask_fn(lo, hi), lo, hi, st, hook)
+    return pa, pb, cnn_lookback(layer.attention.attention_predictor_cnn)
+
+
+def row_split_layer_local(layer, q, k, v, causal_mask_fn, world: int):
+    """The row-split SEA layer of `world` ranks run one after another in this process (tests; a single GPU rehearsing the
+    multi-GPU schedule).  causal_mask_fn(lo, hi) -> (N,1,hi-lo,hi) additive mask rows.  Returns the (N, T, H*d) context --
+    the unsharded layer's."""
+    pa, pb, lb = _layer_phases(layer, q, k, v, causal_mask_fn)
+    return run_row_split_local(pa, pb, estimator_row_cuts(q.shape[-2], world), lb)
+
+
+def row_split_layer(layer, q, k, v, causal_mask_fn, group=None):
+    """The row-split SEA layer across the ranks of `group` (one process per GPU, RCCL over xGMI): every rank returns the full
+    (N, T, H*d) context.  16-bit inference with d = 64 (the HIP estimator carries the state)."""
+    pa, pb, lb = _layer_phases(layer, q, k, v, causal_mask_fn)
+    return run_row_split(pa, pb, estimator_row_cuts(q.shape[-2], dist.get_world_size(group)), lb, group=group)

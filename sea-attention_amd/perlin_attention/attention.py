@@ -612,6 +612,8 @@ class PerlinAttention(nn.Module):
         # 16-bit inference, d = 64: the whole estimator stays on the stateless path's kernels.  The Performer continues
         # its own fp32 sums from a state image (`sea_performer_causal_step`), which also carries the column sums of v
         # for the cumulative average; a call that brings many rows (a prefill) is just a long step.
+        if callable(cs.rows_c8):
+            assert self._hip_estimator_ok(q), "a window hand-off hook goes with the HIP estimator (16-bit inference)"
         hip_all = (self._hip_estimator_ok(q) and ps.S is None and cs.rows is None and cav.cumsum is None
                    and v_for_atten is v and q_for_atten.dtype == k_for_atten.dtype == v.dtype
                    and ops.performer_avg_supported(q_for_atten, self.performer_nb_features)
@@ -651,7 +653,7 @@ class PerlinAttention(nn.Module):
                 v_new = v[..., sl, :]
                 avg_rows = None
                 if hip_all:
-                    nseg = ops.performer_plan(N, H, T_DST, HID, self.performer_nb_features, q.dtype)[0]
+                    nseg = self.performer_segments or ops.performer_plan(N, H, T_DST, HID, self.performer_nb_features, q.dtype)[0]
                     performer_value, avg_rows, image = ops.performer_step(
                         q_for_atten, k_for_atten[..., sl, :], v_new, self.v_eye_learned_causal[0, 0, seen:, :],
                         self.performer.projection_matrix, state_in=ps.image, t_base=seen, n_segments=nseg)
@@ -684,7 +686,10 @@ class PerlinAttention(nn.Module):
                         self.attention_predictor_dec_row[0], self.attention_predictor_cnn[0].module,
                         self.attention_predictor_dec_scaler[0], want_tpred=False)
                     gates = (row_scale_, avg_scale_)
-                    xs = x if cs.rows_c8 is None else torch.cat([cs.rows_c8, x], dim=1)      # (N, rows, C/8, W, 8)
+                    # the window may be a hand-off hook instead of a tensor: row-split multi-GPU runs (distributed.py) give
+                    # this rank's freshly computed rows to the next rank and receive the previous rank's last rows here
+                    win = cs.rows_c8(x) if callable(cs.rows_c8) else cs.rows_c8
+                    xs = x if win is None else torch.cat([win, x], dim=1)                     # (N, rows, C/8, W, 8)
                     new_cs = CnnWindowState(cs.lookback)
                     new_cs.rows_c8 = xs[:, -cs.lookback:]
                     state.states[PerlinAttentionState.CNN] = new_cs
@@ -746,9 +751,14 @@ class PerlinAttention(nn.Module):
                 ks, vs = ks.to(qs.dtype), vs.to(qs.dtype)
                 out_dtype = self.context_layer_dtype or torch.float32
                 ctx = torch.empty((N, T_DST, H * HID), dtype=out_dtype, device=q.device)
+                want_p = self.return_attention_probs
+                plan = None
+                if (self.sparse_kernel == "auto" and not want_p and qs.dtype != torch.float32 and HID in (64, 80, 128)
+                        and T_DST >= 16):                    # same per-block dispatch as the stateless path
+                    plan = ops.attention_plan(csr, T_M, is_causal=True)
                 res = ops.sparse_attention(qs, ks, vs, csr, row_scale=row_scale, avg=average_context_layer.to(qs.dtype).contiguous(),
                                            mix=average_scale, out=ctx.view(N, T_DST, H, HID).permute(0, 2, 1, 3),
-                                           want_probs=self.return_attention_probs)
+                                           want_probs=want_p, path="gather" if want_p else self.sparse_kernel, plan=plan)
                 probs_csr = csr.with_values(res[1]) if self.return_attention_probs else None
         bench.register_temp_buffer('estimated_attention_probs', estimated_attention_probs)
         mask_out = csr.to_sparse_csr() if self.materialize_csr else csr

@@ -134,3 +134,61 @@ def _worker_rows(rank, world, port, ret):
 def test_all_gather_of_ragged_row_blocks_world2():
     port = _free_port()
     mp.spawn(_worker_rows, args=(2, port, None), nprocs=2, join=True)
+
+
+# ---- row-split whole layer: the protocol (increments -> prefix in rank order, window hand-off, ragged row gather) -------
+def _toy_phases(x):
+    """A stand-in with the layer's dependency structure: a causal prefix state (sum of all earlier rows) and an 8-row causal
+    window (mean of the last 8 'CNN input' rows), rows (N, T, C)."""
+    LB = 8
+
+    def phase_a(lo, hi):
+        return x[:, lo:hi].sum(1)                                       # additive state increment (N, C)
+
+    def phase_b(lo, hi, state_in, hook):
+        xr = x[:, lo:hi]
+        prefix = torch.cumsum(xr, 1) + (state_in.unsqueeze(1) if state_in is not None else 0.0)
+        feat = torch.tanh(prefix) * 0.5 + xr                            # "MLP output": the window-carrying rows
+        halo = hook(feat)
+        ext = feat if halo is None else torch.cat([halo, feat], 1)
+        pad = torch.cat([torch.zeros_like(ext[:, :LB]), ext], 1)        # rows before the sequence read as zeros
+        win = torch.stack([pad[:, i:i + ext.shape[1]] for i in range(LB + 1)], 0).sum(0)
+        return (win[:, -xr.shape[1]:] * 0.1 + prefix).contiguous()
+    return phase_a, phase_b, LB
+
+
+def _worker_row_split(rank, world, port, T, ret):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from sea_attention_amd import distributed as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(3)
+    x = torch.randn(2, T, 5, dtype=torch.float64)
+    pa, pb, lb = _toy_phases(x)
+    full = pb(0, T, None, lambda f: None)                               # unsharded
+    cuts = D.estimator_row_cuts(T, world, chunk=16)
+    got = D.run_row_split(pa, pb, cuts, lb)
+    local = D.run_row_split_local(pa, pb, cuts, lb)
+    ok = torch.allclose(got, full, atol=1e-12) and torch.allclose(local, full, atol=1e-12)
+    dist.barrier(); dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(3)
+
+
+@pytest.mark.parametrize("world,T", [(2, 96), (4, 200), (3, 112)])
+def test_row_split_protocol_reproduces_the_unsharded_rows(world, T):
+    """State increments all-gathered and prefix-summed in rank order, the window handed r -> r+1, ragged rows gathered: the
+    sharded result IS the unsharded one (toy estimator with the layer's dependency structure; the real layer runs the same
+    schedule on the GPU, tests/test_gpu_row_split.py)."""
+    port = _free_port()
+    mp.spawn(_worker_row_split, args=(world, port, T, None), nprocs=world, join=True)
+
+
+def test_estimator_row_cuts_are_whole_chunks():
+    from sea_attention_amd.distributed import estimator_row_cuts
+    for T, w in ((4096, 8), (8192, 8), (4096, 3), (1000, 4), (64, 4)):
+        cuts = estimator_row_cuts(T, w)
+        assert cuts[0][0] == 0 and max(hi for _, hi in cuts) == T
+        assert all(a[1] == b[0] or b[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+        assert all(lo % 64 == 0 for lo, hi in cuts if hi > lo)

@@ -34,6 +34,9 @@ def _layer(H, d, T_M, k, T, dtype, use_cache):
         if hasattr(m, 'benchmarking'):
             m.benchmarking = True
     layer.attention.force_torch_estimator = True
+    # steps J-L on ONE kernel: "auto" dispatches per 16-row block from a per-launch plan, and a decode call that brings few
+    # rows may plan them differently from the stateless forward over all rows (equal to rounding, not to the bit)
+    layer.attention.sparse_kernel = "gather"
     return layer
 
 
