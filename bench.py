@@ -156,7 +156,7 @@ def main():
         with torch.no_grad():
             out = layer(None, None, None, query_layer=q, key_layer=kk, value_layer=v, attention_mask=mask)
             ctx = out.context_layer
-            if world > 1:
+            if world > 1:                                  # eager mode only: the graph path writes the slot directly
                 slot = gather.next_slot()
                 gather.local[slot].copy_(ctx)
                 ctx = gather.launch(slot)
@@ -310,8 +310,9 @@ def main():
                     traffic_note = "profiles/traffic_latest.json was taken on other kernel sources: not reported"
             except Exception:
                 pass
-        kname = "sparse_attn_tile_kernel" if args.sparse_kernel == "tile" else \
-                ("sparse_attn_rows80_kernel" if d == 80 and esz == 2 else "sparse_attn_rows_kernel")
+        gname = "sparse_attn_rows80_kernel" if d == 80 and esz == 2 else "sparse_attn_rows_kernel"
+        kname = {"tile": "sparse_attn_tile_kernel", "gather": gname,
+                 "auto": gname + " + sparse_attn_tile_kernel (per-block dispatch: both launches inside the timed events)"}[args.sparse_kernel]
         roof = {"bound": "l2_gather", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
                 "compulsory_bytes": compulsory, "frac_compulsory_hbm": round(compulsory / t_attn / 1e9 / HBM_PEAK_GBS, 4),

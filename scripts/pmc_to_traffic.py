@@ -36,8 +36,8 @@ for name, c in acc.items():
     out["kernels"][name] = {"launches": len(c["FETCH_SIZE"]), "FETCH_SIZE_KB": fs, "WRITE_SIZE_KB": ws,
                             "hbm_bytes_per_launch_corrected": int((2 * fs + ws) * 1024),
                             "l2_requests_per_launch": int(req), "l2_hit_rate": round(hit / (hit + miss), 4) if hit + miss else None}
-    if "sparse_attn" in name:
-        out["sea_sparse_attention_hbm_bytes_per_launch"] = int((2 * fs + ws) * 1024)
+    if "sparse_attn" in name:          # per-block dispatch launches the gather AND the tile kernel: the step's traffic is their sum
+        out["sea_sparse_attention_hbm_bytes_per_launch"] = out.get("sea_sparse_attention_hbm_bytes_per_launch", 0) + int((2 * fs + ws) * 1024)
 for dst in (f"{tag}_pmc_traffic.json", "traffic_latest.json"):
     json.dump(out, open(os.path.join(ROOT, "profiles", dst), "w"), indent=1)
 print(json.dumps({k: (v["hbm_bytes_per_launch_corrected"], v["l2_requests_per_launch"], v["l2_hit_rate"]) for k, v in out["kernels"].items()}, indent=1))
