@@ -23,6 +23,7 @@
 // Contract differences from the gather kernels: a (row, column) pair must not occur twice in the CSR (a bitmap cannot
 // count) -- true of every CSR the interpolation emits; 16-bit data, D in {64, 80, 128}.
 #include "sea_attn.hpp"
+#include <type_traits>
 
 namespace sea {
 
@@ -112,6 +113,8 @@ __global__ __launch_bounds__(NW * 64) void sparse_attn_tile_kernel(AttnParams p,
   using G = TileGeom<D>;
   using X = TileT<T>;
   constexpr int ROWS = 16 * RT, KK = G::KK, MT = G::MT, CH = G::CH, VST = G::VST, VLD = G::VLD;
+  constexpr bool SPLIT = X::SPLIT;   // (one bf16 term for 16-bit outputs was tried: no faster -- the kernel is not VALU bound -- and one ulp worse)
+  constexpr float LOG2E = 1.4426950408889634f;
   extern __shared__ __attribute__((aligned(16))) char at_smem[];
   int pair, tb;
   if (!map_block(p.N * p.H, p.TB, &pair, &tb)) return;
@@ -311,7 +314,7 @@ __global__ __launch_bounds__(NW * 64) void sparse_attn_tile_kernel(AttnParams p,
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           const float mn = fmaxf(m[rt], pmax[rt]);
-          const float alpha = (mn == -INFINITY) ? 1.f : __expf(m[rt] - mn);
+          const float alpha = (mn == -INFINITY) ? 1.f : __builtin_amdgcn_exp2f((m[rt] - mn) * LOG2E);
           l[rt] *= alpha;
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt) {
@@ -322,17 +325,17 @@ __global__ __launch_bounds__(NW * 64) void sparse_attn_tile_kernel(AttnParams p,
       }
 #pragma unroll
       for (int rt = 0; rt < RT; ++rt) {
-        const float ms = (m[rt] == -INFINITY) ? 0.f : m[rt];
+        const float ms2 = (m[rt] == -INFINITY) ? 0.f : -m[rt] * LOG2E;    // exp(s - m) = exp2(s * log2e - m * log2e): fma + exp
         float pv[8];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          pv[j] = __expf(s[rt][0][j] - ms);
-          pv[4 + j] = __expf(s[rt][1][j] - ms);
+          pv[j] = __builtin_amdgcn_exp2f(fmaf(s[rt][0][j], LOG2E, ms2));
+          pv[4 + j] = __builtin_amdgcn_exp2f(fmaf(s[rt][1][j], LOG2E, ms2));
         }
         l[rt] += ((pv[0] + pv[1]) + (pv[2] + pv[3])) + ((pv[4] + pv[5]) + (pv[6] + pv[7]));
         // P^T fragment (B operand): k = 8 g + j <-> j < 4: tile a key 4 g + j, j >= 4: tile b key 4 g + j - 4
         ph[rt] = make_uint4(X::pack(pv[0], pv[1]), X::pack(pv[2], pv[3]), X::pack(pv[4], pv[5]), X::pack(pv[6], pv[7]));
-        if (X::SPLIT) {
+        if (SPLIT) {
           pl[rt] = make_uint4(X::pack(pv[0] - X::lo_val(ph[rt].x), pv[1] - X::hi_val(ph[rt].x)),
                               X::pack(pv[2] - X::lo_val(ph[rt].y), pv[3] - X::hi_val(ph[rt].y)),
                               X::pack(pv[4] - X::lo_val(ph[rt].z), pv[5] - X::hi_val(ph[rt].z)),
@@ -350,7 +353,7 @@ __global__ __launch_bounds__(NW * 64) void sparse_attn_tile_kernel(AttnParams p,
 #pragma unroll
         for (int rt = 0; rt < RT; ++rt) {
           acc[rt][mt] = X::mfma(vf, ph[rt], acc[rt][mt]);
-          if (X::SPLIT) acc[rt][mt] = X::mfma(vf, pl[rt], acc[rt][mt]);
+          if (SPLIT) acc[rt][mt] = X::mfma(vf, pl[rt], acc[rt][mt]);
         }
       }
     }
