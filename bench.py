@@ -353,10 +353,53 @@ def main():
                        "topk_interp_csr_ms": round(tk, 4), "sparse_attention_ms": round(ta, 4),
                        "sparse_attention_GBs": round(kb / (ta / 1e3) / 1e9, 1), "nnz": Zk,
                        "note": "HIP kernels only (steps H..K), softmax(randn) probability map, per GPU"}
+        # the same leg on a map whose neighbouring rows share their keys (what a trained predictor emits: diagonal band,
+        # vertical stripes, sink -- sea_attention_amd/synthetic.py) with the per-block dispatch plan, as the layer runs it
+        if dtype != torch.float32 and d in (64, 80, 128):
+            from sea_attention_amd import synthetic
+            sp = synthetic.structured_probs(NB, H, T, T_M, dev, dtype, seed=1)
+            cs, _ = ops.topk_to_csr(sp, keep, k, target_width=T, z_cap=z_cap)
+            del sp
+            times = {}
+            for name_, kw_ in (("gather", dict(path="gather")), ("tile", dict(path="tile")), ("auto", dict(path="auto"))):
+                for it_ in range(2 + args.kernel_iters):
+                    if it_ == 2:
+                        torch.cuda.synchronize(); e0.record()
+                    pl_ = ops.attention_plan(cs, T_M) if name_ == "auto" else None
+                    ops.sparse_attention(q, kk, v, cs, row_scale=rs, avg=avg, mix=mx, out=ctx2.view(NB, T, H, d).permute(0, 2, 1, 3),
+                                         plan=pl_, **kw_)
+                e1.record(); torch.cuda.synchronize()
+                times[name_] = round(e0.elapsed_time(e1) / args.kernel_iters, 4)
+            Zs = int(cs.crow[:, -1].sum().item())
+            kernel_path["structured_map"] = {"sparse_attention_ms": times, "nnz": Zs,
+                                             "algorithmic_GBs_auto": round(ops.sparse_attention_bytes(Zs, NB, H, T, d, esz) / (times["auto"] / 1e3) / 1e9, 1),
+                                             "note": "auto = plan kernel + both gated launches (what the layer runs)"}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(w, args.cpu_seqs)
+        # like-for-like twin of `value` (the WHOLE layer, steps A..L): the reference's own CPU-runnable form of this layer is
+        # its dense torch mode (BASELINE config 0 runs it on CPU); same weights, one sequence, fp32, all host cores
+        try:
+            import copy
+            cores_ = _usable_cores()
+            torch.set_num_threads(cores_)
+            lc = copy.deepcopy(layer).to("cpu").float().eval()
+            for m in lc.modules():
+                if hasattr(m, 'benchmarking'):
+                    m.benchmarking = False
+            q1, k1, v1 = (t_[:1].float().cpu() for t_ in (q, kk, v))
+            m1 = mask[:1].float().cpu()
+            with torch.no_grad():
+                tc0 = time.perf_counter()
+                lc(None, None, None, query_layer=q1, key_layer=k1, value_layer=v1, attention_mask=m1)
+                dtc = time.perf_counter() - tc0
+            cpu["full_layer"] = {"value": round(T / dtc, 1), "unit": "tokens/s", "cores": cores_, "kind": "port",
+                                 "sample": f"1 sequence x {T} tokens through the whole layer (steps A..L) in the dense torch mode "
+                                           f"(the reference's CPU-runnable path), fp32, {dtc:.1f} s"}
+            del lc
+        except Exception as e_:                                   # the twin is informational: never fail the bench line on it
+            cpu["full_layer"] = {"error": f"{type(e_).__name__}: {e_}"[:200]}
 
     if rank == 0:
         line = {
