@@ -263,7 +263,9 @@ def main():
             keep_t = ops.keep_table_causal(H, T, T_M, k, device=dev)
             zc = ops.z_capacity(keep_t.cpu(), H, T, T, T_M, k, True)
             bits_ok, worst = True, 0.0
-            layer.attention.performer_segments = 1
+            # the lone item takes the Performer path the BATCH took (one pass for a full batch; for a one-sequence workload
+            # the library's sequence-parallel plan of that very shape)
+            layer.attention.performer_segments = ops.performer_plan(NB, H, T, d, layer.attention.performer_nb_features, dtype)[0]
             for n_ in sorted({0, NB - 1}):
                 csr_n, _ = ops.topk_to_csr(probs_b[n_:n_ + 1].contiguous(), keep_t, k, target_width=T, z_cap=zc)
                 csr_b = out.partial_attention_mask

@@ -58,8 +58,13 @@ struct MlpParams {
 // MLP_WAVES waves per (persistent) workgroup: 16 where the accumulators leave room under 128 VGPRs, else 8.
 // STAGE: the (16 heads x 2 splits x Wd) result tile of an item is transposed through a wave-private LDS tile and
 // leaves as 16-byte vectors (whole C8 blocks); without it every lane stores its 4-byte (split0, split1) pairs.
-template <typename T, int NT1, int NT2, int MLP_WAVES, bool STAGE>
-__global__ __launch_bounds__(MLP_WAVES * 64) void predictor_mlp_kernel(MlpParams p) {
+// W1S: the encoder weights do not fit in LDS beside the decoder's (d = 128: 12 k-steps x 16 tiles = 192 KB): they are
+// STREAMED -- the workgroup's waves walk the k-steps of their items in lockstep, one k-step's 16 fragments (16 KB) at a
+// time through a two-slot LDS ring, each thread carrying two 16-byte chunks of the next k-step in registers; one barrier
+// per k-step (a slot is rewritten two steps later, after the barrier every reader has passed).  The 192 KB stay in L2.
+template <typename T, int NT1, int NT2, int MLP_WAVES, bool STAGE, bool W1S = false>
+__global__ __launch_bounds__(MLP_WAVES * 64) __attribute__((amdgpu_waves_per_eu(MLP_WAVES / 4, MLP_WAVES / 4)))
+void predictor_mlp_kernel(MlpParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int D1 = NT1 * 16, D2 = NT2 * 16, Wd = D2 / 2, KS2 = NT1 / 2, HT = NT2 / 2;
   static_assert(NT1 % 2 == 0 && NT2 % 2 == 0, "tile counts must be even");
@@ -67,8 +72,8 @@ __global__ __launch_bounds__(MLP_WAVES * 64) void predictor_mlp_kernel(MlpParams
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int li = lane & 15, lg = lane >> 4;
   // ---- LDS image: weights in fragment order + the fp32 vectors ----------------------------------------
-  T* sW1 = reinterpret_cast<T*>(smem);                                   // KS1*NT1 fragments of 512 elements
-  T* sW2 = sW1 + (size_t)p.KS1 * NT1 * 512;                              // KS2*(NT2+1) fragments
+  T* sW1 = reinterpret_cast<T*>(smem);                                   // KS1*NT1 fragments of 512 elements (W1S: 2*NT1)
+  T* sW2 = sW1 + (size_t)(W1S ? 2 : p.KS1) * NT1 * 512;                  // KS2*(NT2+1) fragments
   float* sV = reinterpret_cast<float*>(sW2 + (size_t)KS2 * (NT2 + 1) * 512);
   constexpr int NVEC = 3 * D1 + D2 + 2 * Wd + 2;
   constexpr int QSTR = Wd * 16 + 16;                                     // bytes per 4-head block row of the tile (+16: banks)
@@ -77,7 +82,8 @@ __global__ __launch_bounds__(MLP_WAVES * 64) void predictor_mlp_kernel(MlpParams
     const int n1 = p.KS1 * NT1 * 64, n2 = KS2 * (NT2 + 1) * 64;          // 16-byte chunks
     const uint4* g1 = reinterpret_cast<const uint4*>(p.w1p);
     const uint4* g2 = reinterpret_cast<const uint4*>(p.w2p);
-    for (int i = threadIdx.x; i < n1; i += MLP_WAVES * 64) reinterpret_cast<uint4*>(sW1)[i] = g1[i];
+    if (!W1S)
+      for (int i = threadIdx.x; i < n1; i += MLP_WAVES * 64) reinterpret_cast<uint4*>(sW1)[i] = g1[i];
     for (int i = threadIdx.x; i < n2; i += MLP_WAVES * 64) reinterpret_cast<uint4*>(sW2)[i] = g2[i];
     for (int i = threadIdx.x; i < NVEC; i += MLP_WAVES * 64) sV[i] = p.vec[i];
   }
@@ -90,12 +96,16 @@ __global__ __launch_bounds__(MLP_WAVES * 64) void predictor_mlp_kernel(MlpParams
   const int htiles = (p.H + 15) / 16;
   const int nitems = p.N * p.T * htiles;
   const int C8 = p.H >> 2;                                               // 8-channel blocks: (H*2)/8
-  for (int item = blockIdx.x * MLP_WAVES + wv; item < nitems; item += gridDim.x * MLP_WAVES) {
+  for (int base = blockIdx.x * MLP_WAVES; base < nitems; base += gridDim.x * MLP_WAVES) {
+    // (workgroup-uniform trip count: with W1S every wave joins the barriers of the weight ring, item or not)
+    const bool active = base + wv < nitems;
+    if (!W1S && !active) continue;
+    const int item = active ? base + wv : nitems - 1;
     const int ht = item % htiles;
     const int nt_ = item / htiles;
     const int t = nt_ % p.T, n = nt_ / p.T;
     const int h = ht * 16 + li;
-    const bool hok = h < p.H;
+    const bool hok = active && h < p.H;
     const T* xr = reinterpret_cast<const T*>(p.x) + n * p.xs_n + (hok ? h : 0) * p.xs_h + t * p.xs_t + 8 * lg;
 
     // ---- product 1: enc^T = W1 . x^T ------------------------------------------------------------------
@@ -105,13 +115,46 @@ __global__ __launch_bounds__(MLP_WAVES * 64) void predictor_mlp_kernel(MlpParams
     {
       // all K fragments of the 16 rows are requested up front (one exposed memory round trip per item; the
       // registers are free here -- the accumulators of product 2 do not exist yet)
-      constexpr int MAXKS = 8;
+      constexpr int MAXKS = W1S ? 12 : 8;
       uint4 xf[MAXKS];
 #pragma unroll
       for (int ks = 0; ks < MAXKS; ++ks) {
         xf[ks] = make_uint4(0, 0, 0, 0);
         if (ks < p.KS1 && hok && 32 * ks + 8 * lg < p.Din) xf[ks] = *reinterpret_cast<const uint4*>(xr + 32 * ks);
       }
+      if constexpr (W1S) {
+        constexpr int WCH = NT1 / MLP_WAVES;                              // 16-byte chunks of a k-step per thread
+        static_assert(NT1 % MLP_WAVES == 0, "a k-step's fragments divide over the workgroup");
+        const uint4* g1 = reinterpret_cast<const uint4*>(p.w1p);
+        // a thread's chunks of the next PF k-steps ride in registers: the L2 round trip of a k-step's weights (~1 us under
+        // load) is three MFMA blocks long, one step of look-ahead left every barrier waiting for it
+        constexpr int PF = 3;
+        uint4 wreg[PF][WCH];
+#pragma unroll
+        for (int f = 0; f < PF; ++f)
+#pragma unroll
+          for (int u = 0; u < WCH; ++u)
+            wreg[f][u] = (f < p.KS1) ? g1[(size_t)f * NT1 * 64 + threadIdx.x + u * MLP_WAVES * 64] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < MAXKS; ++ks) {
+          if (ks < p.KS1) {                                                 // workgroup-uniform
+            uint4* slot = reinterpret_cast<uint4*>(sW1) + (ks & 1) * NT1 * 64;
+#pragma unroll
+            for (int u = 0; u < WCH; ++u) slot[threadIdx.x + u * MLP_WAVES * 64] = wreg[ks % PF][u];
+            if (ks + PF < p.KS1) {
+#pragma unroll
+              for (int u = 0; u < WCH; ++u)
+                wreg[ks % PF][u] = g1[(size_t)(ks + PF) * NT1 * 64 + threadIdx.x + u * MLP_WAVES * 64];
+            }
+            __syncthreads();
+            const T* wk = w1l + (size_t)(ks & 1) * NT1 * 512;
+#pragma unroll
+            for (int i = 0; i < NT1; ++i)
+              acc1[i] = mlp_mfma<T>(*reinterpret_cast<const uint4*>(wk + i * 512), xf[ks], acc1[i]);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+      } else {
 #pragma unroll
       for (int ks = 0; ks < MAXKS; ++ks) {
         if (ks < p.KS1) {
@@ -121,6 +164,7 @@ __global__ __launch_bounds__(MLP_WAVES * 64) void predictor_mlp_kernel(MlpParams
             acc1[i] = mlp_mfma<T>(*reinterpret_cast<const uint4*>(wk + i * 512), xf[ks], acc1[i]);
           __builtin_amdgcn_sched_barrier(0);
         }
+      }
       }
     }
     // ---- bias, round (the Linear's 16-bit output), LayerNorm(D1) + exact GELU, round -> B operand of product 2 --
@@ -230,7 +274,7 @@ __global__ __launch_bounds__(MLP_WAVES * 64) void predictor_mlp_kernel(MlpParams
       for (int c0 = 0; c0 < 4 * Wd; c0 += 64) {
         const int c = c0 + lane, q = c / Wd, w = c - q * Wd;
         const uint4 v = *reinterpret_cast<const uint4*>(sTile + q * QSTR + w * 16);
-        if (ht * 4 + q < C8) *reinterpret_cast<uint4*>(yb + (int64_t)c * 8) = v;
+        if (active && ht * 4 + q < C8) *reinterpret_cast<uint4*>(yb + (int64_t)c * 8) = v;
       }
     } else if (hok) {   // channel = 2h + split: this lane's pair is bytes [4*(h%4), +4) of block h/4, pixel w
       T* yb = reinterpret_cast<T*>(p.x_c8) + (((int64_t)n * p.T + t) * C8 + (h >> 2)) * (Wd * 8) + (h & 3) * 2;
@@ -271,7 +315,22 @@ static int launch_mlp(const MlpParams& p, int nt1, int nt2, hipStream_t s) {
     else hipLaunchKernelGGL((predictor_mlp_kernel<T, A, B, NW, false>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);       \
     rc = SEA_OK;                                                                                                    \
   } while (0)
-  if (nt1 == 8 && nt2 == 8) SEA_MLP(8, 8);
+  if (nt1 == 16 && nt2 == 8) {                               // d = 128: encoder weights streamed through a two-slot LDS ring
+    constexpr int A = 16, B = 8, NW = 8;
+    const size_t wbytes = ((size_t)2 * A + (size_t)(A / 2) * (B + 1)) * 1024 + (size_t)((3 * A * 16 + 2 * B * 16 + 2 + 3) & ~3) * sizeof(float);
+    const size_t lds = wbytes + (size_t)NW * 4 * (B * 8 * 16 + 16);
+    if (lds <= 160 * 1024 && p.KS1 <= 12) {
+      int64_t blocks = (nitems + NW - 1) / NW;
+      if (blocks > 256) blocks = 256;
+      static bool configured = false;
+      if (!configured) {
+        (void)hipFuncSetAttribute((const void*)predictor_mlp_kernel<T, A, B, NW, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        configured = true;
+      }
+      hipLaunchKernelGGL((predictor_mlp_kernel<T, A, B, NW, true, true>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);
+      rc = SEA_OK;
+    }
+  } else if (nt1 == 8 && nt2 == 8) SEA_MLP(8, 8);
   else if (nt1 == 8 && nt2 == 4) SEA_MLP(8, 4);
   else if (nt1 == 8 && nt2 == 16) SEA_MLP(8, 16);
   else if (nt1 == 10 && nt2 == 8) SEA_MLP(10, 8);
@@ -287,8 +346,8 @@ extern "C" int sea_predictor_mlp(const void* x, int dtype, int64_t N, int64_t H,
   SEA_REQUIRE(x && x_strides && w1_packed && w2_packed && vectors && x_c8, SEA_EINVAL, "%s: null pointer", nm);
   SEA_REQUIRE(dtype == SEA_F16 || dtype == SEA_BF16, SEA_EUNSUPPORTED, "%s: 16-bit data only (dtype %d)", nm, dtype);
   SEA_REQUIRE(N > 0 && H > 0 && T > 0 && Din > 0 && D1 > 0 && D2 > 0, SEA_EINVAL, "%s: bad shape", nm);
-  SEA_REQUIRE(Din % 8 == 0 && Din <= 256 && D1 % 32 == 0 && D2 % 32 == 0 && H % 4 == 0, SEA_EUNSUPPORTED,
-              "%s: needs Din %% 8 == 0, Din <= 256, D1 %% 32 == 0, D2 %% 32 == 0, H %% 4 == 0", nm);
+  SEA_REQUIRE(Din % 8 == 0 && Din <= (D1 == 256 ? 384 : 256) && D1 % 32 == 0 && D2 % 32 == 0 && H % 4 == 0, SEA_EUNSUPPORTED,
+              "%s: needs Din %% 8 == 0, Din <= 256 (384 with D1 = 256), D1 %% 32 == 0, D2 %% 32 == 0, H %% 4 == 0", nm);
   SEA_REQUIRE(x_strides[0] % 8 == 0 && x_strides[1] % 8 == 0 && x_strides[2] % 8 == 0 &&
                   (((uintptr_t)x | (uintptr_t)w1_packed | (uintptr_t)w2_packed | (uintptr_t)x_c8 | (uintptr_t)tpred) & 15) == 0,
               SEA_EUNSUPPORTED, "%s: 16-byte alignment", nm);

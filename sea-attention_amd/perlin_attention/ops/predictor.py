@@ -292,6 +292,8 @@ def performer_step(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torch
 
 def predictor_mlp_supported(D1: int, D2: int, H: int, Din: int) -> bool:
     """Shapes csrc/sea_mlp.hip is instantiated for (launch_mlp)."""
+    if (D1, D2) == (256, 128):                                    # d = 128: encoder weights streamed through LDS
+        return H % 4 == 0 and Din % 8 == 0 and Din <= 384
     return (D1, D2) in ((128, 128), (128, 64), (128, 256), (160, 128)) and H % 4 == 0 and Din % 8 == 0 and Din <= 256
 
 

@@ -280,7 +280,8 @@ def test_estimator_kernels_are_bitwise_reproducible(ops):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,H,T,d,T_M", [(2, 32, 40, 64, 256), (1, 12, 33, 64, 256), (1, 4, 70, 64, 128), (1, 8, 20, 64, 512),
-                                         (1, 20, 17, 80, 256)])
+                                         (1, 20, 17, 80, 256),
+                                         (1, 40, 50, 128, 256), (2, 8, 300, 128, 256)])   # d = 128: encoder weights streamed
 def test_predictor_mlp(ops, dtype, N, H, T, d, T_M):
     """Fused enc Linear+LN+GELU -> dec_row Linear+ChannelSplit+LN (C8) + gate Linear+sigmoid vs the module chain in fp32
     with the 16-bit rounding of every module output."""
