@@ -1,5 +1,5 @@
 import os, sys, json, ctypes, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sea_attention_amd.perlin_attention import ops
 from sea_attention_amd import _lib
 N, H, T, T_M, k = 8, 32, 4096, 256, 64; dev = "cuda:0"; dt = torch.bfloat16

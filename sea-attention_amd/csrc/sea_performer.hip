@@ -905,6 +905,459 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   }
 }
 
+// ---- wide heads (D = 128): the same algorithm with the chunk cut to C = 32 rows so that the LDS images fit (the D = 64
+// plan scaled up is 208 KB), two 16-column blocks of [pos | v] per wave (E / 16 = 16 blocks over 8 waves: each wave keeps
+// two state tiles S), 16 staging chunks per row, and a V image of 512-byte rows whose chunk swizzle spreads the eight
+// rows of a transposing read over the eight 8-bank groups.  Everything else -- split operands, transposed products,
+// transposing reads, the cumulative average on the matrix cores, segments, state images -- is the D = 64 kernel's.
+template <typename T, int D, int C, int NBT, bool STATE_ONLY>
+__global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
+  constexpr int NW = 8, NTH = 512, E = 2 * D, CPR = D / 8;
+  static_assert(C * CPR == NTH && (E / 16) % NW == 0 && C % 16 == 0, "one staging chunk per thread, whole column blocks per wave");
+  constexpr int NBP = NBT * 16;
+  constexpr int KF = (NBT + 1) / 2;            // 32-wide k-steps over the (padded) features
+  constexpr int FP = KF * 32;                  // padded feature count
+  constexpr int RB = C / 16, EB = E / 16, JB = EB / NW, NPART = 8;
+  // LDS row strides picked with a bank model of the two access patterns (64 banks x 4 B; b128 row reads are served in
+  // 4 lane groups of 16, transposing b64 reads in 2 of 32): 160 / 224 B rows make the operand row reads conflict-free
+  // (4 cycles per wave instruction; the first version's 144 B rows: 8), 192 B rows halve the conflicts of the
+  // transposing reads of phi(K) (4 cycles; 144 B: 8; the conflict-free 2 needs a swizzle); rows stay 16-byte multiples
+  constexpr int LDQ2 = FP + 16;                // phi(Q) rows (elements): row reads only
+  constexpr int LDK2 = (FP == 64) ? 96 : FP + 8; // phi(K) rows (16-byte multiples): transposing reads + a few row reads
+  constexpr int LDA = C + 16;                  // A rows: row reads only
+  constexpr int DSL = RB + NPART;              // denominator partial slots per row
+  extern __shared__ __attribute__((aligned(16))) char smem_b[];
+  unsigned short* sW = reinterpret_cast<unsigned short*>(smem_b);   // [D/8][NBP][8]   projection, k-chunked
+  unsigned short* sQ = sW + (D / 8) * NBP * 8;                      // [D/8][C][8]
+  unsigned short* sK = sQ + (D / 8) * C * 8;                        // [D/8][C][8]
+  unsigned short* sV = sK + (D / 8) * C * 8;                        // [C][E] 256-byte rows, chunk-swizzled
+  unsigned short* sQh = sV + C * E;                                 // [C][LDQ2]
+  unsigned short* sQl = sQh + C * LDQ2;
+  unsigned short* sKh = sQl + C * LDQ2;                             // [C][LDK2]
+  unsigned short* sKl = sKh + C * LDK2;
+  unsigned short* sAh = sKl + C * LDK2;                             // [C][LDA]
+  unsigned short* sAl = sAh + C * LDA;
+  constexpr int LDO = E + 8;
+  unsigned short* sO = sAl + C * LDA;                               // [C][LDO]  the chunk's result rows, flushed one chunk later
+  constexpr int LDG = D + 8;
+  unsigned short* sAvg = sO + C * LDO;                              // [C][LDG]  cumulative-average rows (optional output)
+  float* sKsum = reinterpret_cast<float*>(sAvg + C * LDG);          // [FP]
+  float* sDen = sKsum + FP;                                         // [C]
+  float* sDenP = sDen + C;                                          // [C][DSL]
+  float* sKsP = sDenP + C * DSL;                                    // [NW][FP]   per-wave k-sum increments
+  float* sRinv = sKsP + NW * FP;                                    // [C]        1 / (absolute row index + 1)
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int nh = blockIdx.x;
+  const int n = nh / p.H, h = nh - n * p.H;
+  const int seg = blockIdx.y;                              // sequence-parallel form, see PerfParams
+  const int t_begin = seg * p.seg_len, t_end = min(p.T, t_begin + p.seg_len);
+  const T* qb = reinterpret_cast<const T*>(p.q) + n * p.qs[0] + h * p.qs[1];
+  const T* kb = reinterpret_cast<const T*>(p.k) + n * p.ks[0] + h * p.ks[1];
+  const T* vb = reinterpret_cast<const T*>(p.v) + n * p.vs[0] + h * p.vs[1];
+  const T* pb = reinterpret_cast<const T*>(p.pos);
+  T* ob = reinterpret_cast<T*>(p.out) + (int64_t)nh * p.T * (3 * D);
+  const float cnorm = powf((float)D, -0.25f);
+
+  // projection (its values are bf16-exact: the reference casts the buffer to the data dtype), zero padded rows
+  for (int i = tid; i < (D / 8) * NBP * 8; i += NTH) {
+    const int j = i & 7, f = (i >> 3) % NBP, kc = (i >> 3) / NBP;
+    sW[i] = f < p.nb ? S16<T>::bits(p.W[f * D + kc * 8 + j]) : (unsigned short)0;
+  }
+  // phi and A images: padded features / upper-triangular tiles are written once (zero) and never again
+  for (int i = tid; i < 2 * C * LDQ2 + 2 * C * LDK2 + 2 * C * LDA; i += NTH) sQh[i] = 0;
+  for (int i = tid; i < C * DSL; i += NTH) sDenP[i] = 0.f;   // slots of key blocks above the diagonal stay zero
+
+  // carry image of one (n, h, segment): per-thread state registers, the k-sum, the per-thread column sum of v
+  constexpr int CARRY = JB * NBT * 4 * NTH + FP + JB * NTH;
+  f4 S[JB][NBT];
+  float csum[JB];                                          // running column sums of v (cumulative-average output)
+#pragma unroll
+  for (int jq = 0; jq < JB; ++jq) {
+    csum[jq] = 0.f;
+#pragma unroll
+    for (int b = 0; b < NBT; ++b) S[jq][b] = f4{0.f, 0.f, 0.f, 0.f};
+  }
+  {
+    float ks0 = 0.f;
+    if (!STATE_ONLY && p.state_in) {                       // increments of pass 1 do not include the incoming state
+      const float* cr = p.state_in + (int64_t)nh * CARRY;
+#pragma unroll
+      for (int jq = 0; jq < JB; ++jq) {
+#pragma unroll
+        for (int b = 0; b < NBT; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) S[jq][b][r] = cr[((jq * NBT + b) * 4 + r) * NTH + tid];
+        csum[jq] = cr[JB * NBT * 4 * NTH + FP + jq * NTH + tid];
+      }
+      if (tid < FP) ks0 = cr[JB * NBT * 4 * NTH + tid];
+    }
+    if (!STATE_ONLY) {
+      for (int s2 = 0; s2 < seg; ++s2) {                   // fixed order: bitwise reproducible
+        const float* cr = p.carry + ((int64_t)nh * (p.nseg - 1) + s2) * CARRY;
+#pragma unroll
+        for (int jq = 0; jq < JB; ++jq) {
+#pragma unroll
+          for (int b = 0; b < NBT; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) S[jq][b][r] += cr[((jq * NBT + b) * 4 + r) * NTH + tid];
+          csum[jq] += cr[JB * NBT * 4 * NTH + FP + jq * NTH + tid];
+        }
+        if (tid < FP) ks0 += cr[JB * NBT * 4 * NTH + tid];
+      }
+    }
+    if (tid < FP) sKsum[tid] = ks0;
+  }
+
+  // one 16-byte piece of each tensor per thread and chunk; prefetched one chunk ahead
+  const int sr = tid / CPR, sc = tid - sr * CPR;   // staging row, 8-element column chunk
+  // All global traffic goes through buffer instructions with hardware range checking: a row beyond T reads zeros /
+  // drops its store WITHOUT a branch.  (Branches around loads and stores make the compiler's vmcnt bookkeeping
+  // pessimistic: the wait for the prefetched chunk then also waits for every output store of the previous one.)
+  constexpr unsigned OOB = 0x7FFFFF00u;
+  auto mk = [&](const T* base, int64_t row_stride) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (int)(((int64_t)(p.T - 1) * row_stride + D) * 2), 0x00020000);
+  };
+  const __amdgpu_buffer_rsrc_t rq = mk(qb, p.qs[2]), rk = mk(kb, p.ks[2]), rv = mk(vb, p.vs[2]), rp = mk(pb, p.pos_stride);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((int64_t)p.T * 3 * D * 2), 0x00020000);
+  typedef __attribute__((ext_vector_type(4))) unsigned int bu4;
+  const bool want_avg = p.avg != nullptr;                  // block-uniform
+  T* gb = reinterpret_cast<T*>(p.avg) + (want_avg ? (int64_t)nh * p.T * D : 0);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(gb, 0, want_avg ? (int)((int64_t)p.T * D * 2) : 0, 0x00020000);
+  bu4 pq, pk, pv, pp;
+  auto issue_loads = [&](int t0n) {
+    const int t = t0n + sr;
+    const bool ok = t < t_end;
+    pq = __builtin_amdgcn_raw_buffer_load_b128(rq, (ok && !STATE_ONLY) ? (int)((t * p.qs[2] + sc * 8) * 2) : (int)OOB, 0, 0);
+    pk = __builtin_amdgcn_raw_buffer_load_b128(rk, ok ? (int)((t * p.ks[2] + sc * 8) * 2) : (int)OOB, 0, 0);
+    pv = __builtin_amdgcn_raw_buffer_load_b128(rv, ok ? (int)((t * p.vs[2] + sc * 8) * 2) : (int)OOB, 0, 0);
+    pp = __builtin_amdgcn_raw_buffer_load_b128(rp, ok ? (int)((t * p.pos_stride + sc * 8) * 2) : (int)OOB, 0, 0);
+  };
+  issue_loads(t_begin);
+  // the result tile of a chunk leaves LDS as 16-byte row pieces at the START of the next chunk, i.e. before that
+  // chunk's prefetch loads are issued: a wait for those loads never has younger stores in front of it
+  auto flush_out = [&](int t0p, int rowsp) {
+#pragma unroll
+    for (int i = tid; i < C * (E / 8); i += NTH) {
+      const int row = i / (E / 8), ch = i - row * (E / 8);
+      const bu4 v = *reinterpret_cast<const bu4*>(sO + row * LDO + ch * 8);
+      __builtin_amdgcn_raw_buffer_store_b128(v, ro, row < rowsp ? ((t0p + row) * (3 * D) + ch * 8) * 2 : (int)OOB, 0, 0);
+    }
+    if (want_avg) {                                        // C * D / 8 = 512 pieces: one per thread
+      const int row = tid / (D / 8), ch = tid - row * (D / 8);
+      const bu4 v = *reinterpret_cast<const bu4*>(sAvg + row * LDG + ch * 8);
+      __builtin_amdgcn_raw_buffer_store_b128(v, rg, row < rowsp ? ((t0p + row) * D + ch * 8) * 2 : (int)OOB, 0, 0);
+    }
+  };
+  // swizzled chunk position inside a 256-byte row of the V image (conflict-free transposing reads)
+  // 512-byte rows (32 chunks): rows {r..r+3, r+8..r+11} of one transposing read get the eight values of
+  // (row & 3) | (bit 3 of row) << 2 XOR-ed into bits 1..3 of the chunk index -> eight disjoint 8-bank groups
+  auto vchunk = [](int row, int ch) {
+    if (E == 128) return ch ^ (((row & 3) << 2) | ((row >> 2) & 3));
+    return ch ^ ((((row & 3) | (((row >> 3) & 1) << 2))) << 1);
+  };
+
+  // cumulative average of v (step K's input) on the waves that own the v columns: prefix sum over the chunk rows =
+  // tril(ones) . V on the matrix cores (1.0 and v are exact in bf16, fp32 accumulation) + the running column sum
+  auto tril_frag = [&](int ib, int ks) {
+    unsigned short o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (ks * 32 + lg * 8 + j <= ib * 16 + li) ? S16<T>::ONE : (unsigned short)0;
+    const unsigned short (&o0)[4] = *reinterpret_cast<const unsigned short (*)[4]>(&o[0]);
+    const unsigned short (&o1)[4] = *reinterpret_cast<const unsigned short (*)[4]>(&o[4]);
+    return cat8(pack4(o0), pack4(o1));
+  };
+
+  uint4 tril[RB][C / 32];                                  // loop-invariant A operands of the prefix-sum product
+#pragma unroll
+  for (int ib = 0; ib < RB; ++ib)
+#pragma unroll
+    for (int ks = 0; ks < C / 32; ++ks) tril[ib][ks] = tril_frag(ib, ks);
+
+  for (int t0 = t_begin; t0 < t_end; t0 += C) {
+    const int rows = min(C, t_end - t0);
+    // ---- (a) staging ---------------------------------------------------------------------------------
+    if (!STATE_ONLY) __builtin_amdgcn_raw_buffer_store_b128(pv, ro, sr < rows ? ((t0 + sr) * (3 * D) + 2 * D + sc * 8) * 2 : (int)OOB, 0, 0);
+    *reinterpret_cast<bu4*>(sQ + (sc * C + sr) * 8) = pq;
+    *reinterpret_cast<bu4*>(sK + (sc * C + sr) * 8) = pk;
+    *reinterpret_cast<bu4*>(sV + sr * E + vchunk(sr, sc) * 8) = pp;
+    *reinterpret_cast<bu4*>(sV + sr * E + vchunk(sr, D / 8 + sc) * 8) = pv;
+    if (!STATE_ONLY && t0 > t_begin) flush_out(t0 - C, C);                     // (block-uniform)
+    issue_loads(t0 + C);                                                      // rows beyond T come back as zeros
+    __syncthreads();
+
+    // ---- (b) feature maps, transposed: X^T[f][t] = sum_d W[f][d] x[t][d]; wave = (Q | K, row block) ----------
+    if (wv < 2 * RB && (!STATE_ONLY || wv >= RB)) {          // the state-only pass needs phi(K) alone (wave-uniform)
+      const int which = wv / RB, rb = wv - which * RB;
+      const unsigned short* src = which ? sK : sQ;
+      f4 acc[NBT];
+#pragma unroll
+      for (int fb = 0; fb < NBT; ++fb) acc[fb] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < D / 32; ++ks) {
+        const uint4 bx = *reinterpret_cast<const uint4*>(src + ((4 * ks + lg) * C + rb * 16 + li) * 8);
+#pragma unroll
+        for (int fb = 0; fb < NBT; ++fb) {
+          const uint4 aw = *reinterpret_cast<const uint4*>(sW + ((4 * ks + lg) * NBP + fb * 16 + li) * 8);
+          acc[fb] = S16<T>::mfma(aw, bx, acc[fb]);
+        }
+      }
+      unsigned short* dh = which ? sKh : sQh;
+      unsigned short* dl = which ? sKl : sQl;
+      const int row = rb * 16 + li;                          // lane: 4 consecutive features of one row
+#pragma unroll
+      for (int fb = 0; fb < NBT; ++fb) {
+        unsigned short hh[4], ll[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int f = fb * 16 + lg * 4 + r;
+          float val = fmaxf(cnorm * acc[fb][r], 0.f) + 1e-3f;
+          if (f >= p.nb || row >= rows) val = 0.f;           // padded features / rows beyond T contribute nothing
+          split16<T>(val, hh[r], ll[r]);
+        }
+        // feature 32kk + 16a + 4g + j is stored at position 32kk + 8g + 4a + j: the 8 features lane group g needs of
+        // a 32-wide k-step in (d) (4 of tile 2kk, 4 of tile 2kk+1) are then one 16-byte piece
+        const int pos = (fb >> 1) * 32 + lg * 8 + (fb & 1) * 4;
+        const int ldx = which ? LDK2 : LDQ2;
+        *reinterpret_cast<uint2*>(dh + row * ldx + pos) = pack4(hh);
+        *reinterpret_cast<uint2*>(dl + row * ldx + pos) = pack4(ll);
+      }
+    }
+    __syncthreads();
+
+    // ---- (c) A^T tiles (lower triangle), denominator and k-sum partials ------------------------------------
+    if constexpr (!STATE_ONLY)
+    for (int tile = wv; tile < RB * (RB + 1) / 2; tile += NW) {
+      int ib = 0, rem = tile;
+      while (rem > ib) { rem -= ib + 1; ++ib; }              // tile -> (query block ib, key block jb <= ib)
+      const int jb = rem;
+      f4 acc = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KF; ++ks) {
+        const int ko = ks * 32 + lg * 8;
+        const uint4 kh = *reinterpret_cast<const uint4*>(sKh + (jb * 16 + li) * LDK2 + ko);
+        const uint4 kl = *reinterpret_cast<const uint4*>(sKl + (jb * 16 + li) * LDK2 + ko);
+        const uint4 qh = *reinterpret_cast<const uint4*>(sQh + (ib * 16 + li) * LDQ2 + ko);
+        const uint4 ql = *reinterpret_cast<const uint4*>(sQl + (ib * 16 + li) * LDQ2 + ko);
+        acc = S16<T>::mfma(kh, qh, acc);
+        acc = S16<T>::mfma(kh, ql, acc);
+        acc = S16<T>::mfma(kl, qh, acc);
+      }
+      const int trow = ib * 16 + li;                         // lane: A[trow][s0 .. s0+3]
+      const int s0 = jb * 16 + lg * 4;
+      unsigned short hh[4], ll[4];
+      float rs = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float val = (s0 + r <= trow) ? acc[r] : 0.f;   // causal mask inside the diagonal tiles
+        rs += val;
+        split16<T>(val, hh[r], ll[r]);
+      }
+      *reinterpret_cast<uint2*>(sAh + trow * LDA + s0) = pack4(hh);
+      *reinterpret_cast<uint2*>(sAl + trow * LDA + s0) = pack4(ll);
+      rs = xor32_sum(xor16_sum(rs));
+      if (lg == 0) sDenP[trow * DSL + jb] = rs;              // one writer per (row, key block)
+    }
+    {
+      // carry part of the denominators: phi(q_t) . (ksum + eps) over the (permuted) feature positions
+      const int row = tid & (C - 1), part = tid / C;         // NPART parts x (FP / NPART) positions
+      constexpr int PER = FP / NPART;
+      static_assert(PER % 4 == 0, "four positions per step");
+      float s = 0.f;
+      if constexpr (!STATE_ONLY)
+      if (part < NPART)
+#pragma unroll
+      for (int g4 = 0; g4 < PER / 4; ++g4) {
+        const int f = part * PER + g4 * 4;
+        const uint2 qh = *reinterpret_cast<const uint2*>(sQh + row * LDQ2 + f);
+        const uint2 ql = *reinterpret_cast<const uint2*>(sQl + row * LDQ2 + f);
+        const float4 ks = *reinterpret_cast<const float4*>(sKsum + f);
+        s = fmaf(S16<T>::val((unsigned short)(qh.x & 0xffff)) + S16<T>::val((unsigned short)(ql.x & 0xffff)), ks.x + 1e-6f, s);
+        s = fmaf(S16<T>::val((unsigned short)(qh.x >> 16)) + S16<T>::val((unsigned short)(ql.x >> 16)), ks.y + 1e-6f, s);
+        s = fmaf(S16<T>::val((unsigned short)(qh.y & 0xffff)) + S16<T>::val((unsigned short)(ql.y & 0xffff)), ks.z + 1e-6f, s);
+        s = fmaf(S16<T>::val((unsigned short)(qh.y >> 16)) + S16<T>::val((unsigned short)(ql.y >> 16)), ks.w + 1e-6f, s);
+      }
+      if (part < NPART) sDenP[row * DSL + RB + part] = s;
+      // k-sum increment: wave w owns rows 8w .. 8w+7; lane = (4-position group fc, row lane rr)
+      constexpr int FG = FP / 4, RRN = 64 / FG, RPL = (C / NW) / RRN;
+      const int fc = lane % FG, rr = lane / FG;
+      float k4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (rr < RRN) {
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+          const int r2 = wv * (C / NW) + rr * RPL + j;
+          const uint2 kh = *reinterpret_cast<const uint2*>(sKh + r2 * LDK2 + fc * 4);
+          const uint2 kl = *reinterpret_cast<const uint2*>(sKl + r2 * LDK2 + fc * 4);
+          k4[0] += S16<T>::val((unsigned short)(kh.x & 0xffff)) + S16<T>::val((unsigned short)(kl.x & 0xffff));
+          k4[1] += S16<T>::val((unsigned short)(kh.x >> 16)) + S16<T>::val((unsigned short)(kl.x >> 16));
+          k4[2] += S16<T>::val((unsigned short)(kh.y & 0xffff)) + S16<T>::val((unsigned short)(kl.y & 0xffff));
+          k4[3] += S16<T>::val((unsigned short)(kh.y >> 16)) + S16<T>::val((unsigned short)(kl.y >> 16));
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (FG == 16) {
+          k4[j] = xor16_sum(xor32_sum(k4[j]));                   // (l, l+32) then (+16): same association as the shuffle form
+        } else {
+#pragma unroll
+          for (int o = FG * (RRN / 2); o >= FG; o >>= 1) k4[j] += __shfl_down(k4[j], o);   // fixed order
+        }
+      }
+      if (lane < FG) *reinterpret_cast<float4*>(sKsP + wv * FP + fc * 4) = make_float4(k4[0], k4[1], k4[2], k4[3]);
+    }
+    __syncthreads();
+    if (tid < C) {
+      float s = 0.f;
+#pragma unroll
+      for (int i = 0; i < DSL; ++i) s += sDenP[tid * DSL + i];
+      sDen[tid] = 1.0f / s;                                  // the 16 column waves multiply by the reciprocal
+      sRinv[tid] = 1.0f / (float)(p.t_base + t0 + tid + 1);
+    } else if (tid >= C && tid < C + FP) {
+      const int f = tid - C;
+      float s = sKsum[f];
+#pragma unroll
+      for (int i = 0; i < NW; ++i) s += sKsP[i * FP + f];         // fixed order: bitwise reproducible
+      sKsum[f] = s;
+    }
+    __syncthreads();
+
+    // ---- (d) O = A V + phi(Q) S over this wave's 16 columns; (e) S += phi(K)^T V ------------------------------
+#pragma unroll
+    for (int jq = 0; jq < JB; ++jq) {
+      const int jb = wv + jq * NW, e0 = jb * 16;
+      // V fragments (B operand, k = chunk row): rows 32ks + 8lg + {0..3 | 4..7}, columns e0 .. e0+15
+      uint4 vf[C / 32];
+      {
+        const int q = li >> 2, pp_ = li & 3;
+#pragma unroll
+        for (int ks = 0; ks < C / 32; ++ks) {
+          const int r0 = ks * 32 + lg * 8;
+          const uint2 a = lds_tr(sV + (r0 + q) * E + vchunk(r0 + q, 2 * jb + (pp_ >> 1)) * 8 + 4 * (pp_ & 1));
+          const uint2 b = lds_tr(sV + (r0 + 4 + q) * E + vchunk(r0 + 4 + q, 2 * jb + (pp_ >> 1)) * 8 + 4 * (pp_ & 1));
+          vf[ks] = cat8(a, b);
+        }
+      }
+      if constexpr (STATE_ONLY) {
+        if (want_avg && jb >= EB / 2) {                    // column total of the chunk = the last row's prefix
+          f4 cum = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks <= (RB - 1) / 2; ++ks) cum = S16<T>::mfma(tril[RB - 1][ks], vf[ks], cum);
+          csum[jq] += __shfl(cum[3], 48 + li);
+        }
+      } else {
+      f4 o[RB];
+#pragma unroll
+      for (int ib = 0; ib < RB; ++ib) o[ib] = f4{0.f, 0.f, 0.f, 0.f};
+      // A V: key k-step ks covers key blocks 2ks, 2ks+1; query block ib needs k-steps <= ib/2
+#pragma unroll
+      for (int ib = 0; ib < RB; ++ib) {
+#pragma unroll
+        for (int ks = 0; ks <= ib / 2; ++ks) {
+          const uint4 ah = *reinterpret_cast<const uint4*>(sAh + (ib * 16 + li) * LDA + ks * 32 + lg * 8);
+          const uint4 al = *reinterpret_cast<const uint4*>(sAl + (ib * 16 + li) * LDA + ks * 32 + lg * 8);
+          o[ib] = S16<T>::mfma(ah, vf[ks], o[ib]);
+          o[ib] = S16<T>::mfma(al, vf[ks], o[ib]);
+        }
+      }
+      // phi(Q) S: the state tiles, split, are the B operand; k-step kk pairs feature blocks 2kk and 2kk+1
+#pragma unroll
+      for (int kk = 0; kk < KF; ++kk) {
+        unsigned short h0[4], h1[4], l0[4], l1[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          split16<T>(S[jq][2 * kk][r], h0[r], l0[r]);
+          if (2 * kk + 1 < NBT) split16<T>(S[jq][(2 * kk + 1 < NBT) ? 2 * kk + 1 : 0][r], h1[r], l1[r]);
+          else h1[r] = l1[r] = 0;
+        }
+        const uint4 bh = cat8(pack4(h0), pack4(h1)), bl = cat8(pack4(l0), pack4(l1));
+#pragma unroll
+        for (int ib = 0; ib < RB; ++ib) {
+          const uint4 ah = *reinterpret_cast<const uint4*>(sQh + (ib * 16 + li) * LDQ2 + kk * 32 + lg * 8);
+          const uint4 al = *reinterpret_cast<const uint4*>(sQl + (ib * 16 + li) * LDQ2 + kk * 32 + lg * 8);
+          o[ib] = S16<T>::mfma(ah, bh, o[ib]);
+          o[ib] = S16<T>::mfma(ah, bl, o[ib]);
+          o[ib] = S16<T>::mfma(al, bh, o[ib]);
+        }
+      }
+      const int col = e0 + li;
+#pragma unroll
+      for (int ib = 0; ib < RB; ++ib) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = ib * 16 + lg * 4 + r;
+          sO[row * LDO + col] = S16<T>::bits(o[ib][r] * sDen[row]);
+        }
+      }
+      if (want_avg && jb >= EB / 2) {                      // wave-uniform: this wave's 16 columns are v features
+        f4 cum[RB];
+#pragma unroll
+        for (int ib = 0; ib < RB; ++ib) {
+          cum[ib] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks <= ib / 2; ++ks) cum[ib] = S16<T>::mfma(tril[ib][ks], vf[ks], cum[ib]);
+        }
+        const int gcol = col - D;
+#pragma unroll
+        for (int ib = 0; ib < RB; ++ib)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = ib * 16 + lg * 4 + r;
+            sAvg[row * LDG + gcol] = S16<T>::bits((cum[ib][r] + csum[jq]) * sRinv[row]);
+          }
+        csum[jq] += __shfl(cum[RB - 1][3], 48 + li);       // column total of the chunk = its last row's prefix
+      }
+      }
+      // (e) S[f][e] += sum_s phi(k_s)[f] V[s][e]: A operand = phi(K)^T by transposing reads of the row-major images
+      {
+        const int q = li >> 2, pp_ = li & 3;
+#pragma unroll
+        for (int rb = 0; rb < NBT; ++rb) {
+#pragma unroll
+          for (int ks = 0; ks < C / 32; ++ks) {
+            const int r0 = ks * 32 + lg * 8;
+            const int co = (rb >> 1) * 32 + 8 * pp_ + (rb & 1) * 4;      // positions of features 16rb + 4p .. +3
+            const uint4 kh = cat8(lds_tr(sKh + (r0 + q) * LDK2 + co), lds_tr(sKh + (r0 + 4 + q) * LDK2 + co));
+            const uint4 kl = cat8(lds_tr(sKl + (r0 + q) * LDK2 + co), lds_tr(sKl + (r0 + 4 + q) * LDK2 + co));
+            S[jq][rb] = S16<T>::mfma(kh, vf[ks], S[jq][rb]);
+            S[jq][rb] = S16<T>::mfma(kl, vf[ks], S[jq][rb]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if constexpr (STATE_ONLY) {
+    float* cw = p.carry + ((int64_t)nh * (p.nseg - 1) + seg) * CARRY;
+#pragma unroll
+    for (int jq = 0; jq < JB; ++jq) {
+#pragma unroll
+      for (int b = 0; b < NBT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cw[((jq * NBT + b) * 4 + r) * NTH + tid] = S[jq][b][r];
+      cw[JB * NBT * 4 * NTH + FP + jq * NTH + tid] = csum[jq];
+    }
+    if (tid < FP) cw[JB * NBT * 4 * NTH + tid] = sKsum[tid];
+  } else {
+    const int t0l = t_begin + ((t_end - t_begin - 1) / C) * C;
+    flush_out(t0l, t_end - t0l);
+    if (p.state_out && seg == p.nseg - 1) {                // the block that walked the last rows holds the final state
+      float* cw = p.state_out + (int64_t)nh * CARRY;
+#pragma unroll
+      for (int jq = 0; jq < JB; ++jq) {
+#pragma unroll
+        for (int b = 0; b < NBT; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) cw[((jq * NBT + b) * 4 + r) * NTH + tid] = S[jq][b][r];
+        cw[JB * NBT * 4 * NTH + FP + jq * NTH + tid] = csum[jq];
+      }
+      if (tid < FP) cw[JB * NBT * 4 * NTH + tid] = sKsum[tid];
+    }
+  }
+}
+
 }  // namespace sea
 
 using namespace sea;
@@ -959,13 +1412,37 @@ static int launch_perf_bf16(const PerfParams& p, hipStream_t s) {
 template <int NBT>
 constexpr int64_t perf_bf16_carry_floats() { return (int64_t)NBT * 4 * 512 + ((NBT + 1) / 2) * 32 + 512; }
 
+// the wide-head form of the 16-bit kernel (d = 128: 32-row chunks, two column blocks per wave)
+template <typename T, int D, int C, int NBT>
+static int launch_perf_bf16w(const PerfParams& p, hipStream_t s) {
+  constexpr int NTH = 512, E = 2 * D, NBP = NBT * 16, FP = ((NBT + 1) / 2) * 32, LDQ2 = FP + 16, LDK2 = (FP == 64) ? 96 : FP + 8, LDA = C + 16;
+  constexpr size_t lds = 2 * ((D / 8) * NBP * 8 + 2 * (D / 8) * C * 8 + C * E + 2 * C * LDQ2 + 2 * C * LDK2 + 2 * C * LDA + C * (E + 8) + C * (D + 8)) +
+                         sizeof(float) * (FP + C + C * (C / 16 + 8) + 8 * FP + C);
+  static_assert(lds <= 160 * 1024, "LDS budget");
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute((const void*)performer_bf16w_kernel<T, D, C, NBT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute((const void*)performer_bf16w_kernel<T, D, C, NBT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    configured = true;
+  }
+  if (p.seg_len % C != 0) return SEA_EINVAL;
+  if (p.nseg > 1)
+    hipLaunchKernelGGL((performer_bf16w_kernel<T, D, C, NBT, true>), dim3((unsigned)(p.N * p.H), (unsigned)(p.nseg - 1)), dim3(NTH), lds, s, p);
+  hipLaunchKernelGGL((performer_bf16w_kernel<T, D, C, NBT, false>), dim3((unsigned)(p.N * p.H), (unsigned)p.nseg), dim3(NTH), lds, s, p);
+  return SEA_OK;
+}
+
+template <int D, int NBT>
+constexpr int64_t perf_bf16w_carry_floats() { return (int64_t)(2 * D / 16 / 8) * NBT * 4 * 512 + ((NBT + 1) / 2) * 32 + (2 * D / 16 / 8) * 512; }
+
 template <typename T>
 static int dispatch_perf(const PerfParams& p, int D, int nbt, hipStream_t s) {
-  if constexpr (!std::is_same<T, float>::value) {           // 16-bit data, d = 64: split-operand 16-bit MFMA kernel
+  if constexpr (!std::is_same<T, float>::value) {           // 16-bit data, d = 64 / 128: split-operand 16-bit MFMA kernels
     if (D == 64) {
       if (nbt <= 3) return launch_perf_bf16<T, 3>(p, s);
       if (nbt <= 5) return launch_perf_bf16<T, 5>(p, s);
     }
+    if (D == 128 && nbt <= 5) return launch_perf_bf16w<T, 128, 32, 5>(p, s);
   }
   if (D == 64 && nbt <= 3) return launch_perf<T, 64, 3, 64>(p, s);
   if (D == 64 && nbt <= 5) return launch_perf<T, 64, 5, 64>(p, s);
@@ -990,6 +1467,7 @@ static int64_t perf_carry_floats_for(int dtype, int D, int nbt) {
     if (nbt <= 3) return perf_bf16_carry_floats<3>();
     if (nbt <= 5) return perf_bf16_carry_floats<5>();
   }
+  if (dtype != SEA_F32 && D == 128 && nbt <= 5) return perf_bf16w_carry_floats<128, 5>();
   if (D == 64 && nbt <= 3) return perf_carry_floats<64, 3>();
   if (D == 64 && nbt <= 5) return perf_carry_floats<64, 5>();
   if (D == 80 && nbt <= 3) return perf_carry_floats<80, 3>();
@@ -1004,9 +1482,9 @@ static int64_t perf_seg_len(int64_t T, int64_t nseg) {
   return ((chunks + nseg - 1) / nseg) * 64;
 }
 
-// avg_out comes from the 16-bit MFMA kernel only (16-bit data, d = 64, up to 80 features)
+// avg_out comes from the 16-bit MFMA kernels only (16-bit data, d = 64 or 128, up to 80 features)
 extern "C" int sea_performer_avg_supported(int64_t D, int64_t nb, int dtype) {
-  return (dtype == SEA_BF16 || dtype == SEA_F16) && D == 64 && nb > 0 && nb <= 80;
+  return (dtype == SEA_BF16 || dtype == SEA_F16) && (D == 64 || D == 128) && nb > 0 && nb <= 80;
 }
 
 extern "C" int sea_performer_plan(int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb, int dtype,

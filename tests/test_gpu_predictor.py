@@ -120,7 +120,8 @@ def test_module_hip_estimator_matches_torch_estimator():
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,H,T,D,nbf", [(1, 2, 256, 64, 8), (2, 3, 200, 64, 8), (1, 2, 130, 80, 8), (1, 2, 96, 128, 8),
-                                         (1, 1, 64, 64, 4), (1, 4, 1024, 64, 8), (1, 2, 333, 64, 8)])
+                                         (1, 1, 64, 64, 4), (1, 4, 1024, 64, 8), (1, 2, 333, 64, 8), (2, 2, 1000, 128, 8),
+                                         (1, 3, 161, 128, 8), (1, 1, 31, 128, 8)])
 def test_performer_value(ops, dtype, N, H, T, D, nbf):
     """Fused Performer kernel vs the torch restatement (perlin_attention/performer.py) evaluated in fp32, and vs
     the naive prefix-sum formula of the published algorithm."""
@@ -150,12 +151,12 @@ def test_performer_value(ops, dtype, N, H, T, D, nbf):
         torch.testing.assert_close(ctx, mine, atol=2e-4, rtol=2e-4)
     elif dtype == torch.float16:
         torch.testing.assert_close(ctx, ref, atol=4e-3, rtol=4e-3)
-        refh = ref.to(dtype).float()                      # d = 64: split-fp16 MFMA kernel, 2 x 11 significand bits
-        if D == 64:
+        refh = ref.to(dtype).float()                      # d = 64 / 128: split-fp16 MFMA kernels, 2 x 11 significand bits
+        if D in (64, 128):
             assert ((ctx - refh).abs() <= refh.abs() * 2.0 ** -10 + 2.0 ** -14).all()
     else:
         torch.testing.assert_close(ctx, ref, atol=3e-2, rtol=2e-2)
-        # bf16 data runs the split-bf16 MFMA kernel (D = 64): its result is the fp32 formula to ~2^-16 of the row's
+        # bf16 data runs the split-bf16 MFMA kernels (D = 64, 128): their result is the fp32 formula to ~2^-16 of the row's
         # magnitude (outputs are averages of O(1) values; an element that cancels to ~0 keeps that ABSOLUTE error),
         # i.e. after the final rounding almost every element equals bf16(ref) and none is further than one bf16
         # step plus 2^-13
@@ -349,14 +350,14 @@ def test_predictor_tail_select_bit_identical(ops, dtype, N, H, T, k):
     assert torch.equal(c2.bits, c3.bits) and torch.equal(c2.crow, c3.crow)
 
 
+@pytest.mark.parametrize("D", [64, 128])
 @pytest.mark.parametrize("N,H,T", [(1, 2, 256), (2, 3, 200), (1, 4, 1000)])
-def test_performer_emits_cumulative_average(ops, N, H, T):
+def test_performer_emits_cumulative_average(ops, N, H, T, D):
     """The bf16 Performer launch can also write cumsum(v)/(t+1) (step K's input): equals the cumavg kernel's values
     (fp32 accumulation on both sides, at most a bf16 rounding step apart) and leaves the main output untouched."""
     import math
     from sea_attention_amd.perlin_attention.performer import FastAttention
     torch.manual_seed(11)
-    D = 64
     fa = FastAttention(D, nb_features=int(D * math.log(D) / 8), causal=True, generalized_attention=True).to(DEV)
     q = (torch.randn(N, H, T, D, device=DEV) * D ** -0.5).bfloat16(); k = torch.randn(N, H, T, D, device=DEV).bfloat16()
     v = torch.randn(N, H, T, D, device=DEV).bfloat16(); pos = torch.randn(T, D, device=DEV).bfloat16()
@@ -374,7 +375,9 @@ def test_performer_emits_cumulative_average(ops, N, H, T):
 @pytest.mark.parametrize("dtype,N,H,T,D,nbf", [
     (torch.bfloat16, 1, 4, 1024, 64, 8),     # split-bf16 kernel, plan cuts (4 pairs)
     (torch.float16, 1, 3, 777, 64, 8),       # ragged last segment / last chunk
-    (torch.bfloat16, 1, 4, 1024, 128, 8),    # fp32-MFMA kernel, 32-row chunks
+    (torch.bfloat16, 1, 4, 1024, 128, 8),    # wide split-bf16 kernel, 32-row chunks
+    (torch.float16, 1, 2, 1111, 128, 8),
+    (torch.float32, 1, 2, 600, 128, 8),      # fp32-MFMA kernel, 32-row chunks
     (torch.bfloat16, 2, 2, 640, 80, 8),
     (torch.float32, 1, 2, 900, 64, 8),
 ])
@@ -416,7 +419,8 @@ def test_performer_sequence_parallel_equals_sequential(ops, dtype, N, H, T, D, n
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("dtype,N,H,T,D", [(torch.bfloat16, 2, 4, 448, 64), (torch.float16, 1, 4, 300, 64)])
+@pytest.mark.parametrize("dtype,N,H,T,D", [(torch.bfloat16, 2, 4, 448, 64), (torch.float16, 1, 4, 300, 64),
+                                           (torch.bfloat16, 1, 3, 448, 128), (torch.float16, 2, 2, 300, 128)])
 def test_performer_step_continues_the_sequence(ops, dtype, N, H, T, D):
     """`sea_performer_causal_step` (kv-cache decoding): feeding the rows in pieces with the carried state image gives
     the rows -- and the cumulative average of v -- of the one-pass kernel.  Pieces that end on 64-row chunk boundaries
