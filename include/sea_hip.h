@@ -308,11 +308,11 @@ int sea_predictor_mlp(const void* x, int dtype, int64_t N, int64_t H, int64_t T,
  * Replaces performer_pytorch.FastAttention(causal, generalized) as called at attention.py:556-572 plus the
  * concatenations at :506-510 and :577-590.  q,k,v (N,H,T,D) of `dtype` (element strides [n,h,t]), pos (>=T, D)
  * with row stride pos_stride, proj (nb, D) FP32.  out (N,H,T,3D) contiguous of `dtype` = [ctx_pos | ctx_v | v].
- * Supported: D in {64,80,128}, nb <= 80 (48 for D=80 with 64-row chunks).
- * 16-bit data with D = 64 runs on 16-bit MFMA with split (hi+lo) operands; that kernel can also emit
- * avg_out (N,H,T,D) = cumsum_t(v)/(t+1), the input of the mix step (attention.py:1220-1222) -- pass NULL otherwise.
- * 16-bit data with D in {80,128}: fp32 MFMA, except the feature-map product, which is exact on the 16-bit MFMA
- * (q, k and the projection are 16-bit values).  FP32 data: fp32 MFMA throughout. */
+ * Supported: D in {64,80,128}, nb <= 80.
+ * 16-bit data runs on 16-bit MFMA with split (hi+lo) operands (64-row chunks at D = 64, 32-row chunks
+ * and two column blocks per wave at D = 80 / 128); those kernels can also emit avg_out (N,H,T,D) = cumsum_t(v)/(t+1),
+ * the input of the mix step (attention.py:1220-1222) -- pass NULL otherwise (sea_performer_avg_supported says when it
+ * may be non-NULL).  FP32 data: fp32 MFMA throughout. */
 int sea_performer_causal(const void* q, const void* k, const void* v, const void* pos, int dtype,
                          const float* proj, int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb,
                          const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,

@@ -905,19 +905,24 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   }
 }
 
-// ---- wide heads (D = 128): the same algorithm with the chunk cut to C = 32 rows so that the LDS images fit (the D = 64
-// plan scaled up is 208 KB), two 16-column blocks of [pos | v] per wave (E / 16 = 16 blocks over 8 waves: each wave keeps
-// two state tiles S), 16 staging chunks per row, and a V image of 512-byte rows whose chunk swizzle spreads the eight
-// rows of a transposing read over the eight 8-bank groups.  Everything else -- split operands, transposed products,
-// transposing reads, the cumulative average on the matrix cores, segments, state images -- is the D = 64 kernel's.
+// ---- wide heads (D = 80, 128): the same algorithm with the chunk cut to C = 32 rows so that the LDS images fit (the
+// D = 64 plan scaled up is 208 KB), up to two 16-column blocks of [pos | v] per wave (E / 16 = 16 or 10 blocks over 8
+// waves: a wave keeps two state tiles S; at D = 80 only waves 0 and 1 own a second block), D / 8 staging chunks per row
+// on the first C * D / 8 threads, the head dimension zero-padded to whole 32-wide k-steps (D = 80: 96) in the operand
+// images of the feature-map product, and a V image of 512-byte rows whose chunk swizzle spreads the eight rows of a
+// transposing read over the eight 8-bank groups.  Everything else -- split operands, transposed products, transposing
+// reads, the cumulative average on the matrix cores, segments, state images -- is the D = 64 kernel's.
 template <typename T, int D, int C, int NBT, bool STATE_ONLY>
 __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
   constexpr int NW = 8, NTH = 512, E = 2 * D, CPR = D / 8;
-  static_assert(C * CPR == NTH && (E / 16) % NW == 0 && C % 16 == 0, "one staging chunk per thread, whole column blocks per wave");
+  constexpr int DP = (D + 31) / 32 * 32, KC = DP / 8;    // head dimension padded to whole k-steps, its 8-element chunks
+  constexpr int EL = 256;                                // elements per row of the V image (512 bytes: room for the swizzle)
+  constexpr int STG = C * CPR;                           // threads that stage one 16-byte piece of each tensor
+  static_assert(STG <= NTH && D % 16 == 0 && E <= EL && C % 16 == 0 && C <= 32, "staging pieces fit the block, whole column blocks");
   constexpr int NBP = NBT * 16;
   constexpr int KF = (NBT + 1) / 2;            // 32-wide k-steps over the (padded) features
   constexpr int FP = KF * 32;                  // padded feature count
-  constexpr int RB = C / 16, EB = E / 16, JB = EB / NW, NPART = 8;
+  constexpr int RB = C / 16, EB = E / 16, JB = (EB + NW - 1) / NW, NPART = 8;
   // LDS row strides picked with a bank model of the two access patterns (64 banks x 4 B; b128 row reads are served in
   // 4 lane groups of 16, transposing b64 reads in 2 of 32): 160 / 224 B rows make the operand row reads conflict-free
   // (4 cycles per wave instruction; the first version's 144 B rows: 8), 192 B rows halve the conflicts of the
@@ -927,11 +932,11 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
   constexpr int LDA = C + 16;                  // A rows: row reads only
   constexpr int DSL = RB + NPART;              // denominator partial slots per row
   extern __shared__ __attribute__((aligned(16))) char smem_b[];
-  unsigned short* sW = reinterpret_cast<unsigned short*>(smem_b);   // [D/8][NBP][8]   projection, k-chunked
-  unsigned short* sQ = sW + (D / 8) * NBP * 8;                      // [D/8][C][8]
-  unsigned short* sK = sQ + (D / 8) * C * 8;                        // [D/8][C][8]
-  unsigned short* sV = sK + (D / 8) * C * 8;                        // [C][E] 256-byte rows, chunk-swizzled
-  unsigned short* sQh = sV + C * E;                                 // [C][LDQ2]
+  unsigned short* sW = reinterpret_cast<unsigned short*>(smem_b);   // [KC][NBP][8]  projection, k-chunked (zero padded)
+  unsigned short* sQ = sW + KC * NBP * 8;                           // [KC][C][8]    (chunks >= D / 8: zero)
+  unsigned short* sK = sQ + KC * C * 8;                             // [KC][C][8]
+  unsigned short* sV = sK + KC * C * 8;                             // [C][EL] 512-byte rows, chunk-swizzled
+  unsigned short* sQh = sV + C * EL;                                // [C][LDQ2]
   unsigned short* sQl = sQh + C * LDQ2;
   unsigned short* sKh = sQl + C * LDQ2;                             // [C][LDK2]
   unsigned short* sKl = sKh + C * LDK2;
@@ -963,10 +968,12 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
   const float cnorm = powf((float)D, -0.25f);
 
   // projection (its values are bf16-exact: the reference casts the buffer to the data dtype), zero padded rows
-  for (int i = tid; i < (D / 8) * NBP * 8; i += NTH) {
+  for (int i = tid; i < KC * NBP * 8; i += NTH) {
     const int j = i & 7, f = (i >> 3) % NBP, kc = (i >> 3) / NBP;
-    sW[i] = f < p.nb ? S16<T>::bits(p.W[f * D + kc * 8 + j]) : (unsigned short)0;
+    sW[i] = (f < p.nb && kc < CPR) ? S16<T>::bits(p.W[f * D + kc * 8 + j]) : (unsigned short)0;
   }
+  if constexpr (KC > CPR)                                  // padded k-chunks of the q / k images: zero, never written again
+    for (int i = tid; i < (KC - CPR) * C * 8; i += NTH) sQ[CPR * C * 8 + i] = sK[CPR * C * 8 + i] = 0;
   // phi and A images: padded features / upper-triangular tiles are written once (zero) and never again
   for (int i = tid; i < 2 * C * LDQ2 + 2 * C * LDK2 + 2 * C * LDA; i += NTH) sQh[i] = 0;
   for (int i = tid; i < C * DSL; i += NTH) sDenP[i] = 0.f;   // slots of key blocks above the diagonal stay zero
@@ -1030,7 +1037,7 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
   bu4 pq, pk, pv, pp;
   auto issue_loads = [&](int t0n) {
     const int t = t0n + sr;
-    const bool ok = t < t_end;
+    const bool ok = t < t_end && (STG == NTH || tid < STG);
     pq = __builtin_amdgcn_raw_buffer_load_b128(rq, (ok && !STATE_ONLY) ? (int)((t * p.qs[2] + sc * 8) * 2) : (int)OOB, 0, 0);
     pk = __builtin_amdgcn_raw_buffer_load_b128(rk, ok ? (int)((t * p.ks[2] + sc * 8) * 2) : (int)OOB, 0, 0);
     pv = __builtin_amdgcn_raw_buffer_load_b128(rv, ok ? (int)((t * p.vs[2] + sc * 8) * 2) : (int)OOB, 0, 0);
@@ -1046,19 +1053,15 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
       const bu4 v = *reinterpret_cast<const bu4*>(sO + row * LDO + ch * 8);
       __builtin_amdgcn_raw_buffer_store_b128(v, ro, row < rowsp ? ((t0p + row) * (3 * D) + ch * 8) * 2 : (int)OOB, 0, 0);
     }
-    if (want_avg) {                                        // C * D / 8 = 512 pieces: one per thread
-      const int row = tid / (D / 8), ch = tid - row * (D / 8);
-      const bu4 v = *reinterpret_cast<const bu4*>(sAvg + row * LDG + ch * 8);
-      __builtin_amdgcn_raw_buffer_store_b128(v, rg, row < rowsp ? ((t0p + row) * D + ch * 8) * 2 : (int)OOB, 0, 0);
+    if (want_avg && (STG == NTH || tid < STG)) {           // C * D / 8 pieces: one per staging thread
+      const bu4 v = *reinterpret_cast<const bu4*>(sAvg + sr * LDG + sc * 8);
+      __builtin_amdgcn_raw_buffer_store_b128(v, rg, sr < rowsp ? ((t0p + sr) * D + sc * 8) * 2 : (int)OOB, 0, 0);
     }
   };
-  // swizzled chunk position inside a 256-byte row of the V image (conflict-free transposing reads)
+  // swizzled chunk position inside a row of the V image (conflict-free transposing reads):
   // 512-byte rows (32 chunks): rows {r..r+3, r+8..r+11} of one transposing read get the eight values of
   // (row & 3) | (bit 3 of row) << 2 XOR-ed into bits 1..3 of the chunk index -> eight disjoint 8-bank groups
-  auto vchunk = [](int row, int ch) {
-    if (E == 128) return ch ^ (((row & 3) << 2) | ((row >> 2) & 3));
-    return ch ^ ((((row & 3) | (((row >> 3) & 1) << 2))) << 1);
-  };
+  auto vchunk = [](int row, int ch) { return ch ^ ((((row & 3) | (((row >> 3) & 1) << 2))) << 1); };
 
   // cumulative average of v (step K's input) on the waves that own the v columns: prefix sum over the chunk rows =
   // tril(ones) . V on the matrix cores (1.0 and v are exact in bf16, fp32 accumulation) + the running column sum
@@ -1081,10 +1084,12 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
     const int rows = min(C, t_end - t0);
     // ---- (a) staging ---------------------------------------------------------------------------------
     if (!STATE_ONLY) __builtin_amdgcn_raw_buffer_store_b128(pv, ro, sr < rows ? ((t0 + sr) * (3 * D) + 2 * D + sc * 8) * 2 : (int)OOB, 0, 0);
-    *reinterpret_cast<bu4*>(sQ + (sc * C + sr) * 8) = pq;
-    *reinterpret_cast<bu4*>(sK + (sc * C + sr) * 8) = pk;
-    *reinterpret_cast<bu4*>(sV + sr * E + vchunk(sr, sc) * 8) = pp;
-    *reinterpret_cast<bu4*>(sV + sr * E + vchunk(sr, D / 8 + sc) * 8) = pv;
+    if (STG == NTH || tid < STG) {
+      *reinterpret_cast<bu4*>(sQ + (sc * C + sr) * 8) = pq;
+      *reinterpret_cast<bu4*>(sK + (sc * C + sr) * 8) = pk;
+      *reinterpret_cast<bu4*>(sV + sr * EL + vchunk(sr, sc) * 8) = pp;
+      *reinterpret_cast<bu4*>(sV + sr * EL + vchunk(sr, CPR + sc) * 8) = pv;
+    }
     if (!STATE_ONLY && t0 > t_begin) flush_out(t0 - C, C);                     // (block-uniform)
     issue_loads(t0 + C);                                                      // rows beyond T come back as zeros
     __syncthreads();
@@ -1097,7 +1102,7 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
 #pragma unroll
       for (int fb = 0; fb < NBT; ++fb) acc[fb] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int ks = 0; ks < D / 32; ++ks) {
+      for (int ks = 0; ks < DP / 32; ++ks) {
         const uint4 bx = *reinterpret_cast<const uint4*>(src + ((4 * ks + lg) * C + rb * 16 + li) * 8);
 #pragma unroll
         for (int fb = 0; fb < NBT; ++fb) {
@@ -1228,6 +1233,7 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
 #pragma unroll
     for (int jq = 0; jq < JB; ++jq) {
       const int jb = wv + jq * NW, e0 = jb * 16;
+      if (EB % NW != 0 && jb >= EB) break;                 // wave-uniform: no such column block
       // V fragments (B operand, k = chunk row): rows 32ks + 8lg + {0..3 | 4..7}, columns e0 .. e0+15
       uint4 vf[C / 32];
       {
@@ -1235,8 +1241,8 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
 #pragma unroll
         for (int ks = 0; ks < C / 32; ++ks) {
           const int r0 = ks * 32 + lg * 8;
-          const uint2 a = lds_tr(sV + (r0 + q) * E + vchunk(r0 + q, 2 * jb + (pp_ >> 1)) * 8 + 4 * (pp_ & 1));
-          const uint2 b = lds_tr(sV + (r0 + 4 + q) * E + vchunk(r0 + 4 + q, 2 * jb + (pp_ >> 1)) * 8 + 4 * (pp_ & 1));
+          const uint2 a = lds_tr(sV + (r0 + q) * EL + vchunk(r0 + q, 2 * jb + (pp_ >> 1)) * 8 + 4 * (pp_ & 1));
+          const uint2 b = lds_tr(sV + (r0 + 4 + q) * EL + vchunk(r0 + 4 + q, 2 * jb + (pp_ >> 1)) * 8 + 4 * (pp_ & 1));
           vf[ks] = cat8(a, b);
         }
       }
@@ -1416,7 +1422,8 @@ constexpr int64_t perf_bf16_carry_floats() { return (int64_t)NBT * 4 * 512 + ((N
 template <typename T, int D, int C, int NBT>
 static int launch_perf_bf16w(const PerfParams& p, hipStream_t s) {
   constexpr int NTH = 512, E = 2 * D, NBP = NBT * 16, FP = ((NBT + 1) / 2) * 32, LDQ2 = FP + 16, LDK2 = (FP == 64) ? 96 : FP + 8, LDA = C + 16;
-  constexpr size_t lds = 2 * ((D / 8) * NBP * 8 + 2 * (D / 8) * C * 8 + C * E + 2 * C * LDQ2 + 2 * C * LDK2 + 2 * C * LDA + C * (E + 8) + C * (D + 8)) +
+  constexpr int KC = (D + 31) / 32 * 4, EL = 256;
+  constexpr size_t lds = 2 * (KC * NBP * 8 + 2 * KC * C * 8 + C * EL + 2 * C * LDQ2 + 2 * C * LDK2 + 2 * C * LDA + C * (E + 8) + C * (D + 8)) +
                          sizeof(float) * (FP + C + C * (C / 16 + 8) + 8 * FP + C);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool configured = false;
@@ -1433,7 +1440,7 @@ static int launch_perf_bf16w(const PerfParams& p, hipStream_t s) {
 }
 
 template <int D, int NBT>
-constexpr int64_t perf_bf16w_carry_floats() { return (int64_t)(2 * D / 16 / 8) * NBT * 4 * 512 + ((NBT + 1) / 2) * 32 + (2 * D / 16 / 8) * 512; }
+constexpr int64_t perf_bf16w_carry_floats() { return (int64_t)((2 * D / 16 + 7) / 8) * NBT * 4 * 512 + ((NBT + 1) / 2) * 32 + ((2 * D / 16 + 7) / 8) * 512; }
 
 template <typename T>
 static int dispatch_perf(const PerfParams& p, int D, int nbt, hipStream_t s) {
@@ -1442,6 +1449,8 @@ static int dispatch_perf(const PerfParams& p, int D, int nbt, hipStream_t s) {
       if (nbt <= 3) return launch_perf_bf16<T, 3>(p, s);
       if (nbt <= 5) return launch_perf_bf16<T, 5>(p, s);
     }
+    if (D == 80 && nbt <= 3) return launch_perf_bf16w<T, 80, 32, 3>(p, s);
+    if (D == 80 && nbt <= 5) return launch_perf_bf16w<T, 80, 32, 5>(p, s);
     if (D == 128 && nbt <= 5) return launch_perf_bf16w<T, 128, 32, 5>(p, s);
   }
   if (D == 64 && nbt <= 3) return launch_perf<T, 64, 3, 64>(p, s);
@@ -1467,6 +1476,8 @@ static int64_t perf_carry_floats_for(int dtype, int D, int nbt) {
     if (nbt <= 3) return perf_bf16_carry_floats<3>();
     if (nbt <= 5) return perf_bf16_carry_floats<5>();
   }
+  if (dtype != SEA_F32 && D == 80 && nbt <= 3) return perf_bf16w_carry_floats<80, 3>();
+  if (dtype != SEA_F32 && D == 80 && nbt <= 5) return perf_bf16w_carry_floats<80, 5>();
   if (dtype != SEA_F32 && D == 128 && nbt <= 5) return perf_bf16w_carry_floats<128, 5>();
   if (D == 64 && nbt <= 3) return perf_carry_floats<64, 3>();
   if (D == 64 && nbt <= 5) return perf_carry_floats<64, 5>();
@@ -1482,9 +1493,9 @@ static int64_t perf_seg_len(int64_t T, int64_t nseg) {
   return ((chunks + nseg - 1) / nseg) * 64;
 }
 
-// avg_out comes from the 16-bit MFMA kernels only (16-bit data, d = 64 or 128, up to 80 features)
+// avg_out comes from the 16-bit MFMA kernels only (16-bit data, d = 64, 80 or 128, up to 80 features)
 extern "C" int sea_performer_avg_supported(int64_t D, int64_t nb, int dtype) {
-  return (dtype == SEA_BF16 || dtype == SEA_F16) && (D == 64 || D == 128) && nb > 0 && nb <= 80;
+  return (dtype == SEA_BF16 || dtype == SEA_F16) && (D == 64 || D == 80 || D == 128) && nb > 0 && nb <= 80;
 }
 
 extern "C" int sea_performer_plan(int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb, int dtype,

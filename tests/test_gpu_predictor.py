@@ -121,7 +121,7 @@ def test_module_hip_estimator_matches_torch_estimator():
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,H,T,D,nbf", [(1, 2, 256, 64, 8), (2, 3, 200, 64, 8), (1, 2, 130, 80, 8), (1, 2, 96, 128, 8),
                                          (1, 1, 64, 64, 4), (1, 4, 1024, 64, 8), (1, 2, 333, 64, 8), (2, 2, 1000, 128, 8),
-                                         (1, 3, 161, 128, 8), (1, 1, 31, 128, 8)])
+                                         (1, 3, 161, 128, 8), (1, 1, 31, 128, 8), (2, 3, 1000, 80, 8), (1, 2, 95, 80, 6)])
 def test_performer_value(ops, dtype, N, H, T, D, nbf):
     """Fused Performer kernel vs the torch restatement (perlin_attention/performer.py) evaluated in fp32, and vs
     the naive prefix-sum formula of the published algorithm."""
@@ -151,12 +151,12 @@ def test_performer_value(ops, dtype, N, H, T, D, nbf):
         torch.testing.assert_close(ctx, mine, atol=2e-4, rtol=2e-4)
     elif dtype == torch.float16:
         torch.testing.assert_close(ctx, ref, atol=4e-3, rtol=4e-3)
-        refh = ref.to(dtype).float()                      # d = 64 / 128: split-fp16 MFMA kernels, 2 x 11 significand bits
-        if D in (64, 128):
+        refh = ref.to(dtype).float()                      # split-fp16 MFMA kernels, 2 x 11 significand bits
+        if D in (64, 80, 128):
             assert ((ctx - refh).abs() <= refh.abs() * 2.0 ** -10 + 2.0 ** -14).all()
     else:
         torch.testing.assert_close(ctx, ref, atol=3e-2, rtol=2e-2)
-        # bf16 data runs the split-bf16 MFMA kernels (D = 64, 128): their result is the fp32 formula to ~2^-16 of the row's
+        # bf16 data runs the split-bf16 MFMA kernels (D = 64, 80, 128): their result is the fp32 formula to ~2^-16 of the row's
         # magnitude (outputs are averages of O(1) values; an element that cancels to ~0 keeps that ABSOLUTE error),
         # i.e. after the final rounding almost every element equals bf16(ref) and none is further than one bf16
         # step plus 2^-13
@@ -350,7 +350,7 @@ def test_predictor_tail_select_bit_identical(ops, dtype, N, H, T, k):
     assert torch.equal(c2.bits, c3.bits) and torch.equal(c2.crow, c3.crow)
 
 
-@pytest.mark.parametrize("D", [64, 128])
+@pytest.mark.parametrize("D", [64, 80, 128])
 @pytest.mark.parametrize("N,H,T", [(1, 2, 256), (2, 3, 200), (1, 4, 1000)])
 def test_performer_emits_cumulative_average(ops, N, H, T, D):
     """The bf16 Performer launch can also write cumsum(v)/(t+1) (step K's input): equals the cumavg kernel's values
@@ -378,7 +378,8 @@ def test_performer_emits_cumulative_average(ops, N, H, T, D):
     (torch.bfloat16, 1, 4, 1024, 128, 8),    # wide split-bf16 kernel, 32-row chunks
     (torch.float16, 1, 2, 1111, 128, 8),
     (torch.float32, 1, 2, 600, 128, 8),      # fp32-MFMA kernel, 32-row chunks
-    (torch.bfloat16, 2, 2, 640, 80, 8),
+    (torch.bfloat16, 2, 2, 640, 80, 8),      # wide kernel, padded head dimension, ragged column blocks
+    (torch.float16, 1, 3, 1500, 80, 8),
     (torch.float32, 1, 2, 900, 64, 8),
 ])
 def test_performer_sequence_parallel_equals_sequential(ops, dtype, N, H, T, D, nbf):
@@ -420,7 +421,8 @@ def test_performer_sequence_parallel_equals_sequential(ops, dtype, N, H, T, D, n
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("dtype,N,H,T,D", [(torch.bfloat16, 2, 4, 448, 64), (torch.float16, 1, 4, 300, 64),
-                                           (torch.bfloat16, 1, 3, 448, 128), (torch.float16, 2, 2, 300, 128)])
+                                           (torch.bfloat16, 1, 3, 448, 128), (torch.float16, 2, 2, 300, 128),
+                                           (torch.bfloat16, 1, 3, 448, 80), (torch.float16, 1, 2, 300, 80)])
 def test_performer_step_continues_the_sequence(ops, dtype, N, H, T, D):
     """`sea_performer_causal_step` (kv-cache decoding): feeding the rows in pieces with the carried state image gives
     the rows -- and the cumulative average of v -- of the one-pass kernel.  Pieces that end on 64-row chunk boundaries
