@@ -174,23 +174,33 @@ def _causal_conv_ref(x, weight, bias, k, dil, pad_w, relu):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dil", [2, 1, 3])
 @pytest.mark.parametrize("N,Cin,Cout,T,W", [(2, 64, 64, 40, 64), (1, 24, 24, 33, 16), (1, 80, 80, 20, 64), (1, 64, 64, 9, 32),
-                                            (1, 32, 48, 17, 128)])
-def test_causal_conv_c8(ops, dtype, N, Cin, Cout, T, W):
+                                            (1, 32, 48, 17, 128), (1, 16, 32, 12, 40)])
+def test_causal_conv_c8(ops, dtype, N, Cin, Cout, T, W, dil):
     g = torch.Generator().manual_seed(3)
     x = torch.randn((N, Cin, T, W), generator=g).to(dtype)
     wt = (torch.randn((Cout, Cin, 5, 3), generator=g) * (Cin * 9) ** -0.5).to(dtype)
     b = (torch.randn(Cout, generator=g) * 0.1).to(dtype)
     for relu in (True, False):
-        ref = _causal_conv_ref(x, wt, b, 3, 2, 2, relu)
+        ref = _causal_conv_ref(x, wt, b, 3, dil, dil, relu)
         xd = ops.to_c8(x.to(DEV))
-        y = ops.causal_conv_c8(xd, wt.to(DEV), b.to(DEV), 3, 2, 2, relu=relu)
+        y = ops.causal_conv_c8(xd, wt.to(DEV), b.to(DEV), 3, dil, dil, relu=relu)
         assert tuple(y.shape) == (N, T, Cout // 8, W, 8) and y.is_contiguous()
         torch.testing.assert_close(ops.from_c8(y).float().cpu(), ref, atol=2e-2, rtol=2e-2)
+    # a one-hot image: every output pixel is a single weight (+ bias), exact in 16 bits -> tap positions checked bitwise
+    xo = torch.zeros_like(x); xo[0, Cin // 2, T // 2, W // 3] = 1.0
+    ref = _causal_conv_ref(xo, wt, b.float().to(dtype), 3, dil, dil, False).to(dtype)
+    y = ops.from_c8(ops.causal_conv_c8(ops.to_c8(xo.to(DEV)), wt.to(DEV), b.to(DEV), 3, dil, dil, relu=False)).cpu()
+    assert torch.equal(y, ref)
+    xo = torch.zeros_like(x); xo[0, 0, T - 1, 0] = 1.0; xo[0, Cin - 1, 0, W - 1] = -2.0           # the row ends
+    ref = _causal_conv_ref(xo, wt, b.float().to(dtype), 3, dil, dil, False).to(dtype)
+    y = ops.from_c8(ops.causal_conv_c8(ops.to_c8(xo.to(DEV)), wt.to(DEV), b.to(DEV), 3, dil, dil, relu=False)).cpu()
+    assert torch.equal(y, ref)
     # causality along T: future rows do not leak
     x2 = x.clone(); x2[:, :, T // 2:] += 50
-    y1 = ops.causal_conv_c8(ops.to_c8(x.to(DEV)), wt.to(DEV), b.to(DEV), 3, 2, 2)
-    y2 = ops.causal_conv_c8(ops.to_c8(x2.to(DEV)), wt.to(DEV), b.to(DEV), 3, 2, 2)
+    y1 = ops.causal_conv_c8(ops.to_c8(x.to(DEV)), wt.to(DEV), b.to(DEV), 3, dil, dil)
+    y2 = ops.causal_conv_c8(ops.to_c8(x2.to(DEV)), wt.to(DEV), b.to(DEV), 3, dil, dil)
     assert torch.equal(y1[:, :T // 2], y2[:, :T // 2])
     # 1x1 kernel (no taps to shift): plain channel GEMM per pixel
     w1 = (torch.randn((Cout, Cin, 1, 1), generator=g) * Cin ** -0.5).to(dtype)
