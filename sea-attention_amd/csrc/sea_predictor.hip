@@ -273,12 +273,14 @@ __global__ __launch_bounds__(256) void predictor_tail_mfma_kernel(TailParams p) 
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int LDZ = p.W4 + 3;                     // z row: W4 pixels, [W4] = bias, [W4+1] = 0 (odd stride: no bank aliasing)
   float* s_z = reinterpret_cast<float*>(smem);  // HP x LDZ
+  uint32_t* s_tab = reinterpret_cast<uint32_t*>(s_z + ((p.H + 15) / 16) * 16 * LDZ);   // per-pixel constants [3][64 E]
   const int row = blockIdx.x;
   const int n = row / p.T, t = row - n * p.T;
   tail_z_tile<T>(p, s_z, n, t);
-  TailRow<T, E> tr;
-  tr.init(p, lane);
+  tail_consts_fill<T>(p, s_tab, 64 * E);
   __syncthreads();
+  TailRow<T, E> tr;
+  tr.load(s_tab, lane);
   for (int h = wv; h < p.H; h += 4) {
     float a[E];
     tr.head(p, s_z + h * LDZ, lane, (((int64_t)n * p.H + h) * p.T + t) * p.T_M, a);
@@ -471,8 +473,8 @@ template <typename T>
 static int launch_tail_mfma(const TailParams& p, dim3 grid, hipStream_t s) {
   const int E = (p.T_M + 63) / 64;
   const int HP = ((p.H + 15) / 16) * 16;
-  const size_t lds = (size_t)HP * (p.W4 + 3) * sizeof(float);
-  if (lds > 64 * 1024) return SEA_EUNSUPPORTED;
+  const size_t lds = (size_t)HP * (p.W4 + 3) * sizeof(float) + (size_t)TAIL_TAB_ROWS * 64 * (E == 5 ? 6 : E == 7 ? 8 : E) * sizeof(uint32_t);
+  if (lds > 64 * 1024 || p.W4 + 1 >= 1024 || p.W4 * p.UP + 2 > 2 * p.T_M) return SEA_EUNSUPPORTED;   // 10-bit taps, windows of <= 3 of them
 #define SEA_TAILM(EE) hipLaunchKernelGGL((predictor_tail_mfma_kernel<T, EE>), grid, dim3(256), lds, s, p)
   switch (E) {
     case 1: SEA_TAILM(1); break; case 2: SEA_TAILM(2); break; case 3: SEA_TAILM(3); break; case 4: SEA_TAILM(4); break;

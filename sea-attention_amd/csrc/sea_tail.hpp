@@ -126,36 +126,63 @@ __device__ __forceinline__ void tail_z_tile(const TailParams& p, float* s_z, int
   for (int h = threadIdx.x; h < HP; h += 256) { s_z[h * LDZ + p.W4] = h < p.H ? bF[h] : 0.f; s_z[h * LDZ + p.W4 + 1] = 0.f; }
 }
 
-// ---- per-lane constants of the area-resize / LayerNorm stage + one head's row -----------------------------------
+// ---- per-pixel constants of the area-resize / LayerNorm stage ----------------------------------------------------
+// They depend on the output pixel j only (not on the row, the head or the wave), and every wave needs all T_M of them:
+// the workgroup computes each ONCE (thread <-> pixel) into an LDS table and a lane then reads its E pixels back
+// (the first version recomputed them per lane in every wave: ~300 of the ~2700 vector instructions of a wave of the
+// fused tail + selection kernel, which is vector-issue bound -- profiles/r02d_pmc_per_kernel.txt).
+// Table: [3][TMP] words, TMP = 64 * E:  [0] taps packed 3 x 10 bits (index into the z row: pixel, W4 = bias i.e. the
+// zero-padded border, W4+1 = unused tap) + the tap count (1..3, 0 beyond T_M) in bits 30..31;  [1] gamma;  [2] beta.
+constexpr int TAIL_TAB_ROWS = 3;
+template <typename T>
+__device__ __forceinline__ void tail_consts_fill(const TailParams& p, uint32_t* s_tab, int TMP) {
+  const int Wp = p.W4 * p.UP + 2;
+  const T* gam = reinterpret_cast<const T*>(p.gamma);
+  const T* bet = reinterpret_cast<const T*>(p.beta);
+  const bool up_pow2 = (p.UP & (p.UP - 1)) == 0;            // block-uniform; x4 in every configuration the reference builds
+  const int up_sh = __ffs(p.UP) - 1;
+  for (int j = threadIdx.x; j < TMP; j += blockDim.x) {
+    uint32_t pk = (uint32_t)(p.W4 + 1) * 0x100401u;         // three unused taps, count 0
+    float g = 0.f, be = 0.f;
+    if (j < p.T_M) {
+      g = Elem<T>::to_f(gam[j]); be = Elem<T>::to_f(bet[j]);
+      // adaptive-average-pool window of output pixel j over the Wp padded pixels (ATen's float formula)
+      const int xs = (int)floorf((float)(j * Wp) / (float)p.T_M);
+      const int xe = (int)ceilf((float)((j + 1) * Wp) / (float)p.T_M);
+      pk = (uint32_t)(xe - xs) << 30;                       // launcher: Wp <= 3 * T_M, so 1..3 taps
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        const int x = xs + k;
+        int sidx = p.W4 + 1;
+        // source pixel of tap x: (x - 1) / UP (a shift for the power-of-two factors)
+        if (x < xe) sidx = (x == 0 || x == Wp - 1) ? p.W4 : (up_pow2 ? ((x - 1) >> up_sh) : (x - 1) / p.UP);
+        pk |= (uint32_t)sidx << (10 * k);
+      }
+    }
+    s_tab[j] = pk;
+    s_tab[TMP + j] = __float_as_uint(g);
+    s_tab[2 * TMP + j] = __float_as_uint(be);
+  }
+}
+
+// ---- a lane's constants + one head's row --------------------------------------------------------------------------
 template <typename T, int E>
 struct TailRow {
   float g[E], be[E], rcnt[E];
   int src[E][3];   // index into the z row: pixel, W4 (bias: zero-padded border) or W4+1 (unused tap)
 
-  __device__ __forceinline__ void init(const TailParams& p, int lane) {
-    const int Wp = p.W4 * p.UP + 2;
-    const T* gam = reinterpret_cast<const T*>(p.gamma);
-    const T* bet = reinterpret_cast<const T*>(p.beta);
+  // after the barrier that publishes tail_consts_fill's table
+  __device__ __forceinline__ void load(const uint32_t* s_tab, int lane) {
+    constexpr int TMP = 64 * E;
 #pragma unroll
     for (int e = 0; e < E; ++e) {
-      const int j = lane * E + e;
-      g[e] = 0.f; be[e] = 0.f; rcnt[e] = 0.f;
-      src[e][0] = src[e][1] = src[e][2] = p.W4 + 1;
-      if (j < p.T_M) {
-        g[e] = Elem<T>::to_f(gam[j]); be[e] = Elem<T>::to_f(bet[j]);
-        const int xs = (int)floorf((float)(j * Wp) / (float)p.T_M);
-        const int xe = (int)ceilf((float)((j + 1) * Wp) / (float)p.T_M);
-        rcnt[e] = 1.0f / (float)(xe - xs);
-        // source pixel of tap x: (x - 1) / UP; UP is a power of two in every configuration the reference builds
-        // (x4), so the 12 runtime integer divisions per lane (~20 VALU each) become shifts
-        const bool up_pow2 = (p.UP & (p.UP - 1)) == 0;          // block-uniform
-        const int up_sh = __ffs(p.UP) - 1;
+      const uint32_t pk = s_tab[lane * E + e];
+      g[e] = __uint_as_float(s_tab[TMP + lane * E + e]);
+      be[e] = __uint_as_float(s_tab[2 * TMP + lane * E + e]);
 #pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const int x = xs + k;
-          if (x < xe) src[e][k] = (x == 0 || x == Wp - 1) ? p.W4 : (up_pow2 ? ((x - 1) >> up_sh) : (x - 1) / p.UP);
-        }
-      }
+      for (int k = 0; k < 3; ++k) src[e][k] = (int)__builtin_amdgcn_ubfe(pk, 10 * k, 10);
+      const uint32_t cnt = pk >> 30;                         // 1 / cnt, as the division gives it
+      rcnt[e] = cnt == 1 ? 1.0f : cnt == 2 ? 0.5f : cnt == 3 ? (1.0f / 3.0f) : 0.f;
     }
   }
 

@@ -208,12 +208,13 @@ __device__ inline long long block_excl_scan64(long long v, long long* s_wave /*[
 // Everything after the keys of the row are in registers: threshold search, bit mask, per-head entry counts.
 // Shared by topk_select_kernel (keys loaded from the probability map) and predictor_tail_select_kernel (keys
 // produced in registers by the predictor tail).  `base` = the row's probabilities in memory (slow path only).
-template <typename T, int EPT, bool FROM_MASK, bool FULL>
+// HMAX: bound on p.H (sizes the per-head counters; the fused kernel's 64 keeps five workgroups per CU with its tables).
+template <typename T, int EPT, bool FROM_MASK, bool FULL, int HMAX = 1024>
 __device__ __forceinline__ void select_body(const TopkParams& p, uint32_t (&key)[EPT], unsigned long long sel, int n, int t,
                                             int row, const T* base) {
   constexpr int R = EPT / 4;  // chunk rounds
   __shared__ int s_hist[TK_MAX_BINS + 1];          // +1: dump bin for unused register slots
-  __shared__ int s_head[1024];
+  __shared__ int s_head[HMAX];
   __shared__ int s_wave[TK_WAVES];
   __shared__ uint32_t s_red[2 * TK_WAVES];
   __shared__ int s_bcast[4];
@@ -460,11 +461,13 @@ __global__ __launch_bounds__(TK_THREADS) void predictor_tail_select_kernel(TailP
 #ifdef SEA_STAMP
   unsigned long long _tprev = __builtin_amdgcn_s_memtime();
 #endif
+  uint32_t* s_tab = reinterpret_cast<uint32_t*>(s_z + ((tp.H + 15) / 16) * 16 * LDZ);   // per-pixel constants [3][64 E]
   tail_z_tile<T>(tp, s_z, n, t);
-  TailRow<T, E> tr;
-  tr.init(tp, lane);
+  tail_consts_fill<T>(tp, s_tab, 64 * E);
   __syncthreads();
-  STAMP(8);   // z tile (MFMA) + per-lane constants
+  TailRow<T, E> tr;
+  tr.load(s_tab, lane);
+  STAMP(8);   // z tile (MFMA) + per-pixel constants
   uint32_t key[EPT];
 #pragma unroll
   for (int j = 0; j < R; ++j) {
@@ -472,11 +475,12 @@ __global__ __launch_bounds__(TK_THREADS) void predictor_tail_select_kernel(TailP
     float a[E] = {0.f, 0.f, 0.f, 0.f};
     if (FULL || h < tp.H) tr.head(tp, s_z + h * LDZ, lane, (((int64_t)n * tp.H + h) * tp.T + t) * tp.T_M, a);
 #pragma unroll
-    for (int e = 0; e < E; ++e) key[4 * j + e] = (FULL || h < tp.H) ? f2key(Elem<T>::to_f(from_f<T>(a[e]))) : 0u;
+    for (int e = 0; e < E; ++e)   // probabilities are >= +0: the order-preserving key is the bit pattern with the sign bit set
+      key[4 * j + e] = (FULL || h < tp.H) ? (__float_as_uint(Elem<T>::to_f(from_f<T>(a[e]))) | 0x80000000u) : 0u;
   }
   STAMP(9);   // 8 heads per wave: resize + LayerNorm + softmax + store
   const T* base = reinterpret_cast<const T*>(p.src) + n * p.sn + t * p.st;   // = the map just written (slow path re-reads it)
-  select_body<T, EPT, false, FULL>(p, key, 0ull, n, t, row, base);
+  select_body<T, EPT, false, FULL, 64>(p, key, 0ull, n, t, row, base);     // H <= 64: sea_predictor_tail_select checks
 }
 
 // ---- crow = exclusive scan of row_nnz ------------------------------------------------------------
@@ -756,7 +760,7 @@ extern "C" int sea_mask_to_bits(const void* mask, int dtype, int64_t N, int64_t 
 template <typename T>
 static int launch_tail_select(const TailParams& tp, const TopkParams& p, int64_t rows, hipStream_t s) {
   const int ept = ((p.nchunks + TK_THREADS - 1) / TK_THREADS) * 4;
-  const size_t lds = (size_t)(((tp.H + 15) / 16) * 16) * (tp.W4 + 3) * sizeof(float);
+  const size_t lds = (size_t)(((tp.H + 15) / 16) * 16) * (tp.W4 + 3) * sizeof(float) + (size_t)TAIL_TAB_ROWS * 256 * sizeof(uint32_t);
   dim3 grid((unsigned)rows), block(TK_THREADS);
 #define SEA_TSEL(EE)                                                                                              \
   do {                                                                                                            \
