@@ -124,6 +124,33 @@ template <typename T, typename Op> __device__ inline T wave_reduce32(T v, Op op)
   }
   return v;
 }
+// EIGHT values per lane reduced over the 64 lanes at once: returns x with x[lane] = op over all lanes of v[lane >> 3]
+// (read result k back with v_readlane from lane 8k).  A transposing butterfly -- each cross-lane step also halves the
+// number of live values: v_permlane32_swap pairs (k, k+4), v_permlane16_swap pairs again, one select + row_ror:8 step,
+// then three DPP steps inside the groups of 8 lanes.  18 vector instructions instead of 8 x 10 for eight wave_reduce32.
+template <typename Op> __device__ inline float wave_reduce8(const float (&v)[8], Op op) {
+  float r[4], q[2];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {          // lanes < 32: value k over (l, l+32);  lanes >= 32: value k+4
+    const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[k]), __float_as_uint(v[k + 4]), false, false);
+    r[k] = op(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {          // rows of 16 lanes: q[0] holds values 0, 2, 4, 6;  q[1] holds 1, 3, 5, 7
+    const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(r[k]), __float_as_uint(r[k + 2]), false, false);
+    q[k] = op(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+  }
+  const bool b3 = (threadIdx.x & 8) != 0;
+  const float keep = b3 ? q[1] : q[0], give = b3 ? q[0] : q[1];
+  float x = op(keep, __uint_as_float(dpp_u32<0x128>(__float_as_uint(give))));   // row_ror:8 -> value index = lane >> 3
+  x = op(x, __uint_as_float(dpp_u32<0xB1>(__float_as_uint(x))));                // quad_perm [1,0,3,2]
+  x = op(x, __uint_as_float(dpp_u32<0x4E>(__float_as_uint(x))));                // quad_perm [2,3,0,1]
+  x = op(x, __uint_as_float(dpp_u32<0x141>(__float_as_uint(x))));               // row_half_mirror
+  return x;
+}
+// result k of wave_reduce8, wave-uniform (a scalar register)
+__device__ inline float reduce8_get(float x, int k) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(x), 8 * k)); }
+
 // v[l] + v[l ^ 16] and v[l] + v[l ^ 32] for every lane, through the gfx950 row-swap instructions (no LDS crossbar)
 __device__ inline float xor16_sum(float v) {
   const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);

@@ -281,9 +281,12 @@ __global__ __launch_bounds__(256) void predictor_tail_mfma_kernel(TailParams p) 
   __syncthreads();
   TailRow<T, E> tr;
   tr.load(s_tab, lane);
-  for (int h = wv; h < p.H; h += 4) {
-    float a[E];
-    tr.head(p, s_z + h * LDZ, lane, (((int64_t)n * p.H + h) * p.T + t) * p.T_M, a);
+  const int mine = (p.H - wv + 3) / 4;                     // heads wv, wv + 4, ... of this wave, in batches of 8
+  for (int k0 = 0; k0 < mine; k0 += 8) {
+    float a[8][E];
+    tr.heads(p, lane, min(8, mine - k0),
+             [&](int b) { return s_z + (wv + 4 * (k0 + b)) * LDZ; },
+             [&](int b) { return (((int64_t)n * p.H + (wv + 4 * (k0 + b))) * p.T + t) * p.T_M; }, a);
   }
 }
 

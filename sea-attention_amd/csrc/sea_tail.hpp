@@ -186,45 +186,87 @@ struct TailRow {
     }
   }
 
-  // area resize -> LayerNorm -> (scores) -> softmax -> probs of head h (one wave); a[] returns the probabilities.
-  // FULLROW: T_M == 64 * E, every lane slot is a real pixel -- no per-element predicates, packed 8-byte stores.
-  template <bool FULLROW>
-  __device__ __forceinline__ void head_impl(const TailParams& p, const float* zr, int lane, int64_t obase, float (&a)[E]) const {
+  // area resize -> LayerNorm -> (scores) -> softmax -> probs of up to NBC <= 8 heads of one wave AT ONCE: the four wave
+  // reductions of a head (mean, variance, max, sum of exponentials) run as four wave_reduce8 over the batch -- 4 x 26
+  // vector instructions (butterfly + readlanes) instead of 8 x 4 x 10, in a kernel that is vector-issue bound.
+  // Head b of the batch (b < nb, wave-uniform) reads z row zrow(b) and writes at element offset obase(b); a[b][] returns
+  // its probabilities.  FULLROW: T_M == 64 * E, every lane slot is a real pixel -- no per-element predicates.
+  template <bool FULLROW, int NBC, typename ZF, typename OF>
+  __device__ __forceinline__ void heads_impl(const TailParams& p, int lane, int nb, ZF zrow, OF obase, float (&a)[NBC][E]) const {
+    static_assert(NBC >= 1 && NBC <= 8, "one wave_reduce8 per statistic");
     const float invT = 1.0f / (float)p.T_M;
-    float s1 = 0.f;
+    float red[8], st[NBC];
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      a[e] = (zr[src[e][0]] + zr[src[e][1]] + zr[src[e][2]]) * rcnt[e];
-      s1 += a[e];
+    for (int b = 0; b < 8; ++b) red[b] = 0.f;
+#pragma unroll
+    for (int b = 0; b < NBC; ++b) {
+      float s1 = 0.f;
+      if (b < nb) {
+        const float* zr = zrow(b);
+#pragma unroll
+        for (int e = 0; e < E; ++e) {
+          a[b][e] = (zr[src[e][0]] + zr[src[e][1]] + zr[src[e][2]]) * rcnt[e];
+          s1 += a[b][e];
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < E; ++e) a[b][e] = 0.f;
+      }
+      red[b] = s1;
     }
-    const float mean = wave_sum(s1) * invT;
-    float s2 = 0.f;
+    float x = wave_reduce8(red, [](float u, float v) { return u + v; }) * invT;
 #pragma unroll
-    for (int e = 0; e < E; ++e)
-      if (FULLROW || lane * E + e < p.T_M) { const float d = a[e] - mean; s2 += d * d; }
-    const float rstd = rsqrtf(wave_sum(s2) * invT + p.eps);
-    float mx = -INFINITY;
+    for (int b = 0; b < NBC; ++b) st[b] = reduce8_get(x, b);                       // mean
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      a[e] = (a[e] - mean) * rstd * g[e] + be[e];
-      if (FULLROW || lane * E + e < p.T_M) mx = fmaxf(mx, a[e]);
+    for (int b = 0; b < NBC; ++b) {
+      float s2 = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e)
+        if (FULLROW || lane * E + e < p.T_M) { const float d = a[b][e] - st[b]; s2 += d * d; }
+      red[b] = s2;
     }
-    mx = wave_max(mx);
-    if (p.scores) store_run<T, E>(reinterpret_cast<T*>(p.scores) + obase, a, lane * E, FULLROW ? 64 * E : p.T_M);
-    float se = 0.f;
+    x = rsqrtf(wave_reduce8(red, [](float u, float v) { return u + v; }) * invT + p.eps);
 #pragma unroll
-    for (int e = 0; e < E; ++e) {
-      a[e] = (FULLROW || lane * E + e < p.T_M) ? __expf(a[e] - mx) : 0.f;
-      se += a[e];
+    for (int b = 0; b < NBC; ++b) {
+      const float rstd = reduce8_get(x, b);
+      float mx = -INFINITY;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        a[b][e] = (a[b][e] - st[b]) * rstd * g[e] + be[e];
+        if (FULLROW || lane * E + e < p.T_M) mx = fmaxf(mx, a[b][e]);
+      }
+      red[b] = mx;
     }
-    const float inv = 1.0f / wave_sum(se);
 #pragma unroll
-    for (int e = 0; e < E; ++e) a[e] *= inv;
-    store_run<T, E>(reinterpret_cast<T*>(p.probs) + obase, a, lane * E, FULLROW ? 64 * E : p.T_M);
+    for (int b = NBC; b < 8; ++b) red[b] = -INFINITY;
+    x = wave_reduce8(red, [](float u, float v) { return fmaxf(u, v); });
+#pragma unroll
+    for (int b = NBC; b < 8; ++b) red[b] = 0.f;
+#pragma unroll
+    for (int b = 0; b < NBC; ++b) {
+      const float mx = reduce8_get(x, b);
+      if (p.scores && b < nb) store_run<T, E>(reinterpret_cast<T*>(p.scores) + obase(b), a[b], lane * E, FULLROW ? 64 * E : p.T_M);
+      float se = 0.f;
+#pragma unroll
+      for (int e = 0; e < E; ++e) {
+        a[b][e] = (FULLROW || lane * E + e < p.T_M) ? __expf(a[b][e] - mx) : 0.f;
+        se += a[b][e];
+      }
+      red[b] = se;
+    }
+    x = 1.0f / wave_reduce8(red, [](float u, float v) { return u + v; });          // (slots >= NBC: 1/0 = inf, never read)
+#pragma unroll
+    for (int b = 0; b < NBC; ++b) {
+      const float inv = reduce8_get(x, b);
+#pragma unroll
+      for (int e = 0; e < E; ++e) a[b][e] *= inv;
+      if (b < nb) store_run<T, E>(reinterpret_cast<T*>(p.probs) + obase(b), a[b], lane * E, FULLROW ? 64 * E : p.T_M);
+    }
   }
-  __device__ __forceinline__ void head(const TailParams& p, const float* zr, int lane, int64_t obase, float (&a)[E]) const {
-    if (p.T_M == 64 * E) head_impl<true>(p, zr, lane, obase, a);      // wave-uniform
-    else head_impl<false>(p, zr, lane, obase, a);
+  template <int NBC, typename ZF, typename OF>
+  __device__ __forceinline__ void heads(const TailParams& p, int lane, int nb, ZF zrow, OF obase, float (&a)[NBC][E]) const {
+    if (p.T_M == 64 * E) heads_impl<true>(p, lane, nb, zrow, obase, a);      // wave-uniform
+    else heads_impl<false>(p, lane, nb, zrow, obase, a);
   }
 };
 

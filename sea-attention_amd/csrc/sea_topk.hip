@@ -469,14 +469,27 @@ __global__ __launch_bounds__(TK_THREADS) void predictor_tail_select_kernel(TailP
   tr.load(s_tab, lane);
   STAMP(8);   // z tile (MFMA) + per-pixel constants
   uint32_t key[EPT];
+  const int mine = FULL ? R : max(0, (tp.H - wv + 3) / 4);         // heads wv, wv + 4, ... of this wave (wave-uniform)
+  auto batch = [&](auto j0c, auto nbc) {                           // heads 4 (J0 + b) + wv, b < NBC, through one batch
+    constexpr int J0 = decltype(j0c)::value, NBC = decltype(nbc)::value;
+    float a[NBC][E];
+    const int nb = min(NBC, mine - J0);
+    if (nb > 0) {
+      tr.heads(tp, lane, nb, [&](int b) { return s_z + (4 * (J0 + b) + wv) * LDZ; },
+               [&](int b) { return (((int64_t)n * tp.H + (4 * (J0 + b) + wv)) * tp.T + t) * tp.T_M; }, a);
+    }
 #pragma unroll
-  for (int j = 0; j < R; ++j) {
-    const int h = 4 * j + wv;                                      // wave-uniform
-    float a[E] = {0.f, 0.f, 0.f, 0.f};
-    if (FULL || h < tp.H) tr.head(tp, s_z + h * LDZ, lane, (((int64_t)n * tp.H + h) * tp.T + t) * tp.T_M, a);
+    for (int b = 0; b < NBC; ++b)
 #pragma unroll
-    for (int e = 0; e < E; ++e)   // probabilities are >= +0: the order-preserving key is the bit pattern with the sign bit set
-      key[4 * j + e] = (FULL || h < tp.H) ? (__float_as_uint(Elem<T>::to_f(from_f<T>(a[e]))) | 0x80000000u) : 0u;
+      for (int e = 0; e < E; ++e)   // probabilities are >= +0: the order-preserving key is the bit pattern with the sign bit set
+        key[4 * (J0 + b) + e] = (b < nb) ? (__float_as_uint(Elem<T>::to_f(from_f<T>(a[b][e]))) | 0x80000000u) : 0u;
+  };
+  static_assert(R <= 16, "two batches of eight heads per wave");
+  if constexpr (R <= 8) {
+    batch(std::integral_constant<int, 0>{}, std::integral_constant<int, R>{});
+  } else {
+    batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
+    batch(std::integral_constant<int, 8>{}, std::integral_constant<int, R - 8>{});
   }
   STAMP(9);   // 8 heads per wave: resize + LayerNorm + softmax + store
   const T* base = reinterpret_cast<const T*>(p.src) + n * p.sn + t * p.st;   // = the map just written (slow path re-reads it)
