@@ -457,7 +457,7 @@ __global__ __launch_bounds__(TK_THREADS) void predictor_tail_select_kernel(TailP
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int row = blockIdx.x;
   const int n = row / tp.T, t = row - n * tp.T;
-  const int LDZ = tp.W4 + 3;
+  constexpr int LDZ = 64 + 3;      // = W4 + 3 (sea_predictor_tail_select checks W4 == 64): z-row offsets become immediates
 #ifdef SEA_STAMP
   unsigned long long _tprev = __builtin_amdgcn_s_memtime();
 #endif
