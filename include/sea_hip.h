@@ -356,6 +356,34 @@ int sea_performer_causal_step(const void* q, const void* k, const void* v, const
                               int64_t state_bytes, int64_t t_base, int64_t n_segments, void* workspace,
                               int64_t workspace_bytes, sea_stream_t stream);
 
+/* ---- decode step with the position in DEVICE memory ------------------------------------------------------------------
+ * The reference's generation loop (src/main/opt_generate.py:131 -> attention.py use_cache branches + attention_state.py)
+ * runs one position per forward.  For a step that is captured ONCE as a HIP graph and replayed per token, nothing that
+ * changes with the position may sit in kernel arguments: these three entry points read it from device memory instead
+ * (an int32 the captured step itself increments).  Everything else of the step -- predictor MLP, the two convolutions
+ * over the cached window, row scan, fused attention over K / V caches of fixed capacity -- has static arguments already.
+ *
+ * sea_performer_causal_step_at: sea_performer_causal_step with t_base = *t_base_dev; pos_table is the BASE of the value
+ *   embedding (the kernel reads rows *t_base_dev ..); state_in / state_out may be one image (updated in place).
+ * sea_predictor_tail_select_at: sea_predictor_tail_select for the LAST T rows of sequences of *t_src_dev tokens;
+ *   keep_table[i] = K of the row that sees i+1 keys, for every position the session can reach (attention.py:849-866).
+ * sea_csr_emit_at: sea_csr_emit with the row widths following *t_src_dev and column ids = head * T_cap + key for a FIXED
+ *   capacity T_cap >= *t_src_dev (the K / V caches' row count), so sea_sparse_attention is called with T_src = T_cap. */
+int sea_performer_causal_step_at(const void* q, const void* k, const void* v, const void* pos_table, int dtype,
+                                 const float* proj, int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb,
+                                 const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                                 int64_t pos_stride, void* out, void* avg_out, const void* state_in, void* state_out,
+                                 int64_t state_bytes, const int32_t* t_base_dev, sea_stream_t stream);
+int sea_predictor_tail_select_at(const void* y, int dtype, int64_t N, int64_t C, int64_t H, int64_t T, int64_t W4,
+                                 int64_t up, int64_t T_m, const int64_t* y_strides, const void* conv_b,
+                                 const void* conv_w16, int64_t Cp, const void* gamma, const void* beta, float eps,
+                                 void* probs, void* scores, const int32_t* keep_table, const int32_t* t_src_dev,
+                                 int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz, int32_t* head_off,
+                                 sea_stream_t stream);
+int sea_csr_emit_at(const uint32_t* bits, const void* crow, int64_t N, int64_t H, int64_t T_dst, int64_t T_m,
+                    const int32_t* t_src_dev, int64_t T_cap, int is_causal, int max_k, void* col, int idx_bytes,
+                    int64_t col_stride_n, int64_t z_cap, sea_stream_t stream);
+
 /* Algorithmic bytes of one sea_sparse_attention launch:
  * Z*(2*D*s + 4) + N*H*T_dst*(2*D*s + 4).  Host-side helper, no device work. */
 int64_t sea_sparse_attention_bytes(int64_t Z, int64_t N, int64_t H, int64_t T_dst, int64_t D, int elem_bytes);

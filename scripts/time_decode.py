@@ -34,5 +34,19 @@ with torch.no_grad():
         hi = T0 + i + 1
         st = layer(None, None, None, query_layer=q[:, :, hi - 1:hi], key_layer=x[:, :, :hi], value_layer=x[:, :, :hi], attention_mask=mask(1, hi), last_state=st).state
     torch.cuda.synchronize(); t_dec = (time.perf_counter() - t0) / (steps - 4)
-print(json.dumps({"batch": N, "prefill_tokens": T0, "prefill_ms": round(t_prefill * 1e3, 2), "decode_ms_per_token_step": round(t_dec * 1e3, 3),
+    # the same positions through the graph-replayed session (perlin_attention/decode.py)
+    from sea_attention_amd.perlin_attention.decode import DecodeSession
+    res_s = {}
+    for label, use_graph in (("session_eager", False), ("session_graph", True)):
+        sess = DecodeSession(layer.attention, out.state, x[:, :, :T0], x[:, :, :T0], capacity=T0 + steps, use_graph=use_graph)
+        for i in range(4):
+            hi = T0 + i + 1
+            sess.step(q[:, :, hi - 1:hi], x[:, :, hi - 1:hi], x[:, :, hi - 1:hi])
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(4, steps):
+            hi = T0 + i + 1
+            sess.step(q[:, :, hi - 1:hi], x[:, :, hi - 1:hi], x[:, :, hi - 1:hi])
+        torch.cuda.synchronize()
+        res_s[label + "_ms_per_step"] = round((time.perf_counter() - t0) / (steps - 4) * 1e3, 3)
+print(json.dumps({**res_s, "batch": N, "prefill_tokens": T0, "prefill_ms": round(t_prefill * 1e3, 2), "decode_ms_per_token_step": round(t_dec * 1e3, 3),
                   "decode_tokens_per_s": round(N / t_dec, 1)}))

@@ -54,6 +54,11 @@ _SIGNATURES = {
     "sea_performer_state_bytes": ([i64, i64, i64, i64, c_int], i64),
     "sea_performer_causal_step": ([ptr, ptr, ptr, ptr, c_int, ptr, i64, i64, i64, i64, i64, _i64p, _i64p, _i64p, i64, ptr, ptr,
                                    ptr, ptr, i64, i64, i64, ptr, i64, ptr], c_int),
+    "sea_performer_causal_step_at": ([ptr, ptr, ptr, ptr, c_int, ptr, i64, i64, i64, i64, i64, _i64p, _i64p, _i64p, i64, ptr, ptr,
+                                      ptr, ptr, i64, ptr, ptr], c_int),
+    "sea_predictor_tail_select_at": ([ptr, c_int, i64, i64, i64, i64, i64, i64, i64, _i64p, ptr, ptr, i64, ptr, ptr,
+                                      ctypes.c_float, ptr, ptr, ptr, ptr, c_int, c_int, ptr, ptr, ptr, ptr], c_int),
+    "sea_csr_emit_at": ([ptr, ptr, i64, i64, i64, i64, ptr, i64, c_int, c_int, ptr, c_int, i64, i64, ptr], c_int),
     "sea_performer_avg_supported": ([i64, i64, c_int], c_int),
     "sea_performer_plan": ([i64, i64, i64, i64, i64, c_int, _i64p, _i64p], c_int),
     "sea_performer_causal_segmented": ([ptr, ptr, ptr, ptr, c_int, ptr, i64, i64, i64, i64, i64, _i64p, _i64p, _i64p, i64, ptr, ptr,

@@ -55,6 +55,9 @@ struct PerfParams {
   const float* state_in;
   float* state_out;
   int t_base;
+  // device-resident form of t_base (a captured decode step replayed as a HIP graph: the position lives in memory).  When
+  // set, `pos` is the BASE of the embedding table and the kernel reads its rows from row *t_base_dev on.
+  const int32_t* t_base_dev;
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 pbf8;
@@ -126,7 +129,8 @@ __global__ __launch_bounds__(NW * 64) void performer_kernel(PerfParams p) {
   const T* qb = reinterpret_cast<const T*>(p.q) + n * p.qs[0] + h * p.qs[1];
   const T* kb = reinterpret_cast<const T*>(p.k) + n * p.ks[0] + h * p.ks[1];
   const T* vb = reinterpret_cast<const T*>(p.v) + n * p.vs[0] + h * p.vs[1];
-  const T* pb = reinterpret_cast<const T*>(p.pos);
+  const int tb = p.t_base_dev ? *p.t_base_dev : p.t_base;       // rows the state has already seen (block-uniform)
+  const T* pb = reinterpret_cast<const T*>(p.pos) + (p.t_base_dev ? (int64_t)tb * p.pos_stride : 0);
   T* ob = reinterpret_cast<T*>(p.out) + (int64_t)nh * p.T * (3 * D);
   const float cnorm = powf((float)D, -0.25f);
 
@@ -522,7 +526,8 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   const T* qb = reinterpret_cast<const T*>(p.q) + n * p.qs[0] + h * p.qs[1];
   const T* kb = reinterpret_cast<const T*>(p.k) + n * p.ks[0] + h * p.ks[1];
   const T* vb = reinterpret_cast<const T*>(p.v) + n * p.vs[0] + h * p.vs[1];
-  const T* pb = reinterpret_cast<const T*>(p.pos);
+  const int tb = p.t_base_dev ? *p.t_base_dev : p.t_base;       // rows the state has already seen (block-uniform)
+  const T* pb = reinterpret_cast<const T*>(p.pos) + (p.t_base_dev ? (int64_t)tb * p.pos_stride : 0);
   T* ob = reinterpret_cast<T*>(p.out) + (int64_t)nh * p.T * (3 * D);
   const float cnorm = powf((float)D, -0.25f);
 
@@ -766,7 +771,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 #pragma unroll
       for (int i = 0; i < DSL; ++i) s += sDenP[tid * DSL + i];
       sDen[tid] = 1.0f / s;                                  // the 16 column waves multiply by the reciprocal
-      sRinv[tid] = 1.0f / (float)(p.t_base + t0 + tid + 1);
+      sRinv[tid] = 1.0f / (float)(tb + t0 + tid + 1);
     } else if (tid >= C && tid < C + FP) {
       const int f = tid - C;
       float s = sKsum[f];
@@ -963,7 +968,8 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
   const T* qb = reinterpret_cast<const T*>(p.q) + n * p.qs[0] + h * p.qs[1];
   const T* kb = reinterpret_cast<const T*>(p.k) + n * p.ks[0] + h * p.ks[1];
   const T* vb = reinterpret_cast<const T*>(p.v) + n * p.vs[0] + h * p.vs[1];
-  const T* pb = reinterpret_cast<const T*>(p.pos);
+  const int tb = p.t_base_dev ? *p.t_base_dev : p.t_base;       // rows the state has already seen (block-uniform)
+  const T* pb = reinterpret_cast<const T*>(p.pos) + (p.t_base_dev ? (int64_t)tb * p.pos_stride : 0);
   T* ob = reinterpret_cast<T*>(p.out) + (int64_t)nh * p.T * (3 * D);
   const float cnorm = powf((float)D, -0.25f);
 
@@ -1219,7 +1225,7 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
 #pragma unroll
       for (int i = 0; i < DSL; ++i) s += sDenP[tid * DSL + i];
       sDen[tid] = 1.0f / s;                                  // the 16 column waves multiply by the reciprocal
-      sRinv[tid] = 1.0f / (float)(p.t_base + t0 + tid + 1);
+      sRinv[tid] = 1.0f / (float)(tb + t0 + tid + 1);
     } else if (tid >= C && tid < C + FP) {
       const int f = tid - C;
       float s = sKsum[f];
@@ -1526,6 +1532,7 @@ static int perf_entry(const char* nm, const void* q, const void* k, const void* 
                       const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                       int64_t pos_stride, void* out, void* avg_out, int64_t n_segments, void* workspace,
                       int64_t workspace_bytes, const void* state_in, void* state_out, int64_t state_bytes, int64_t t_base,
+                      const int32_t* t_base_dev,
                       sea_stream_t stream) {
   SEA_REQUIRE(q && k && v && pos && proj && out && q_strides && k_strides && v_strides, SEA_EINVAL, "%s: null pointer", nm);
   SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_F16 || dtype == SEA_BF16, SEA_EINVAL, "%s: bad dtype %d", nm, dtype);
@@ -1550,6 +1557,7 @@ static int perf_entry(const char* nm, const void* q, const void* k, const void* 
   p.state_in = reinterpret_cast<const float*>(state_in);
   p.state_out = reinterpret_cast<float*>(state_out);
   p.t_base = (int)t_base;
+  p.t_base_dev = t_base_dev;
   if (state_in || state_out) {
     const int64_t need = N * H * perf_carry_floats_for(dtype, (int)D, nbt) * (int64_t)sizeof(float);
     SEA_REQUIRE(need > 0 && state_bytes >= need && ((((uintptr_t)state_in) | ((uintptr_t)state_out)) & 15) == 0 && t_base >= 0,
@@ -1579,7 +1587,7 @@ extern "C" int sea_performer_causal(const void* q, const void* k, const void* v,
                                     const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                                     int64_t pos_stride, void* out, void* avg_out, sea_stream_t stream) {
   return perf_entry("sea_performer_causal", q, k, v, pos, dtype, proj, N, H, T, D, nb, q_strides, k_strides, v_strides,
-                    pos_stride, out, avg_out, 1, nullptr, 0, nullptr, nullptr, 0, 0, stream);
+                    pos_stride, out, avg_out, 1, nullptr, 0, nullptr, nullptr, 0, 0, nullptr, stream);
 }
 
 extern "C" int sea_performer_causal_segmented(const void* q, const void* k, const void* v, const void* pos, int dtype,
@@ -1588,7 +1596,7 @@ extern "C" int sea_performer_causal_segmented(const void* q, const void* k, cons
                                               int64_t pos_stride, void* out, void* avg_out, int64_t n_segments,
                                               void* workspace, int64_t workspace_bytes, sea_stream_t stream) {
   return perf_entry("sea_performer_causal_segmented", q, k, v, pos, dtype, proj, N, H, T, D, nb, q_strides, k_strides,
-                    v_strides, pos_stride, out, avg_out, n_segments, workspace, workspace_bytes, nullptr, nullptr, 0, 0, stream);
+                    v_strides, pos_stride, out, avg_out, n_segments, workspace, workspace_bytes, nullptr, nullptr, 0, 0, nullptr, stream);
 }
 
 extern "C" int64_t sea_performer_state_bytes(int64_t N, int64_t H, int64_t D, int64_t nb, int dtype) {
@@ -1604,5 +1612,20 @@ extern "C" int sea_performer_causal_step(const void* q, const void* k, const voi
                                          void* workspace, int64_t workspace_bytes, sea_stream_t stream) {
   return perf_entry("sea_performer_causal_step", q, k, v, pos, dtype, proj, N, H, T, D, nb, q_strides, k_strides,
                     v_strides, pos_stride, out, avg_out, n_segments, workspace, workspace_bytes, state_in, state_out,
-                    state_bytes, t_base, stream);
+                    state_bytes, t_base, nullptr, stream);
+}
+
+// The same step with the position in DEVICE memory (SURVEY 8f-3 / opt_generate.py:131: the decode loop captured once as
+// a HIP graph and replayed per token -- nothing position-dependent may live in kernel arguments).  *t_base_dev = rows the
+// state has seen; pos_table is the BASE of the value-embedding table (the kernel reads rows *t_base_dev ..); state_in
+// and state_out may be the same image (updated in place); one segment.
+extern "C" int sea_performer_causal_step_at(const void* q, const void* k, const void* v, const void* pos_table, int dtype,
+                                            const float* proj, int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb,
+                                            const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                                            int64_t pos_stride, void* out, void* avg_out, const void* state_in,
+                                            void* state_out, int64_t state_bytes, const int32_t* t_base_dev,
+                                            sea_stream_t stream) {
+  SEA_REQUIRE(t_base_dev && state_in && state_out, SEA_EINVAL, "sea_performer_causal_step_at: null pointer");
+  return perf_entry("sea_performer_causal_step_at", q, k, v, pos_table, dtype, proj, N, H, T, D, nb, q_strides, k_strides,
+                    v_strides, pos_stride, out, avg_out, 1, nullptr, 0, state_in, state_out, state_bytes, 0, t_base_dev, stream);
 }

@@ -57,6 +57,9 @@ struct TopkParams {
   float* mask_out;
   int32_t* row_nnz;
   int32_t* head_off;
+  // decode step replayed as a HIP graph: T_src (the rows' absolute widths) read from device memory; `keep` is then a
+  // table over ABSOLUTE row indices (entry i = K of the row with i+1 visible keys), not over the T_dst rows of the call
+  const int32_t* t_src_dev;
 };
 
 template <typename T> __device__ inline void load4(const T* p, float* f);
@@ -238,7 +241,7 @@ __device__ __forceinline__ void select_body(const TopkParams& p, uint32_t (&key)
 #if SEA_EXP == 1
     const int K = p.M;   // ablation: skip the selection
 #else
-    const int K = p.keep[n * p.keep_stride_n + t];
+    const int K = p.keep[n * p.keep_stride_n + t + (p.t_src_dev ? *p.t_src_dev - p.T_dst : 0)];
 #endif
     if (K >= p.M) {
 #pragma unroll
@@ -347,7 +350,7 @@ __device__ __forceinline__ void select_body(const TopkParams& p, uint32_t (&key)
 
   STAMP(3);   // selection flags
   // ---- outputs ----------------------------------------------------------------------------------
-  const int w_t = row_width(t, p.T_dst, p.T_src, p.is_causal);
+  const int w_t = row_width(t, p.T_dst, p.t_src_dev ? *p.t_src_dev : p.T_src, p.is_causal);
   const float scale = interp_scale(w_t, p.T_m);
   const bool tm_pow2 = (p.T_m & (p.T_m - 1)) == 0;      // block-uniform
   const int tm_sh = __ffs(p.T_m) - 1;
@@ -529,6 +532,8 @@ struct EmitParams {
   void* col;
   int64_t col_stride_n, z_cap;
   float* values_out;
+  int T_enc;                       // column = head * T_enc + key (T_src, or a fixed cache capacity in the decode form)
+  const int32_t* t_src_dev;        // decode step replayed as a HIP graph: T_src (row widths) read from device memory
 };
 
 // One workgroup per row.
@@ -557,7 +562,7 @@ __global__ __launch_bounds__(TK_THREADS) void csr_emit_kernel(EmitParams p) {
   I* col = reinterpret_cast<I*>(p.col) + n * p.col_stride_n;
   float* vals = p.values_out ? p.values_out + n * p.col_stride_n : nullptr;
   const uint32_t* bits = p.bits + (int64_t)row * p.W;
-  const int w_t = row_width(t, p.T_dst, p.T_src, p.is_causal);
+  const int w_t = row_width(t, p.T_dst, p.t_src_dev ? *p.t_src_dev : p.T_src, p.is_causal);
   const float scale = interp_scale(w_t, p.T_m);
   const bool table = p.T_m <= EM_TABLE;
   if (table)
@@ -597,7 +602,7 @@ __global__ __launch_bounds__(TK_THREADS) void csr_emit_kernel(EmitParams p) {
           if (!aligned) { const int q = b / p.T_m; h += q; b -= q * p.T_m; }
           const int lo = bnd(b), hi = bnd(b + 1);
           const int wd = hi - lo;
-          const int hb = h * p.T_src;
+          const int hb = h * p.T_enc;
           if (wd <= p.max_k) {
             if (inside) {                                           // the common case: no per-entry window test
               int* dst = s_out + (off - win);
@@ -732,7 +737,7 @@ static int select_common(const char* name, const void* src, int dtype, int64_t N
   p.is_causal = is_causal; p.max_k = max_k;
   p.M = (int)(H * T_m); p.nchunks = p.M / 4; p.W = (p.M + 31) / 32; p.G = group_lanes((int)T_m);
   p.keep = keep; p.keep_stride_n = keep_stride_n;
-  p.bits = bits; p.mask_out = mask_out; p.row_nnz = row_nnz; p.head_off = head_off;
+  p.bits = bits; p.mask_out = mask_out; p.row_nnz = row_nnz; p.head_off = head_off; p.t_src_dev = nullptr;
   const int64_t rows = N * T_dst;
   if (dtype == SEA_F32) launch_select<float, FROM_MASK>(p, rows, s);
   else if (dtype == SEA_F16) launch_select<__half, FROM_MASK>(p, rows, s);
@@ -791,13 +796,12 @@ static int launch_tail_select(const TailParams& tp, const TopkParams& p, int64_t
   return SEA_OK;
 }
 
-extern "C" int sea_predictor_tail_select(const void* y, int dtype, int64_t N, int64_t C, int64_t H, int64_t T, int64_t W4,
-                                         int64_t up, int64_t T_m, const int64_t* y_strides, const void* conv_b,
-                                         const void* conv_w16, int64_t Cp, const void* gamma, const void* beta, float eps,
-                                         void* probs, void* scores, const int32_t* keep, int64_t keep_stride_n,
-                                         int64_t T_src, int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz,
-                                         int32_t* head_off, sea_stream_t stream) {
-  const char* nm = "sea_predictor_tail_select";
+static int tail_select_common(const char* nm, const void* y, int dtype, int64_t N, int64_t C, int64_t H, int64_t T, int64_t W4,
+                              int64_t up, int64_t T_m, const int64_t* y_strides, const void* conv_b,
+                              const void* conv_w16, int64_t Cp, const void* gamma, const void* beta, float eps,
+                              void* probs, void* scores, const int32_t* keep, int64_t keep_stride_n,
+                              int64_t T_src, const int32_t* t_src_dev, int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz,
+                              int32_t* head_off, sea_stream_t stream) {
   SEA_REQUIRE(y && y_strides && conv_b && conv_w16 && gamma && beta && probs && keep && bits && row_nnz && head_off, SEA_EINVAL,
               "%s: null pointer", nm);
   SEA_REQUIRE(dtype == SEA_F16 || dtype == SEA_BF16, SEA_EUNSUPPORTED, "%s: 16-bit data only (dtype %d)", nm, dtype);
@@ -820,12 +824,37 @@ extern "C" int sea_predictor_tail_select(const void* y, int dtype, int64_t N, in
   p.is_causal = is_causal; p.max_k = max_k;
   p.M = (int)(H * T_m); p.nchunks = p.M / 4; p.W = (p.M + 31) / 32; p.G = group_lanes((int)T_m);
   p.keep = keep; p.keep_stride_n = keep_stride_n;
-  p.bits = bits; p.mask_out = nullptr; p.row_nnz = row_nnz; p.head_off = head_off;
+  p.bits = bits; p.mask_out = nullptr; p.row_nnz = row_nnz; p.head_off = head_off; p.t_src_dev = t_src_dev;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == SEA_F16) launch_tail_select<__half>(tp, p, N * T, s);
   else launch_tail_select<__hip_bfloat16>(tp, p, N * T, s);
   SEA_CHECK_LAUNCH(nm);
   return SEA_OK;
+}
+
+extern "C" int sea_predictor_tail_select(const void* y, int dtype, int64_t N, int64_t C, int64_t H, int64_t T, int64_t W4,
+                                         int64_t up, int64_t T_m, const int64_t* y_strides, const void* conv_b,
+                                         const void* conv_w16, int64_t Cp, const void* gamma, const void* beta, float eps,
+                                         void* probs, void* scores, const int32_t* keep, int64_t keep_stride_n,
+                                         int64_t T_src, int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz,
+                                         int32_t* head_off, sea_stream_t stream) {
+  return tail_select_common("sea_predictor_tail_select", y, dtype, N, C, H, T, W4, up, T_m, y_strides, conv_b, conv_w16, Cp, gamma,
+                            beta, eps, probs, scores, keep, keep_stride_n, T_src, nullptr, is_causal, max_k, bits, row_nnz,
+                            head_off, stream);
+}
+
+// Decode form (a step captured as a HIP graph): the T new rows are the LAST rows of sequences of *t_src_dev tokens (device
+// memory); keep_table[i] = K of the row with i+1 visible keys, for every position the session can reach.
+extern "C" int sea_predictor_tail_select_at(const void* y, int dtype, int64_t N, int64_t C, int64_t H, int64_t T, int64_t W4,
+                                            int64_t up, int64_t T_m, const int64_t* y_strides, const void* conv_b,
+                                            const void* conv_w16, int64_t Cp, const void* gamma, const void* beta, float eps,
+                                            void* probs, void* scores, const int32_t* keep_table, const int32_t* t_src_dev,
+                                            int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz, int32_t* head_off,
+                                            sea_stream_t stream) {
+  SEA_REQUIRE(t_src_dev, SEA_EINVAL, "sea_predictor_tail_select_at: null pointer");
+  return tail_select_common("sea_predictor_tail_select_at", y, dtype, N, C, H, T, W4, up, T_m, y_strides, conv_b, conv_w16, Cp,
+                            gamma, beta, eps, probs, scores, keep_table, 0, T, t_src_dev, is_causal, max_k, bits, row_nnz,
+                            head_off, stream);
 }
 
 extern "C" int sea_csr_row_scan(const int32_t* row_nnz, int64_t N, int64_t T_dst, void* crow, int idx_bytes,
@@ -842,17 +871,16 @@ extern "C" int sea_csr_row_scan(const int32_t* row_nnz, int64_t N, int64_t T_dst
   return SEA_OK;
 }
 
-extern "C" int sea_csr_emit(const uint32_t* bits, const void* crow, const int32_t* head_off, int64_t N, int64_t H,
-                            int64_t T_dst, int64_t T_m, int64_t T_src, int is_causal, int max_k, void* col, int idx_bytes,
-                            int64_t col_stride_n, int64_t z_cap, float* values_out, sea_stream_t stream) {
-  (void)head_off;  // offsets follow from the flat (head-major) emission order; kept in the ABI for symmetry
-  SEA_REQUIRE(bits && crow && col, SEA_EINVAL, "sea_csr_emit: null pointer");
-  SEA_REQUIRE(idx_bytes == 4 || idx_bytes == 8, SEA_EINVAL, "sea_csr_emit: idx_bytes must be 4 or 8");
-  SEA_REQUIRE(N > 0 && H > 0 && T_dst > 0 && T_m > 0 && max_k > 0, SEA_EINVAL, "sea_csr_emit: bad shape");
-  SEA_REQUIRE(H * T_src < (1ll << 24), SEA_EUNSUPPORTED, "sea_csr_emit: H*T_src must stay below 2^24 (fp32-exact ids)");
+static int emit_common(const char* nm, const uint32_t* bits, const void* crow, int64_t N, int64_t H, int64_t T_dst, int64_t T_m,
+                       int64_t T_src, const int32_t* t_src_dev, int64_t T_enc, int is_causal, int max_k, void* col, int idx_bytes,
+                       int64_t col_stride_n, int64_t z_cap, float* values_out, sea_stream_t stream) {
+  SEA_REQUIRE(bits && crow && col, SEA_EINVAL, "%s: null pointer", nm);
+  SEA_REQUIRE(idx_bytes == 4 || idx_bytes == 8, SEA_EINVAL, "%s: idx_bytes must be 4 or 8", nm);
+  SEA_REQUIRE(N > 0 && H > 0 && T_dst > 0 && T_m > 0 && max_k > 0, SEA_EINVAL, "%s: bad shape", nm);
+  SEA_REQUIRE(H * T_enc < (1ll << 24) && T_enc >= T_src, SEA_EUNSUPPORTED, "%s: H*T_src must stay below 2^24 (fp32-exact ids)", nm);
   if (z_cap == 0) return SEA_OK;
   EmitParams p;
-  p.bits = bits; p.crow = crow;
+  p.bits = bits; p.crow = crow; p.T_enc = (int)T_enc; p.t_src_dev = t_src_dev;
   p.H = (int)H; p.T_dst = (int)T_dst; p.T_m = (int)T_m; p.T_src = (int)T_src;
   p.is_causal = is_causal; p.max_k = max_k; p.W = (int)((H * T_m + 31) / 32);
   p.col = col; p.col_stride_n = col_stride_n; p.z_cap = z_cap; p.values_out = values_out;
@@ -860,8 +888,27 @@ extern "C" int sea_csr_emit(const uint32_t* bits, const void* crow, const int32_
   dim3 grid((unsigned)(N * T_dst)), block(TK_THREADS);
   if (idx_bytes == 4) hipLaunchKernelGGL((csr_emit_kernel<int32_t>), grid, block, 0, s, p);
   else hipLaunchKernelGGL((csr_emit_kernel<int64_t>), grid, block, 0, s, p);
-  SEA_CHECK_LAUNCH("sea_csr_emit");
+  SEA_CHECK_LAUNCH(nm);
   return SEA_OK;
+}
+
+extern "C" int sea_csr_emit(const uint32_t* bits, const void* crow, const int32_t* head_off, int64_t N, int64_t H,
+                            int64_t T_dst, int64_t T_m, int64_t T_src, int is_causal, int max_k, void* col, int idx_bytes,
+                            int64_t col_stride_n, int64_t z_cap, float* values_out, sea_stream_t stream) {
+  (void)head_off;  // offsets follow from the flat (head-major) emission order; kept in the ABI for symmetry
+  return emit_common("sea_csr_emit", bits, crow, N, H, T_dst, T_m, T_src, nullptr, T_src, is_causal, max_k, col, idx_bytes,
+                     col_stride_n, z_cap, values_out, stream);
+}
+
+// Decode form (a step captured as a HIP graph): the rows' widths follow *t_src_dev (device memory: the current sequence
+// length), the column ids are head * T_cap + key with a FIXED capacity T_cap >= *t_src_dev, so the attention launch that
+// consumes them (K / V caches of T_cap rows) needs nothing position-dependent in its arguments.
+extern "C" int sea_csr_emit_at(const uint32_t* bits, const void* crow, int64_t N, int64_t H, int64_t T_dst, int64_t T_m,
+                               const int32_t* t_src_dev, int64_t T_cap, int is_causal, int max_k, void* col, int idx_bytes,
+                               int64_t col_stride_n, int64_t z_cap, sea_stream_t stream) {
+  SEA_REQUIRE(t_src_dev, SEA_EINVAL, "sea_csr_emit_at: null pointer");
+  return emit_common("sea_csr_emit_at", bits, crow, N, H, T_dst, T_m, T_dst, t_src_dev, T_cap, is_causal, max_k, col, idx_bytes,
+                     col_stride_n, z_cap, nullptr, stream);
 }
 
 extern "C" int sea_csr_head_offsets(const void* crow, const void* col, int idx_bytes, int64_t N, int64_t H,

@@ -576,6 +576,12 @@ class PerlinAttention(nn.Module):
             )
 
     # ------------------------------------------------------------------------------------------------
+    def decode_session(self, state, key_prefix, value_prefix, capacity: int, use_graph: bool = True):
+        """Graph-replayed single-token decoding from `state` (the `.state` of a cached forward over `key_prefix` /
+        `value_prefix`, (N,H,L,D)) up to `capacity` tokens: see perlin_attention/decode.py."""
+        from .decode import DecodeSession
+        return DecodeSession(self, state, key_prefix, value_prefix, capacity, use_graph=use_graph)
+
     def _decode_keep(self, H, T_DST, T_SRC, T_M):
         """K_t of the new rows only (absolute positions T_SRC-T_DST+1 .. T_SRC), same fp32 expression as
         ops.keep_table_causal (attention.py:849-866), and the capacity bound of their CSR."""

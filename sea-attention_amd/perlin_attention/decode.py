@@ -1,0 +1,144 @@
+"""Single-token decoding of one SEA attention layer as a replayed HIP graph.
+
+The reference generates one position per forward (src/main/opt_generate.py:131 -> the `use_cache` branches of
+perlin_attention/attention.py + attention_state.py).  `PerlinAttention._forward_cached` is that path on the HIP
+kernels: a dozen launches per position whose arguments change with the position (T_src, the value-embedding row, K_t,
+tensor shapes that grow), so the step is bound by the host enqueueing them.
+
+`DecodeSession` freezes everything position-dependent into DEVICE memory instead:
+
+  * K / V caches of a fixed capacity; the new row is written at a device-resident index,
+  * the Performer state image and the predictor CNN's window are updated in place,
+  * the three kernels that need the position read it from a device int32
+    (`sea_performer_causal_step_at`, `sea_predictor_tail_select_at`, `sea_csr_emit_at`, include/sea_hip.h),
+  * column ids are encoded against the cache capacity, so the fused attention launch has static arguments,
+  * the step ends by incrementing the counters.
+
+The whole step is then captured ONCE with `torch.cuda.graph` and replayed per token; per position the host copies the
+new q / k / v rows into the static input buffers and launches one graph.  Results are bitwise those of
+`_forward_cached` called position by position (tests/test_decode_session.py).
+"""
+from typing import Optional
+
+import torch
+
+from . import ops
+from .attention_state import PerlinAttentionState, cnn_lookback
+
+
+class DecodeSession:
+    """Built from the state of a cached forward (`PerlinAttentionOutput.state`, HIP estimator: 16-bit inference) and the
+    K / V prefix that forward saw.  `step(q, k, v)` takes the NEW row of each tensor, (N, H, 1, D), and returns the
+    context row (N, 1, H*D) -- a static buffer, overwritten by the next step."""
+
+    def __init__(self, attention, state: PerlinAttentionState, key_prefix: torch.Tensor, value_prefix: torch.Tensor,
+                 capacity: int, use_graph: bool = True):
+        at = self.attention = attention
+        pc = at.pconfig
+        assert pc.causal and not at.training, "decoding is the causal inference path"
+        N, H, L, D = key_prefix.shape
+        assert value_prefix.shape == key_prefix.shape and key_prefix.is_cuda
+        assert state is not None and state.seq_len == L, "the state must have seen exactly the prefix"
+        LB = cnn_lookback(at.attention_predictor_cnn)
+        ps = state.states.get(PerlinAttentionState.PERFORMER)
+        cs = state.states.get(PerlinAttentionState.CNN)
+        assert ps is not None and ps.image is not None and cs is not None and torch.is_tensor(cs.rows_c8), \
+            "the session continues a state written by the HIP estimator (16-bit inference, supported head size)"
+        assert cs.rows_c8.shape[1] == LB, f"the prefix must be at least the predictor CNN's reach ({LB} rows)"
+        assert L < capacity <= at.v_eye_learned_causal.shape[2], "capacity: beyond the prefix, within the value embedding"
+        self.N, self.H, self.D, self.capacity = N, H, D, int(capacity)
+        self.T_M = int(pc.attention_predictor_length)
+        self.k = int(pc.k)
+        dev, dt = key_prefix.device, key_prefix.dtype
+        assert dt in (torch.float16, torch.bfloat16)
+        assert ops.predictor_tail_select_supported(cs.rows_c8, H, self.T_M), "fused tail + selection shape (T_M = 256, H <= 64)"
+        self.image = ps.image.clone()                                        # Performer sums, updated in place
+        self.win = cs.rows_c8.clone()                                        # last LB rows of the CNN input
+        self.k_cache = torch.zeros((N, H, capacity, D), dtype=dt, device=dev)
+        self.v_cache = torch.zeros((N, H, capacity, D), dtype=dt, device=dev)
+        self.k_cache[:, :, :L] = key_prefix
+        self.v_cache[:, :, :L] = value_prefix
+        self.seen32 = torch.full((1,), L, dtype=torch.int32, device=dev)      # rows the state has seen
+        self.tsrc32 = torch.full((1,), L + 1, dtype=torch.int32, device=dev)  # keys the new row sees
+        self.idx64 = torch.full((1,), L, dtype=torch.int64, device=dev)       # cache row of the new token
+        self.length = L                                                      # host mirror (bounds check only)
+        # K_t of every reachable position (attention.py:849-866, the same fp32 expression as the stateless path) and
+        # the largest CSR row any of them can emit
+        keep_cpu, _ = at._decode_keep(H, capacity, capacity, self.T_M)
+        self.keep_table = keep_cpu.to(dev)
+        w = torch.arange(1, capacity + 1)
+        per_pixel = torch.clamp_max(torch.div(w + self.T_M - 1, self.T_M, rounding_mode="floor"), self.k)
+        bound = torch.minimum(keep_cpu.to(torch.long) * per_pixel, H * torch.minimum(w, torch.tensor(self.T_M * self.k)))
+        self.z_cap = max(int(bound.max().item()), 1)
+        self.q_in = torch.zeros((N, H, 1, D), dtype=dt, device=dev)
+        self.k_in = torch.zeros_like(self.q_in)
+        self.v_in = torch.zeros_like(self.q_in)
+        self.ctx = torch.zeros((N, 1, H * D), dtype=at.context_layer_dtype or torch.float32, device=dev)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.probs = None                                                    # estimated attention probabilities of the last step
+        if use_graph:
+            self._capture()
+
+    # the launches of one position; everything position-dependent is read from device memory
+    def _launch(self):
+        at, H, D, T_M = self.attention, self.H, self.D, self.T_M
+        self.k_cache.index_copy_(2, self.idx64, self.k_in)
+        self.v_cache.index_copy_(2, self.idx64, self.v_in)
+        performer_value, avg_rows, _ = ops.performer_step(
+            self.q_in, self.k_in, self.v_in, at.v_eye_learned_causal[0, 0], at.performer.projection_matrix,
+            state_in=self.image, t_base_dev=self.seen32)
+        x, _t, row_scale, avg_scale = ops.predictor_mlp(
+            performer_value, at.attention_predictor_enc[0], at.attention_predictor_enc[1],
+            at.attention_predictor_dec_row[0], at.attention_predictor_cnn[0].module,
+            at.attention_predictor_dec_scaler[0], want_tpred=False)
+        xs = torch.cat([self.win, x], dim=1)                                  # (N, LB + 1, C/8, W, 8)
+        self.win.copy_(xs[:, 1:])
+        keepres, ln2 = at.attention_predictor_cnn[1].module, at.attention_predictor_cnn[2].module
+        body = list(keepres.net.children())
+        y = xs
+        for i in range(0, len(body) - 2, 2):
+            conv = body[i].module
+            y = ops.causal_conv_c8(y, conv.weight, conv.bias, conv.kernel_size, conv.dilation, conv.padding[1], relu=True)
+        conv4 = body[-1].module
+        y_new = y[:, -1:].contiguous()
+        self.probs, _, sel = ops.predictor_tail_select(
+            y_new, conv4.weight[:, :, 0, 0], conv4.bias, ln2.weight, ln2.bias, up=4, T_m=T_M, keep=self.keep_table,
+            k=self.k, T_src=0, is_causal=True, eps=ln2.eps, want_scores=False, t_src_dev=self.tsrc32)
+        csr = ops.csr_from_selection(*sel, H, T_M, self.capacity, self.k, True, self.z_cap, t_src_dev=self.tsrc32)
+        ops.sparse_attention(self.q_in, self.k_cache, self.v_cache, csr,
+                             row_scale=row_scale if at.pconfig.partial_attention_scaler else None,
+                             avg=avg_rows, mix=avg_scale, out=self.ctx.view(self.N, 1, H, D).permute(0, 2, 1, 3),
+                             path="gather")
+        self.seen32 += 1
+        self.tsrc32 += 1
+        self.idx64 += 1
+
+    def _capture(self):
+        """One eager step on a side stream would advance the state, so the capture runs against SAVED copies of the
+        mutable buffers, restored afterwards (a capture records launches, it does not execute them)."""
+        saved = [t.clone() for t in (self.image, self.win, self.k_cache, self.v_cache, self.seen32, self.tsrc32, self.idx64)]
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():                        # warm-up: lazy library work happens outside the capture
+            self._launch()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g), torch.no_grad():
+            self._launch()
+        for dst, src in zip((self.image, self.win, self.k_cache, self.v_cache, self.seen32, self.tsrc32, self.idx64), saved):
+            dst.copy_(src)
+        self.graph = g
+
+    @torch.no_grad()
+    def step(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
+        assert self.length < self.capacity, "cache capacity reached"
+        self.q_in.copy_(q)
+        self.k_in.copy_(k)
+        self.v_in.copy_(v)
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._launch()
+        self.length += 1
+        return self.ctx

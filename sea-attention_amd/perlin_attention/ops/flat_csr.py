@@ -171,9 +171,12 @@ def topk_to_csr(probs: torch.Tensor, keep: torch.Tensor, k: int, target_width: O
 
 @_lib.device_guarded
 def csr_from_selection(bits: torch.Tensor, row_nnz: torch.Tensor, head_off: torch.Tensor, H: int, T_m: int, T_src: int,
-                       k: int, is_causal: bool = True, z_cap: Optional[int] = None, keep: Optional[torch.Tensor] = None):
+                       k: int, is_causal: bool = True, z_cap: Optional[int] = None, keep: Optional[torch.Tensor] = None,
+                       t_src_dev: Optional[torch.Tensor] = None):
     """Row scan + emit: the (bits, row_nnz, head_off) of a selection launch (sea_topk_select or the fused
-    sea_predictor_tail_select) -> FlatCSR.  Two launches, no host sync."""
+    sea_predictor_tail_select) -> FlatCSR.  Two launches, no host sync.
+    Decode form (`sea_csr_emit_at`): `t_src_dev` (one int32 on the device) is the sequence length the row widths follow,
+    `T_src` the FIXED capacity the column ids are encoded with (the FlatCSR says T_src = capacity)."""
     lib = _lib.load()
     N, T_dst = row_nnz.shape
     dev = bits.device
@@ -183,6 +186,12 @@ def csr_from_selection(bits: torch.Tensor, row_nnz: torch.Tensor, head_off: torc
     if z_cap is None:
         z_cap = z_capacity(keep.cpu(), H, T_dst, T_src, T_m, int(k), is_causal)
     col = torch.empty((N, z_cap), dtype=torch.int32, device=dev)
+    if t_src_dev is not None:
+        assert t_src_dev.dtype == torch.int32 and t_src_dev.numel() == 1 and t_src_dev.is_cuda
+        _lib.check(lib.sea_csr_emit_at(
+            _p(bits), _p(crow), N, H, T_dst, T_m, _p(t_src_dev), T_src, int(is_causal), int(k),
+            _p(col), 4, col.stride(0), z_cap, st), "sea_csr_emit_at")
+        return FlatCSR(crow, col, head_off, H, T_src, bits=bits, row_nnz=row_nnz)
     _lib.check(lib.sea_csr_emit(
         _p(bits), _p(crow), _p(head_off), N, H, T_dst, T_m, T_src, int(is_causal), int(k),
         _p(col), 4, col.stride(0), z_cap, None, st), "sea_csr_emit")

@@ -114,9 +114,11 @@ def predictor_tail_select_supported(y: torch.Tensor, H: int, T_m: int) -> bool:
 @_lib.device_guarded
 def predictor_tail_select(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor,
                           up: int, T_m: int, keep: torch.Tensor, k: int, T_src: int, is_causal: bool = True,
-                          eps: float = 1e-5, want_scores: bool = False):
+                          eps: float = 1e-5, want_scores: bool = False, t_src_dev: Optional[torch.Tensor] = None):
     """predictor_tail + grouped top-k selection in one launch.  Returns (probs, scores, (bits, row_nnz, head_off));
-    feed the triple to flat_csr.csr_from_selection.  Bit-identical to predictor_tail followed by topk_to_csr."""
+    feed the triple to flat_csr.csr_from_selection.  Bit-identical to predictor_tail followed by topk_to_csr.
+    Decode form (`sea_predictor_tail_select_at`, a step replayed as a HIP graph): `t_src_dev` is a one-element int32
+    device tensor holding the sequence length (T_src is ignored) and `keep` a table over absolute row indices."""
     lib = _lib.load()
     _lib.require_gpu(y, conv_w, conv_b, ln_w, ln_b, keep)
     if y.dim() == 5:
@@ -127,7 +129,7 @@ def predictor_tail_select(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.T
         N, C, T, W4 = y.shape
     H = conv_w.shape[0]
     assert conv_w.shape == (H, C) and W4 * up == T_m and predictor_tail_select_supported(y, H, T_m)
-    assert keep.dtype == torch.int32 and keep.is_contiguous() and keep.shape in ((T,), (N, T))
+    assert keep.dtype == torch.int32 and keep.is_contiguous() and (t_src_dev is not None or keep.shape in ((T,), (N, T)))
     dt = y.dtype
     Hpad = (H + 7) // 8 * 8
 
@@ -148,6 +150,13 @@ def predictor_tail_select(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.T
     bits = torch.empty((N, T, W), dtype=torch.int32, device=dev)
     row_nnz = torch.empty((N, T), dtype=torch.int32, device=dev)
     head_off = torch.empty((N, T, H + 1), dtype=torch.int32, device=dev)
+    if t_src_dev is not None:
+        assert t_src_dev.dtype == torch.int32 and t_src_dev.numel() == 1 and t_src_dev.is_cuda and keep.ndim == 1
+        _lib.check(lib.sea_predictor_tail_select_at(
+            _p(y), _lib.dtype_code(dt), N, C, H, T, W4, up, T_m, _lib.strides5_blocked(y), _p(cb), _p(w16), Cp, _p(g), _p(b),
+            float(eps), _p(probs), _p(scores), _p(keep), _p(t_src_dev), int(is_causal), int(k),
+            _p(bits), _p(row_nnz), _p(head_off), _lib.stream_ptr()), "sea_predictor_tail_select_at")
+        return probs, scores, (bits, row_nnz, head_off)
     _lib.check(lib.sea_predictor_tail_select(
         _p(y), _lib.dtype_code(dt), N, C, H, T, W4, up, T_m, _lib.strides5_blocked(y), _p(cb), _p(w16), Cp, _p(g), _p(b),
         float(eps), _p(probs), _p(scores), _p(keep), T if keep.ndim == 2 else 0, T_src, int(is_causal), int(k),
@@ -250,11 +259,14 @@ def performer_value(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torc
 
 @_lib.device_guarded
 def performer_step(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torch.Tensor, projection: torch.Tensor,
-                   state_in: torch.Tensor = None, t_base: int = 0, want_avg: bool = True, n_segments: int = 1):
+                   state_in: torch.Tensor = None, t_base: int = 0, want_avg: bool = True, n_segments: int = 1,
+                   t_base_dev: Optional[torch.Tensor] = None):
     """Stateful causal Performer (`sea_performer_causal_step`): q,k,v (N,H,T_new,D) are the NEW rows of sequences
     that have seen `t_base` rows, `state_in` the image a previous call returned (None at t_base = 0), pos the value
     embedding's rows t_base .. t_base+T_new-1.  Returns (performer_value (N,H,T_new,3D), cumulative average of v for
-    the new rows or None, state_out).  Images are opaque fp32 tensors; a new one is returned (the input is kept)."""
+    the new rows or None, state_out).  Images are opaque fp32 tensors; a new one is returned (the input is kept).
+    Decode form (`sea_performer_causal_step_at`, a step replayed as a HIP graph): `t_base_dev` is a one-element int32
+    device tensor holding the rows seen so far, `pos` the WHOLE embedding table, and `state_in` is updated in place."""
     lib = _lib.load()
     _lib.require_gpu(q, k, v, pos, projection)
     N, H, T, D = q.shape
@@ -269,10 +281,14 @@ def performer_step(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torch
     proj = _cached("proj", (projection,), q.dtype, lambda: projection.to(q.dtype).float().contiguous())
     sb = int(lib.sea_performer_state_bytes(N, H, D, nb, _lib.dtype_code(q.dtype)))
     assert sb > 0, "unsupported head size / feature count"
-    assert (state_in is None) == (t_base == 0), "a state image goes with the number of rows it has seen"
+    if t_base_dev is not None:
+        assert t_base_dev.dtype == torch.int32 and t_base_dev.numel() == 1 and t_base_dev.is_cuda
+        assert state_in is not None and t_base == 0 and n_segments == 1
+    else:
+        assert (state_in is None) == (t_base == 0), "a state image goes with the number of rows it has seen"
     if state_in is not None:
         assert state_in.dtype == torch.float32 and state_in.numel() * 4 == sb and state_in.is_contiguous()
-    state_out = torch.empty((sb // 4,), dtype=torch.float32, device=q.device)
+    state_out = state_in if t_base_dev is not None else torch.empty((sb // 4,), dtype=torch.float32, device=q.device)
     out = torch.empty((N, H, T, 3 * D), dtype=q.dtype, device=q.device)
     avg = None
     if want_avg:
@@ -283,6 +299,12 @@ def performer_step(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torch
         one_pair = performer_plan(1, 1, 4096, D, nb, q.dtype)
         ws_bytes = N * H * (n_segments - 1) * (one_pair[1] // (one_pair[0] - 1))
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=q.device)
+    if t_base_dev is not None:
+        _lib.check(lib.sea_performer_causal_step_at(
+            _p(q), _p(k), _p(v), _p(pos), _lib.dtype_code(q.dtype), _p(proj), N, H, T, D, nb, _lib.strides3(q), _lib.strides3(k),
+            _lib.strides3(v), pos.stride(0), _p(out), _p(avg), _p(state_in), _p(state_out), sb, _p(t_base_dev),
+            _lib.stream_ptr()), "sea_performer_causal_step_at")
+        return out, avg, state_out
     _lib.check(lib.sea_performer_causal_step(
         _p(q), _p(k), _p(v), _p(pos), _lib.dtype_code(q.dtype), _p(proj), N, H, T, D, nb, _lib.strides3(q), _lib.strides3(k),
         _lib.strides3(v), pos.stride(0), _p(out), _p(avg), _p(state_in), _p(state_out), sb, int(t_base), int(n_segments),

@@ -1,0 +1,92 @@
+"""-m gpu: the graph-replayed decode step (perlin_attention/decode.py; SURVEY 8f-3, the generation loop of
+src/main/opt_generate.py:131).  `DecodeSession.step` must give, position by position, bitwise the context rows of the
+cached forward (`_forward_cached`, itself held to the stateless forward by test_kv_cache.py) -- eagerly launched and as a
+replayed HIP graph -- while nothing position-dependent travels in kernel arguments."""
+import pytest
+import torch
+
+import sea_attention_amd as S
+from sea_attention_amd.perlin_attention import PerlinAttentionConfig, PerlinSelfAttention
+from sea_attention_amd.perlin_attention.decode import DecodeSession
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+class Cfg:
+    def __init__(self, hidden, heads, max_pos):
+        self.hidden_size, self.num_attention_heads, self.max_position_embeddings = hidden, heads, max_pos
+
+
+def _mask(N, T_dst, T_src, dtype):
+    fp_min = torch.finfo(torch.float16).min / 2
+    rows = torch.arange(T_src - T_dst, T_src, device=DEV).view(T_dst, 1)
+    m = ((torch.arange(T_src, device=DEV).view(1, T_src) > rows) * fp_min).view(1, 1, T_dst, T_src)
+    return m.expand(N, 1, T_dst, T_src).contiguous().to(dtype)
+
+
+def _layer(H, d, T_M, k, T, dtype):
+    S.seed(42)
+    pc = PerlinAttentionConfig(k=k, attention_predictor_length=T_M, performer_nb_factor=8, causal=True, k_flatten=True,
+                               k_flatten_dim='causal_batch', context_output_method='mix', use_cache=True)
+    layer = PerlinSelfAttention(Cfg(H * d, H, T), pc).to(DEV).to(dtype).eval()
+    for m in layer.modules():
+        if hasattr(m, 'benchmarking'):
+            m.benchmarking = True
+    layer.attention.context_layer_dtype = dtype
+    return layer
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("dtype,N,H,d,T0,steps", [(torch.bfloat16, 2, 8, 64, 250, 14),     # crosses T_M = 256: pixel widths 1 -> 2
+                                                  (torch.float16, 1, 4, 64, 40, 6),
+                                                  (torch.bfloat16, 1, 8, 128, 300, 5),
+                                                  (torch.bfloat16, 1, 4, 80, 63, 4)])       # crosses a Performer chunk boundary
+def test_session_steps_equal_cached_forward(dtype, N, H, d, T0, steps, use_graph):
+    T_M, k = 256, 16
+    T = T0 + steps
+    layer = _layer(H, d, T_M, k, T + 3, dtype)
+    S.seed(9)
+    x = torch.randn((N, H, T, d), device=DEV).to(dtype)
+    q = (x.float() * d ** -0.5).to(dtype)
+    with torch.no_grad():
+        out = layer(None, None, None, query_layer=q[:, :, :T0], key_layer=x[:, :, :T0], value_layer=x[:, :, :T0],
+                    attention_mask=_mask(N, T0, T0, dtype))
+        state = out.state
+        sess = DecodeSession(layer.attention, state, x[:, :, :T0], x[:, :, :T0], capacity=T + 3, use_graph=use_graph)
+        assert (sess.graph is not None) == use_graph
+        for i in range(steps):
+            hi = T0 + i + 1
+            ref = layer(None, None, None, query_layer=q[:, :, hi - 1:hi], key_layer=x[:, :, :hi], value_layer=x[:, :, :hi],
+                        attention_mask=_mask(N, 1, hi, dtype), last_state=state)
+            state = ref.state
+            got = sess.step(q[:, :, hi - 1:hi], x[:, :, hi - 1:hi], x[:, :, hi - 1:hi])
+            assert got.shape == ref.context_layer.shape == (N, 1, H * d)
+            assert torch.isfinite(got.float()).all()
+            assert torch.equal(got, ref.context_layer), (i, (got.float() - ref.context_layer.float()).abs().max().item())
+            assert torch.equal(sess.probs, ref.estimated_attention_probs_m), i
+        assert sess.length == T and int(sess.seen32.item()) == T and int(sess.tsrc32.item()) == T + 1
+        # the in-place state is the state the cached forward carries
+        from sea_attention_amd.perlin_attention.attention_state import PerlinAttentionState as PS
+        assert torch.equal(sess.image, state.states[PS.PERFORMER].image)
+        assert torch.equal(sess.win, state.states[PS.CNN].rows_c8)
+        assert torch.equal(sess.k_cache[:, :, :T], x) and torch.equal(sess.v_cache[:, :, :T], x)
+
+
+def test_session_refuses_what_it_cannot_continue():
+    dtype, N, H, d, T_M, k = torch.bfloat16, 1, 4, 64, 256, 16
+    layer = _layer(H, d, T_M, k, 64, dtype)
+    x = torch.randn((N, H, 40, d), device=DEV).to(dtype)
+    with torch.no_grad():
+        out = layer(None, None, None, query_layer=x[:, :, :4], key_layer=x[:, :, :4], value_layer=x[:, :, :4], attention_mask=_mask(N, 4, 4, dtype))
+        with pytest.raises(AssertionError, match="reach"):                # prefix shorter than the CNN's lookback
+            DecodeSession(layer.attention, out.state, x[:, :, :4], x[:, :, :4], capacity=32, use_graph=False)
+        out = layer(None, None, None, query_layer=x, key_layer=x, value_layer=x, attention_mask=_mask(N, 40, 40, dtype))
+        with pytest.raises(AssertionError, match="capacity"):
+            DecodeSession(layer.attention, out.state, x, x, capacity=40, use_graph=False)
+        with pytest.raises(AssertionError, match="exactly the prefix"):
+            DecodeSession(layer.attention, out.state, x[:, :, :30], x[:, :, :30], capacity=64, use_graph=False)
+        sess = DecodeSession(layer.attention, out.state, x, x, capacity=41, use_graph=False)
+        sess.step(x[:, :, :1], x[:, :, :1], x[:, :, :1])
+        with pytest.raises(AssertionError, match="capacity reached"):
+            sess.step(x[:, :, :1], x[:, :, :1], x[:, :, :1])
