@@ -102,6 +102,10 @@ def main():
     ap.add_argument("--sparse-kernel", default="auto", choices=["auto", "gather", "tile"],
                     help="kernel of steps J-L (sea_sparse_attention_ex path)")
     ap.add_argument("--no-output-check", action="store_true")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > 1 on a ONE-GPU box: every rank uses cuda:0 and the process group runs on gloo -- exercises the "
+                         "multi-rank code path of this script (shards, graph capture beside a process group, pipelined gather, "
+                         "max-over-ranks timing); its numbers mean nothing")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -110,8 +114,10 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.rehearse:
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group("gloo" if args.rehearse else "nccl", rank=rank, world_size=world)
     assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs the MI355X"
     dev = torch.device("cuda", local_rank if world > 1 else 0)
     torch.cuda.set_device(dev)
@@ -305,7 +311,9 @@ def main():
         if os.path.exists(tp):
             try:
                 rec = json.load(open(tp))
-                if rec.get("kernel_source_sha256") == _attn_source_sha():
+                if rec.get("kernel_source_sha256") == _attn_source_sha() and rec.get("nnz") != Z:
+                    traffic_note = "profiles/traffic_latest.json was taken on another workload (entry count differs): not reported"
+                elif rec.get("kernel_source_sha256") == _attn_source_sha():
                     traffic = rec.get("sea_sparse_attention_hbm_bytes_per_launch")
                     traffic_note = rec.get("note", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command")
                 else:
