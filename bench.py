@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--sparse-kernel", default="auto", choices=["auto", "gather", "tile"],
                     help="kernel of steps J-L (sea_sparse_attention_ex path)")
     ap.add_argument("--no-output-check", action="store_true")
+    ap.add_argument("--decode-steps", type=int, default=32, help="positions of the generation leg after the timed steps (0: skip)")
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on a ONE-GPU box: every rank uses cuda:0 and the process group runs on gloo -- exercises the "
                          "multi-rank code path of this script (shards, graph capture beside a process group, pipelined gather, "
@@ -385,6 +386,35 @@ def main():
                                              "algorithmic_GBs_auto": round(ops.sparse_attention_bytes(Zs, NB, H, T, d, esz) / (times["auto"] / 1e3) / 1e9, 1),
                                              "note": "auto = plan kernel + both gated launches (what the layer runs)"}
 
+    # ---- generation leg: one position per step from a (T - 64)-token prefix, the step replayed as a HIP graph
+    decode = None
+    if args.decode_steps > 0 and world == 1 and dtype != torch.float32:
+        try:
+            import copy
+            from sea_attention_amd.perlin_attention.decode import DecodeSession
+            lc_ = copy.deepcopy(layer)
+            lc_.pconfig = copy.copy(layer.pconfig); lc_.pconfig.use_cache = True
+            lc_.attention.pconfig = lc_.pconfig
+            T0 = T - 64
+            with torch.no_grad():
+                pre = lc_(None, None, None, query_layer=q[:, :, :T0], key_layer=kk[:, :, :T0], value_layer=v[:, :, :T0],
+                          attention_mask=mask[:, :, :T0, :T0].contiguous())
+                sess = DecodeSession(lc_.attention, pre.state, kk[:, :, :T0], v[:, :, :T0], capacity=T, use_graph=True)
+                nd = min(args.decode_steps, 60)
+                for i in range(4):
+                    sess.step(q[:, :, T0 + i:T0 + i + 1], kk[:, :, T0 + i:T0 + i + 1], v[:, :, T0 + i:T0 + i + 1])
+                torch.cuda.synchronize(); t0_ = time.perf_counter()
+                for i in range(4, 4 + nd):
+                    sess.step(q[:, :, T0 + i:T0 + i + 1], kk[:, :, T0 + i:T0 + i + 1], v[:, :, T0 + i:T0 + i + 1])
+                torch.cuda.synchronize()
+                t_pos = (time.perf_counter() - t0_) / nd
+            decode = {"ms_per_position": round(t_pos * 1e3, 4), "tokens_per_s": round(NB / t_pos, 1), "prefix_tokens": T0,
+                      "positions_timed": nd, "note": "DecodeSession: fixed-capacity caches, position in device memory, "
+                      "the step's launches replayed as one HIP graph; all sequences of the batch advance together"}
+            del sess, lc_, pre
+        except Exception as e:                                   # an extra leg never takes the headline line down
+            decode = {"error": f"{type(e).__name__}: {e}"[:200]}
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline(w, args.cpu_seqs)
@@ -429,7 +459,7 @@ def main():
                                       else ", eager launches"),
                        "global_batch": NB * world, "seq_len": T, "parallelism": f"dp{world} (batch shards)"},
             "roofline": roof, "cpu_baseline": cpu, "output_check": output_check, "kernel_path": kernel_path,
-            "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 3),
+            "decode": decode, "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 3),
             "regions_ms": {k_: round(v_ * 1e3, 4) for k_, v_ in sorted(regions.items())},
         }
         print(json.dumps(line))
