@@ -102,7 +102,9 @@ def main():
     ap.add_argument("--sparse-kernel", default="auto", choices=["auto", "gather", "tile"],
                     help="kernel of steps J-L (sea_sparse_attention_ex path)")
     ap.add_argument("--no-output-check", action="store_true")
-    ap.add_argument("--decode-steps", type=int, default=32, help="positions of the generation leg after the timed steps (0: skip)")
+    ap.add_argument("--decode-steps", type=int, default=0,
+                    help="positions of the generation leg after the timed steps (off by default: its one-row launches share kernel "
+                         "names with the layer's and would dilute a profiler's per-kernel averages of the default command)")
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on a ONE-GPU box: every rank uses cuda:0 and the process group runs on gloo -- exercises the "
                          "multi-rank code path of this script (shards, graph capture beside a process group, pipelined gather, "

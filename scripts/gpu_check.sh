@@ -16,5 +16,5 @@ rm -f gpurun_out/progress.log
 run smoke 300 python -c "import __graft_entry__ as g; g.smoke()"; tail -3 gpurun_out/smoke.log
 run pytest_gpu 1000 python -m pytest tests -m gpu -q -x --timeout 600 ${PYTEST_EXTRA:-}; tail -25 gpurun_out/pytest_gpu.log
 if [ "${SKIP_BENCH:-0}" != "1" ]; then
-  run bench 600 python bench.py --steps ${BENCH_STEPS:-10} --warmup 3 ${BENCH_EXTRA:-}; tail -5 gpurun_out/bench.log
+  run bench 600 python bench.py --steps ${BENCH_STEPS:-10} --warmup 3 --decode-steps 32 ${BENCH_EXTRA:-}; tail -5 gpurun_out/bench.log
 fi
