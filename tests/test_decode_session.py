@@ -90,3 +90,26 @@ def test_session_refuses_what_it_cannot_continue():
         sess.step(x[:, :, :1], x[:, :, :1], x[:, :, :1])
         with pytest.raises(AssertionError, match="capacity reached"):
             sess.step(x[:, :, :1], x[:, :, :1], x[:, :, :1])
+
+
+def test_session_with_the_deeper_predictor_cnn(monkeypatch):
+    """PERLIN_HOTFIX_OPT_DEEPER=1 builds three dilated convolutions (12-row reach): the session's window follows."""
+    monkeypatch.setenv("PERLIN_HOTFIX_OPT_DEEPER", "1")
+    dtype, N, H, d, T_M, k, T0, steps = torch.bfloat16, 1, 4, 64, 256, 16, 30, 5
+    layer = _layer(H, d, T_M, k, T0 + steps + 2, dtype)
+    S.seed(3)
+    x = torch.randn((N, H, T0 + steps, d), device=DEV).to(dtype)
+    q = (x.float() * d ** -0.5).to(dtype)
+    with torch.no_grad():
+        out = layer(None, None, None, query_layer=q[:, :, :T0], key_layer=x[:, :, :T0], value_layer=x[:, :, :T0],
+                    attention_mask=_mask(N, T0, T0, dtype))
+        state = out.state
+        sess = layer.attention.decode_session(state, x[:, :, :T0], x[:, :, :T0], capacity=T0 + steps + 1)
+        assert sess.win.shape[1] == 12
+        for i in range(steps):
+            hi = T0 + i + 1
+            ref = layer(None, None, None, query_layer=q[:, :, hi - 1:hi], key_layer=x[:, :, :hi], value_layer=x[:, :, :hi],
+                        attention_mask=_mask(N, 1, hi, dtype), last_state=state)
+            state = ref.state
+            got = sess.step(q[:, :, hi - 1:hi], x[:, :, hi - 1:hi], x[:, :, hi - 1:hi])
+            assert torch.equal(got, ref.context_layer), i
