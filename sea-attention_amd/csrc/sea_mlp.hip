@@ -20,9 +20,6 @@
 // the conv kernels (channel = head*S + split); optionally the encoder output; the two sigmoid gates.
 #include "sea_common.hpp"
 
-#ifndef SEA_EXP
-#define SEA_EXP 0
-#endif
 
 namespace sea {
 
@@ -193,10 +190,8 @@ void predictor_mlp_kernel(MlpParams p) {
         const float4 e = *reinterpret_cast<const float4*>(sE1 + i * 16 + lg * 4);
         float o[4] = {(acc1[i][0] - mean) * rstd * g.x + e.x, (acc1[i][1] - mean) * rstd * g.y + e.y,
                       (acc1[i][2] - mean) * rstd * g.z + e.z, (acc1[i][3] - mean) * rstd * g.w + e.w};
-#if SEA_EXP != 21
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r]);                     // nn.GELU(): erf form
-#endif
         const uint32_t p0 = pack2<T>(o[0], o[1]), p1 = pack2<T>(o[2], o[3]);
         if (i & 1) { tb[i >> 1].z = p0; tb[i >> 1].w = p1; } else { tb[i >> 1].x = p0; tb[i >> 1].y = p1; }
         __builtin_amdgcn_sched_barrier(0);   // one tile's erf chains at a time: interleaving all 32 blows the register file

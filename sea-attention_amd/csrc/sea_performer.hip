@@ -17,9 +17,6 @@
 // 4g+r of lane group g -- the B operand of the carry term phi(Q_c) S, with the k index of that product
 // permuted accordingly on the A side.  All products run on v_mfma_f32_16x16x4_f32 (exact fp32).
 #include "sea_common.hpp"
-#ifndef SEA_EXP
-#define SEA_EXP 0
-#endif
 #include <cstdlib>
 #include <type_traits>
 
@@ -637,13 +634,13 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   for (int t0 = t_begin; t0 < t_end; t0 += C) {
     const int rows = min(C, t_end - t0);
     // ---- (a) staging ---------------------------------------------------------------------------------
-    if (!STATE_ONLY && SEA_EXP != 32 && SEA_EXP != 31) __builtin_amdgcn_raw_buffer_store_b128(pv, ro, sr < rows ? ((t0 + sr) * (3 * D) + 2 * D + sc * 8) * 2 : (int)OOB, 0, 0);
+    if (!STATE_ONLY) __builtin_amdgcn_raw_buffer_store_b128(pv, ro, sr < rows ? ((t0 + sr) * (3 * D) + 2 * D + sc * 8) * 2 : (int)OOB, 0, 0);
     *reinterpret_cast<bu4*>(sQ + (sc * C + sr) * 8) = pq;
     *reinterpret_cast<bu4*>(sK + (sc * C + sr) * 8) = pk;
     *reinterpret_cast<bu4*>(sV + sr * E + vchunk(sr, sc) * 8) = pp;
     *reinterpret_cast<bu4*>(sV + sr * E + vchunk(sr, D / 8 + sc) * 8) = pv;
-    if (!STATE_ONLY && t0 > t_begin && SEA_EXP != 31) flush_out(t0 - C, C);      // (block-uniform)
-    if (SEA_EXP != 33) issue_loads(t0 + C);                                   // rows beyond T come back as zeros
+    if (!STATE_ONLY && t0 > t_begin) flush_out(t0 - C, C);                     // (block-uniform)
+    issue_loads(t0 + C);                                                      // rows beyond T come back as zeros
     __syncthreads();
     PSTAMP(0);   // (a) staging
 

@@ -17,9 +17,6 @@
 #include "sea_common.hpp"
 #include "sea_tail.hpp"
 
-#ifndef SEA_EXP
-#define SEA_EXP 0
-#endif
 
 #ifdef SEA_STAMP
 __device__ unsigned long long sea_dbg[16];
@@ -238,11 +235,7 @@ __device__ __forceinline__ void select_body(const TopkParams& p, uint32_t (&key)
   if (tid == 0) s_ncand = 0;
 
   if (!FROM_MASK) {
-#if SEA_EXP == 1
-    const int K = p.M;   // ablation: skip the selection
-#else
     const int K = p.keep[n * p.keep_stride_n + t + (p.t_src_dev ? *p.t_src_dev - p.T_dst : 0)];
-#endif
     if (K >= p.M) {
 #pragma unroll
       for (int j = 0; j < R; ++j)
@@ -376,7 +369,6 @@ __device__ __forceinline__ void select_body(const TopkParams& p, uint32_t (&key)
   }
   // entries each kept pixel will emit: min(v_end - v_start, max_k), accumulated per head.  Only kept pixels
   // are visited (a row keeps ~K_t << H*T_m of them once t is large).
-#if SEA_EXP != 2
   {
     unsigned long long m = sel;
     while (m) {
@@ -389,7 +381,6 @@ __device__ __forceinline__ void select_body(const TopkParams& p, uint32_t (&key)
       if (w > 0) atomicAdd(&s_head[h], w);
     }
   }
-#endif
   __syncthreads();
   STAMP(4);   // bit mask + widths + head counts
   // exclusive scan over heads (first wave, 64 heads per step)
@@ -589,7 +580,6 @@ __global__ __launch_bounds__(TK_THREADS) void csr_emit_kernel(EmitParams p) {
     }
     int total;
     const int excl = block_excl_scan(nent, s_wave, &total);
-#if SEA_EXP != 11
     // windows of the row covered by this pass: [carry, carry + total)
     for (int win = (carry / EM_WIN) * EM_WIN; win < carry + total; win += EM_WIN) {
       int off = carry + excl;                                       // row-relative offset of this thread's first entry
@@ -627,7 +617,6 @@ __global__ __launch_bounds__(TK_THREADS) void csr_emit_kernel(EmitParams p) {
         }
       }
       __syncthreads();
-#if SEA_EXP != 12
       // flush the part of the window this pass has completed: [max(win, carry), min(win + EM_WIN, carry + total))
       const int fb = win > carry ? win : carry;
       const int fe = (win + EM_WIN < carry + total) ? win + EM_WIN : carry + total;
@@ -638,10 +627,8 @@ __global__ __launch_bounds__(TK_THREADS) void csr_emit_kernel(EmitParams p) {
           if (vals) vals[dst] = 1.0f;
         }
       }
-#endif
       __syncthreads();
     }
-#endif
     carry += total;
   }
 }
