@@ -24,6 +24,7 @@ import torch
 from torch import nn
 
 from .perlin_attention import PerlinAttentionConfig, PerlinSelfAttention, get_default_config, register_default_config
+from .perlin_attention.decode import SessionState
 from .perlin_attention.lora import LoraLinear, lora_forward
 
 # flag, argparse kwargs, keyword the trainer constructor receives (perlin_trainer.py:41-87); `None` defaults are
@@ -139,6 +140,10 @@ class SeaOPTAttention(nn.Module):
         self.last_perlin_output = None
         self.checkout_perlin_output = False
         self._benchmarking = False
+        # opt-in fast generation: one-token calls that continue a cache run as a replayed HIP graph with room for this many
+        # tokens per sequence (None: every call takes the regular cached forward)
+        self.decode_graph_capacity: Optional[int] = None
+        self._decode_session = None
 
     # the reference flips `benchmarking` on every attention module of the model to select the sparse path
     @property
@@ -153,6 +158,34 @@ class SeaOPTAttention(nn.Module):
     def _heads(self, x: torch.Tensor) -> torch.Tensor:
         n, t, _ = x.shape
         return x.view(n, t, self.num_heads, self.head_dim).transpose(1, 2).contiguous()
+
+    def _graph_decode_step(self, q, k_new, v_new, past_key_value, output_attentions):
+        """Opt-in (`decode_graph_capacity` tokens): a ONE-token call that continues a cached sequence runs as a replayed
+        HIP graph (perlin_attention/decode.py).  The first such call after a prefill builds the session from the tuple's
+        K / V and `PerlinAttentionState`; later calls must bring back the ticket the previous one returned.  Returns the
+        forward's triple, or None when the call is not a step this path serves (the caller falls back)."""
+        cap = self.decode_graph_capacity
+        if (not cap or len(past_key_value) < 3 or q.shape[2] != 1 or self.training or output_attentions
+                or not self.is_decoder or self.pconfig.lora_enabled or self.teacher_context_layer is not None):
+            return None
+        state, sess = past_key_value[2], self._decode_session
+        if isinstance(state, SessionState):
+            if not (state.session is sess and state.current):
+                return None                                   # a stale / foreign ticket: materialize() decides in the caller
+        else:
+            try:
+                sess = self.perlin_self_attention.attention.decode_session(state, past_key_value[0], past_key_value[1], cap)
+            except AssertionError:                            # shapes / dtype / prefix the session does not cover
+                return None
+            self._decode_session = sess
+        if sess.length >= sess.capacity:
+            return None
+        ctx = sess.step(q, k_new, v_new)
+        L = sess.length
+        dtype = self.q_proj.weight.dtype
+        y = self.out_proj(ctx if ctx.dtype == dtype else ctx.to(dtype))
+        self.last_loss = 0
+        return y, None, (sess.k_cache[:, :, :L], sess.v_cache[:, :, :L], SessionState(sess))
 
     def forward(self, hidden_states: torch.Tensor, key_value_states=None,
                 past_key_value: Optional[Tuple[torch.Tensor, ...]] = None, attention_mask: Optional[torch.Tensor] = None,
@@ -172,9 +205,14 @@ class SeaOPTAttention(nn.Module):
         k, v = self._heads(self.k_proj(hidden_states)), self._heads(self.v_proj(hidden_states))
         state = None
         if past_key_value is not None:
+            fast = self._graph_decode_step(q, k, v, past_key_value, output_attentions)
+            if fast is not None:
+                return fast
+            state = past_key_value[2] if len(past_key_value) > 2 else None
+            if isinstance(state, SessionState):              # a call the session cannot serve: continue from a real state
+                state = state.materialize()
             k = torch.cat([past_key_value[0], k], dim=2)
             v = torch.cat([past_key_value[1], v], dim=2)
-            state = past_key_value[2] if len(past_key_value) > 2 else None
         present = (k, v) if self.is_decoder else None
 
         truth = self.teacher_context_layer

@@ -130,6 +130,20 @@ class DecodeSession:
             dst.copy_(src)
         self.graph = g
 
+    def export_state(self) -> PerlinAttentionState:
+        """The session's state as the `PerlinAttentionState` a cached forward continues from (copies: the session keeps
+        running on its own buffers)."""
+        from .attention_state import PerformerState, CnnWindowState, CumAvgState
+        st = PerlinAttentionState(self.attention)
+        ps = PerformerState()
+        ps.image, ps.seq_index = self.image.clone(), self.length
+        cs = CnnWindowState(self.win.shape[1])
+        cs.rows_c8 = self.win.clone()
+        cav = CumAvgState()
+        cav.prev_len, cav.in_image = self.length, True
+        st.states = {PerlinAttentionState.PERFORMER: ps, PerlinAttentionState.CNN: cs, PerlinAttentionState.CUMAVG: cav}
+        return st
+
     @torch.no_grad()
     def step(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
         assert self.length < self.capacity, "cache capacity reached"
@@ -142,3 +156,21 @@ class DecodeSession:
             self._launch()
         self.length += 1
         return self.ctx
+
+
+class SessionState:
+    """What a graph-replayed step hands back in the place of a `PerlinAttentionState` (e.g. as the third element of the
+    OPT block's cache tuple): a ticket for the NEXT step of the same session.  It is valid while the session has not moved
+    on; `materialize()` turns it into a real state for a call the session cannot serve (several tokens at once)."""
+
+    def __init__(self, session: DecodeSession):
+        self.session = session
+        self.seq_len = session.length
+
+    @property
+    def current(self) -> bool:
+        return self.session.length == self.seq_len
+
+    def materialize(self) -> PerlinAttentionState:
+        assert self.current, "this decode state is stale: its session has produced later positions (sessions cannot branch)"
+        return self.session.export_state()

@@ -158,3 +158,50 @@ def test_block_decodes_through_its_cache_tuple(restore_default):
     got = torch.cat(rows, dim=1)
     assert past[0].shape[2] == T and past[2].seq_len == T
     assert (got - full).abs().max().item() < 2e-4 * max(1.0, full.abs().max().item())
+
+
+@pytest.mark.gpu
+def test_block_generates_through_the_graph_replayed_session(restore_default):
+    """`decode_graph_capacity` (opt-in): the one-token calls of a generation loop run as a replayed HIP graph and return the
+    rows -- and a cache tuple of the same shapes -- the regular cached forward returns, bit for bit; a several-token call in
+    the middle falls back (the ticket is turned into a real state) and the next single token opens a new session."""
+    from sea_attention_amd.perlin_attention.decode import SessionState
+    dev, dtype = "cuda", torch.bfloat16
+    cfg = P.perlin_config_from_options(perlin_k=16, perlin_predictor_length=256, perlin_performer_nb_feature_factor=8,
+                                       perlin_context_output_method="mix")
+    cfg.use_cache = True
+    torch.manual_seed(5)
+    blk = P.SeaOPTAttention(4 * 64, 4, max_position_embeddings=160).to(dev, dtype).eval()
+    blk.benchmarking = True
+    blk.perlin_self_attention.attention.context_layer_dtype = dtype
+    N, T0 = 2, 100
+    plan = [1, 1, 1, 3, 1, 1]                                        # tokens per call after the prefill
+    T = T0 + sum(plan)
+    x = torch.randn(N, T, 4 * 64, device=dev, dtype=dtype)
+
+    def run(capacity):
+        blk.decode_graph_capacity, blk._decode_session = capacity, None
+        rows, kinds = [], []
+        with torch.no_grad():
+            y, _, past = blk(x[:, :T0], attention_mask=P.causal_additive_mask(N, T0, T0, dtype, dev))
+            rows.append(y)
+            pos = T0
+            for n_new in plan:
+                y, _, past = blk(x[:, pos:pos + n_new], past_key_value=past,
+                                 attention_mask=P.causal_additive_mask(N, n_new, pos + n_new, dtype, dev))
+                pos += n_new
+                rows.append(y.clone())
+                kinds.append(isinstance(past[2], SessionState))
+                assert past[0].shape == (N, 4, pos, 64) and past[1].shape == (N, 4, pos, 64) and past[2].seq_len == pos
+        return torch.cat(rows, dim=1), kinds, past
+
+    ref, kinds_ref, _ = run(None)
+    got, kinds, past = run(T + 4)
+    assert kinds_ref == [False] * len(plan)
+    assert kinds == [True, True, True, False, True, True]             # the 3-token call falls back, the next token re-opens
+    assert torch.equal(got, ref)
+    with torch.no_grad():                                            # a stale ticket (the session has moved on) is refused
+        stale = past
+        _, _, past = blk(x[:, :1], past_key_value=past, attention_mask=P.causal_additive_mask(N, 1, T + 1, dtype, dev))
+        with pytest.raises(AssertionError, match="stale"):
+            blk(x[:, :1], past_key_value=stale, attention_mask=P.causal_additive_mask(N, 1, T + 1, dtype, dev))
