@@ -141,14 +141,23 @@ __device__ __forceinline__ void tail_consts_fill(const TailParams& p, uint32_t* 
   const T* bet = reinterpret_cast<const T*>(p.beta);
   const bool up_pow2 = (p.UP & (p.UP - 1)) == 0;            // block-uniform; x4 in every configuration the reference builds
   const int up_sh = __ffs(p.UP) - 1;
+  const bool tm_pow2 = (p.T_M & (p.T_M - 1)) == 0 && (int64_t)(p.T_M + 1) * Wp < (1 << 24);   // block-uniform
+  const int tm_sh = __ffs(p.T_M) - 1;
   for (int j = threadIdx.x; j < TMP; j += blockDim.x) {
     uint32_t pk = (uint32_t)(p.W4 + 1) * 0x100401u;         // three unused taps, count 0
     float g = 0.f, be = 0.f;
     if (j < p.T_M) {
       g = Elem<T>::to_f(gam[j]); be = Elem<T>::to_f(bet[j]);
-      // adaptive-average-pool window of output pixel j over the Wp padded pixels (ATen's float formula)
-      const int xs = (int)floorf((float)(j * Wp) / (float)p.T_M);
-      const int xe = (int)ceilf((float)((j + 1) * Wp) / (float)p.T_M);
+      // adaptive-average-pool window of output pixel j over the Wp padded pixels (ATen's float formula; dividing an
+      // integer below 2^24 by a power of two is exact in fp32, so for those T_M the floor / ceil are plain shifts)
+      int xs, xe;
+      if (tm_pow2) {
+        xs = (j * Wp) >> tm_sh;
+        xe = ((j + 1) * Wp + p.T_M - 1) >> tm_sh;
+      } else {
+        xs = (int)floorf((float)(j * Wp) / (float)p.T_M);
+        xe = (int)ceilf((float)((j + 1) * Wp) / (float)p.T_M);
+      }
       pk = (uint32_t)(xe - xs) << 30;                       // launcher: Wp <= 3 * T_M, so 1..3 taps
 #pragma unroll
       for (int k = 0; k < 3; ++k) {
