@@ -60,9 +60,9 @@ def build_library(force=False, extra_flags=(), out=None, verbose=False):
     out = out or LIB_PATH
     if not force and out == LIB_PATH and not is_stale():
         return out
-    os.makedirs(OBJ_DIR, exist_ok=True)
     cc = _hipcc()
     custom = bool(extra_flags) or out != LIB_PATH          # A/B builds keep the product's objects
+    os.makedirs(os.path.join(OBJ_DIR, "custom") if custom else OBJ_DIR, exist_ok=True)
 
     hdr_bytes = b"".join(open(h, "rb").read() for h in HEADERS)
 
@@ -70,7 +70,9 @@ def build_library(force=False, extra_flags=(), out=None, verbose=False):
         flags = [*COMMON_FLAGS, *FILE_FLAGS.get(src, []), *extra_flags]
         key = hashlib.sha256(open(os.path.join(CSRC, src), "rb").read() + hdr_bytes + repr(flags).encode()).hexdigest()[:16]
         stem = os.path.splitext(src)[0]
-        obj = os.path.join(OBJ_DIR, f"{stem}.{key}.o")      # content-addressed: a reused object IS this source + flags
+        # content-addressed: a reused object IS this source + flags.  A/B builds (extra flags / another output) keep their
+        # objects apart, in a directory that neither git nor the gpurun snapshot carries
+        obj = os.path.join(os.path.join(OBJ_DIR, "custom") if custom else OBJ_DIR, f"{stem}.{key}.o")
         if os.path.exists(obj) and not force:
             return obj
         tmp_o = obj + f".tmp.{os.getpid()}"
