@@ -491,3 +491,25 @@ def test_cumavg_sliced(ops, dtype, N, H, T, D):
         out = torch.empty_like(v)
         _lib.check(_lib.load().sea_cumavg_sliced(v.data_ptr(), _lib.dtype_code(dtype), N, H, T, D, _lib.strides3(v), out.data_ptr(),
                                                  4, None, 0, None), "sea_cumavg_sliced")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,T,D", [(2, 3, 300, 64), (1, 4, 257, 80), (2, 2, 190, 128)])
+def test_performer_takes_head_interleaved_views(ops, dtype, N, H, T, D):
+    """q / k / v as the model hands them over -- (N, T, H, D) projections viewed as (N, H, T, D), i.e. a row stride of H*D --
+    give bitwise the result of contiguous copies (the kernels address through the three strides), average output included."""
+    import math
+    from sea_attention_amd.perlin_attention.performer import FastAttention
+    torch.manual_seed(13)
+    nb = int(D * math.log(D) / 8)
+    fa = FastAttention(D, nb_features=nb, causal=True, generalized_attention=True).to(DEV)
+    base = [torch.randn(N, T, H, D, device=DEV).to(dtype) for _ in range(3)]
+    base[0] = (base[0].float() * D ** -0.5).to(dtype)
+    qv, kv, vv = (b.permute(0, 2, 1, 3) for b in base)                 # views: strides (T*H*D, D, H*D, 1)
+    assert not qv.is_contiguous()
+    pos = torch.randn(T, D, device=DEV).to(dtype)
+    a, a_avg = ops.performer_value(qv, kv, vv, pos, fa.projection_matrix, want_avg=True)
+    b, b_avg = ops.performer_value(qv.contiguous(), kv.contiguous(), vv.contiguous(), pos, fa.projection_matrix, want_avg=True)
+    assert torch.equal(a, b) and torch.equal(a_avg, b_avg)
+    assert torch.equal(a[..., 2 * D:], vv)
