@@ -635,8 +635,10 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
     const int rows = min(C, t_end - t0);
     // ---- (a) staging ---------------------------------------------------------------------------------
     if (!STATE_ONLY) __builtin_amdgcn_raw_buffer_store_b128(pv, ro, sr < rows ? ((t0 + sr) * (3 * D) + 2 * D + sc * 8) * 2 : (int)OOB, 0, 0);
-    *reinterpret_cast<bu4*>(sQ + (sc * C + sr) * 8) = pq;
-    *reinterpret_cast<bu4*>(sK + (sc * C + sr) * 8) = pk;
+    // row slot XOR 2 * chunk: the 16 lanes of a b128 store (2 rows x 8 chunks; chunk images are 1 KB = 0 mod 64 banks apart)
+    // land in 16 different 4-bank groups instead of 2 (8-way conflicts); the reads below permute inside their 16-row runs
+    *reinterpret_cast<bu4*>(sQ + (sc * C + (sr ^ (2 * sc))) * 8) = pq;
+    *reinterpret_cast<bu4*>(sK + (sc * C + (sr ^ (2 * sc))) * 8) = pk;
     *reinterpret_cast<bu4*>(sV + sr * E + vchunk(sr, sc) * 8) = pp;
     *reinterpret_cast<bu4*>(sV + sr * E + vchunk(sr, D / 8 + sc) * 8) = pv;
     if (!STATE_ONLY && t0 > t_begin) flush_out(t0 - C, C);                     // (block-uniform)
@@ -653,7 +655,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
       for (int fb = 0; fb < NBT; ++fb) acc[fb] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < D / 32; ++ks) {
-        const uint4 bx = *reinterpret_cast<const uint4*>(src + ((4 * ks + lg) * C + rb * 16 + li) * 8);
+        const uint4 bx = *reinterpret_cast<const uint4*>(src + ((4 * ks + lg) * C + ((rb * 16 + li) ^ (2 * (4 * ks + lg)))) * 8);
 #pragma unroll
         for (int fb = 0; fb < NBT; ++fb) {
           const uint4 aw = *reinterpret_cast<const uint4*>(sW + ((4 * ks + lg) * NBP + fb * 16 + li) * 8);
@@ -1088,8 +1090,10 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
     // ---- (a) staging ---------------------------------------------------------------------------------
     if (!STATE_ONLY) __builtin_amdgcn_raw_buffer_store_b128(pv, ro, sr < rows ? ((t0 + sr) * (3 * D) + 2 * D + sc * 8) * 2 : (int)OOB, 0, 0);
     if (STG == NTH || tid < STG) {
-      *reinterpret_cast<bu4*>(sQ + (sc * C + sr) * 8) = pq;
-      *reinterpret_cast<bu4*>(sK + (sc * C + sr) * 8) = pk;
+      // row slot XOR chunk: the 16 lanes of a b128 store (one row x 16 chunks at D = 128; chunk images are 512 B = 0 mod 64
+      // banks apart) land in 16 different 4-bank groups instead of one; the reads below permute inside their 16-row runs
+      *reinterpret_cast<bu4*>(sQ + (sc * C + (sr ^ sc)) * 8) = pq;
+      *reinterpret_cast<bu4*>(sK + (sc * C + (sr ^ sc)) * 8) = pk;
       *reinterpret_cast<bu4*>(sV + sr * EL + vchunk(sr, sc) * 8) = pp;
       *reinterpret_cast<bu4*>(sV + sr * EL + vchunk(sr, CPR + sc) * 8) = pv;
     }
@@ -1106,7 +1110,7 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
       for (int fb = 0; fb < NBT; ++fb) acc[fb] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < DP / 32; ++ks) {
-        const uint4 bx = *reinterpret_cast<const uint4*>(src + ((4 * ks + lg) * C + rb * 16 + li) * 8);
+        const uint4 bx = *reinterpret_cast<const uint4*>(src + ((4 * ks + lg) * C + ((rb * 16 + li) ^ ((4 * ks + lg) & 15))) * 8);
 #pragma unroll
         for (int fb = 0; fb < NBT; ++fb) {
           const uint4 aw = *reinterpret_cast<const uint4*>(sW + ((4 * ks + lg) * NBP + fb * 16 + li) * 8);
