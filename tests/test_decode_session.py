@@ -113,3 +113,29 @@ def test_session_with_the_deeper_predictor_cnn(monkeypatch):
             state = ref.state
             got = sess.step(q[:, :, hi - 1:hi], x[:, :, hi - 1:hi], x[:, :, hi - 1:hi])
             assert torch.equal(got, ref.context_layer), i
+
+
+def test_session_long_run_stays_bitwise():
+    """300 replayed positions from a 20-token prefix: past two multiples of T_M (the pixel widths change twice), five
+    Performer chunks and the point where K_t stops being clamped -- every position equals the cached forward."""
+    dtype, N, H, d, T_M, k, T0, steps = torch.bfloat16, 1, 4, 64, 256, 8, 20, 300
+    layer = _layer(H, d, T_M, k, T0 + steps + 1, dtype)
+    S.seed(17)
+    x = torch.randn((N, H, T0 + steps, d), device=DEV).to(dtype)
+    q = (x.float() * d ** -0.5).to(dtype)
+    with torch.no_grad():
+        out = layer(None, None, None, query_layer=q[:, :, :T0], key_layer=x[:, :, :T0], value_layer=x[:, :, :T0],
+                    attention_mask=_mask(N, T0, T0, dtype))
+        state = out.state
+        sess = layer.attention.decode_session(state, x[:, :, :T0], x[:, :, :T0], capacity=T0 + steps)
+        bad = []
+        for i in range(steps):
+            hi = T0 + i + 1
+            ref = layer(None, None, None, query_layer=q[:, :, hi - 1:hi], key_layer=x[:, :, :hi], value_layer=x[:, :, :hi],
+                        attention_mask=_mask(N, 1, hi, dtype), last_state=state)
+            state = ref.state
+            got = sess.step(q[:, :, hi - 1:hi], x[:, :, hi - 1:hi], x[:, :, hi - 1:hi])
+            if not torch.equal(got, ref.context_layer):
+                bad.append(hi)
+        assert not bad, bad[:10]
+        assert sess.length == T0 + steps
