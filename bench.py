@@ -267,7 +267,8 @@ def main():
     output_check = None
     if not args.no_output_check:
         with torch.no_grad():
-            ctx_b = out.context_layer
+            # N > 1 in graph mode: the attention launch wrote this rank's shard straight into the gathered buffer
+            ctx_b = ctx[rank * NB:(rank + 1) * NB] if world > 1 else out.context_layer
             probs_b = out.estimated_attention_probs_m
             keep_t = ops.keep_table_causal(H, T, T_M, k, device=dev)
             zc = ops.z_capacity(keep_t.cpu(), H, T, T, T_M, k, True)
@@ -288,9 +289,20 @@ def main():
                 bits_ok &= same_map and bool(torch.equal(alone.context_layer, ctx_b[n_:n_ + 1]))
             layer.attention.performer_segments = None
             finite = bool(torch.isfinite(ctx_b.float()).all().item())
-            output_check = {"status": "ok" if (bits_ok and finite) else "FAILED",
+            gathered_ok = None
+            if world > 1:
+                # the all-gather put every rank's shard where it belongs: each rank's checksum of its own shard, exchanged,
+                # against the checksum of the matching chunk of the gathered buffer this rank holds
+                mine = ctx_b.float().abs().sum(dtype=torch.float64).view(1)
+                sums = [torch.zeros_like(mine) for _ in range(world)]
+                dist.all_gather(sums, mine)
+                here = [ctx[r * NB:(r + 1) * NB].float().abs().sum(dtype=torch.float64).view(1) for r in range(world)]
+                gathered_ok = all(bool(torch.equal(a, b)) for a, b in zip(sums, here))
+            output_check = {"status": "ok" if (bits_ok and finite and gathered_ok is not False) else "FAILED",
                             "items_alone_bitwise_equal_to_batched_rows": bits_ok, "finite": finite,
                             "items_checked": sorted({0, NB - 1}), "layer_item_alone_rel_diff": round(worst, 8)}
+            if gathered_ok is not None:
+                output_check["gathered_shards_match_their_ranks"] = gathered_ok
 
     # ---- roofline of the dominant HIP kernel (fused sparse attention) ---------------------------------
     # achieved = SURVEY 8d's algorithmic bytes (every gathered K / V row counted once per entry) / launch time.  The
