@@ -145,7 +145,7 @@ def main():
     layer.attention.context_layer_dtype = dtype          # the consumer (out_proj) runs in `dtype`
     # the synthetic batch carries no padding by construction; telling the module removes the per-layer host
     # sync the reference pays to find that out (attention.py:434) and lets the CPU enqueue ahead of the GPU
-    layer.attention.assume_not_padded = not args.inspect_padding
+    layer.attention.assume_not_padded = None if args.inspect_padding else True   # None: the module inspects the mask itself
     layer.attention.sparse_kernel = args.sparse_kernel
     torch.manual_seed(42 + rank)
     q = (torch.randn((NB, H, T, d), device=dev) * d ** -0.5).to(dtype)
