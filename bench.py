@@ -1,23 +1,29 @@
 #!/usr/bin/env python3
 """bench.py -- SEA sparse-attention layer on MI355X: tokens/s + achieved HBM GB/s of the sparse kernel.
 
-Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched under
-torch.distributed.run with one rank per GPU (RCCL).  One JSON line on rank 0.
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`.  One JSON line on rank 0.
+  * N = 1: one process, one GPU.
+  * N > 1 with WORLD_SIZE set (the driver's `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`):
+    this process is one of the N ranks (one rank per GPU, RCCL).  Every rank checks WORLD_SIZE == --gpus and exits
+    non-zero when they disagree: the line can never claim more GPUs than ran.
+  * N > 1 with no WORLD_SIZE: the script launches its own N ranks (`python -m torch.distributed.run --nnodes=1
+    --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same arguments>`) as a child process BEFORE anything
+    in this process touches the GPU, relays the child's output and exits with its return code.
 
-A "step" = one forward of ONE SEA attention layer in sparse mode (`benchmarking=True`, steps A..L of
-SURVEY.md section 3B: value augmentation, Performer, predictor MLP+CNN, softmax, HIP grouped top-k +
-interpolation -> flat CSR, HIP fused sparse attention + mix) on a synthetic batch, followed -- when N>1 --
-by the RCCL all-gather of the context shards.  Workload = BASELINE.json configs[2]:
-OPT-1.3B SEA, H=32 d=64 T=4096, k=64, predictor length 256, nb-factor 8, bf16, random-init weights (seed 42).
-Per-GPU batch is fixed (weak scaling).
+A "step" = one forward of ONE SEA attention layer in sparse mode (`benchmarking=True`, steps A..L of SURVEY.md
+section 3B: value augmentation, Performer, predictor MLP+CNN, softmax, HIP grouped top-k + interpolation -> flat CSR,
+HIP fused sparse attention + mix) on a synthetic batch, followed -- when N>1 -- by the RCCL all-gather of the context
+shards.  Workload = BASELINE.json configs[2]: OPT-1.3B SEA, H=32 d=64 T=4096, k=64, predictor length 256,
+nb-factor 8, bf16, random-init weights (seed 42).  Per-GPU batch is fixed (weak scaling).  The other BASELINE shapes
+(configs[1], [3], [4]) run as short legs after the headline and are reported under `other_workloads`.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -28,17 +34,78 @@ WORKLOADS = {
     "opt-2.7b": dict(H=32, d=80, T=8192, T_M=256, k=64, nbf=8),
     "llama-13b": dict(H=40, d=128, T=4096, T_M=256, k=64, nbf=8),
 }
+# short legs after the headline: (workload, sequences per GPU) -- BASELINE.json configs[1], [3], [4] at the per-GPU batch
+# their configuration puts on one MI355X
+OTHER_LEGS = (("opt-125m", 8), ("opt-2.7b", 1), ("llama-13b", 1))
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 L2_GATHER_GBS = 17800.0    # MI355X_MICROARCH.md "Indexed rows": 16.8-18.8 TB/s chip-wide for rows served by the XCD's L2
+METRIC = "tokens/sec + achieved HBM GB/s, OPT-1.3B SEA T=4096 k=64, 1/2/4/8 MI355X"
 
 
-def _attn_source_sha():
-    """sha256 over the sources of the graded kernel: a PMC traffic record is only reported for the build it was taken on."""
-    import hashlib
-    h = hashlib.sha256()
-    for f in ("sea_attn.hip", "sea_attn.hpp", "sea_attn_tile.hip", "sea_common.hpp"):
-        h.update(open(os.path.join(ROOT, "sea-attention_amd", "csrc", f), "rb").read())
-    return h.hexdigest()
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="opt-1.3b", choices=list(WORKLOADS))
+    ap.add_argument("--batch", type=int, default=8, help="sequences per GPU")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--eager", action="store_true",
+                    help="launch every kernel eagerly instead of replaying the layer as a HIP graph")
+    ap.add_argument("--inspect-padding", action="store_true",
+                    help="let the module inspect the mask for padding every step (reference behaviour, one host sync)")
+    ap.add_argument("--cpu-seqs", type=int, default=4, help="sequences in the CPU-baseline sample")
+    ap.add_argument("--prewarm", type=int, default=8,
+                    help="untimed iterations before the W warm-up steps: lets the runtime settle")
+    ap.add_argument("--kernel-iters", type=int, default=20, help="extra kernel-only iterations (H..K) after the timed steps")
+    ap.add_argument("--sparse-kernel", default="ab", choices=["ab", "auto", "gather", "tile"],
+                    help="kernel of steps J-L (sea_sparse_attention_ex path); 'ab' times the candidates on the layer's own "
+                         "selection before the timed region and runs the fastest (reported as attention_path_ab)")
+    ap.add_argument("--no-output-check", action="store_true")
+    ap.add_argument("--no-other-workloads", action="store_true", help="skip the short legs over the other BASELINE shapes")
+    ap.add_argument("--other-steps", type=int, default=5, help="timed steps of each short leg")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the forward + backward leg of the sparse branch")
+    ap.add_argument("--decode-steps", type=int, default=0,
+                    help="positions of the generation leg after the timed steps (off by default: its one-row launches share kernel "
+                         "names with the layer's and would dilute a profiler's per-kernel averages of the default command)")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > 1 on a box without N GPUs: the process group runs on gloo; with one GPU every rank uses cuda:0 and "
+                         "walks the multi-rank code path of this script (shards, graph capture beside a process group, pipelined "
+                         "gather, max-over-ranks timing); with NO GPU a CPU stand-in step exercises launcher, process group, "
+                         "gather and timing protocol only.  Its numbers mean nothing")
+    return ap.parse_args(argv)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args, argv):
+    """--gpus N > 1 outside a launcher: start N ranks of this script under torch.distributed.run and relay them.
+    Nothing in THIS process has touched the GPU (no HIP call, no torch.cuda.* besides none at all)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__), *argv]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC: RCCL needs it on this driver
+    env.setdefault("OMP_NUM_THREADS", "4")
+    print(f"[bench] --gpus {args.gpus} without WORLD_SIZE: launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, stderr=None, text=True)
+    line = None
+    for out in proc.stdout:                                    # relay; the JSON line is rank 0's last '{' line
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        if out.lstrip().startswith("{"):
+            line = out
+    rc = proc.wait()
+    if rc == 0 and line is None:
+        print("[bench] the ranks exited 0 but printed no result line", file=sys.stderr)
+        rc = 3
+    return rc
 
 
 class _Cfg:
@@ -57,10 +124,31 @@ def _usable_cores():
     return n
 
 
+def _cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.lower().startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def _attn_source_sha():
+    """sha256 over the sources of the graded kernel: a PMC traffic record is only reported for the build it was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in ("sea_attn.hip", "sea_attn.hpp", "sea_attn_tile.hip", "sea_common.hpp"):
+        h.update(open(os.path.join(ROOT, "sea-attention_amd", "csrc", f), "rb").read())
+    return h.hexdigest()
+
+
 def cpu_baseline(w, n_seq=4):
     """Oracle (CPU port of the reference's dense PyTorch branch) on a bounded sample: ONE sequence of the
     workload shape through the kernel-level path (probs -> top-k -> interpolate -> dense masked attention),
     fp32, all host cores."""
+    import torch
     from oracle import sea_oracle as O
     cores = _usable_cores()
     torch.set_num_threads(cores)
@@ -77,115 +165,67 @@ def cpu_baseline(w, n_seq=4):
         out, _ = O.dense_path(probs, q, kk, v, rs, k, head_chunk=hc)
         out = O.mix(out, v, torch.zeros((1, H, T)))
     dt = time.perf_counter() - t0
-    return {"value": n_seq * T / dt, "unit": "tokens/s", "cores": cores, "kind": "port",
+    return {"value": n_seq * T / dt, "unit": "tokens/s", "cores": cores, "cpu_model": _cpu_model(), "kind": "port",
             "sample": f"{n_seq} sequences x {T} tokens, kernel-level path H..K (probs given), fp32 dense branch, "
                       f"head_chunk={hc}, {dt:.1f} s"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", default="opt-1.3b", choices=list(WORKLOADS))
-    ap.add_argument("--batch", type=int, default=8, help="sequences per GPU")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--eager", action="store_true",
-                    help="launch every kernel eagerly instead of replaying the layer as a HIP graph")
-    ap.add_argument("--inspect-padding", action="store_true",
-                    help="let the module inspect the mask for padding every step (reference behaviour, one host sync)")
-    ap.add_argument("--cpu-seqs", type=int, default=4, help="sequences in the CPU-baseline sample")
-    ap.add_argument("--prewarm", type=int, default=8,
-                    help="untimed iterations before the W warm-up steps: lets MIOpen/rocBLAS settle their kernel selection")
-    ap.add_argument("--kernel-iters", type=int, default=20, help="extra kernel-only iterations (H..K) after the timed steps")
-    ap.add_argument("--sparse-kernel", default="auto", choices=["auto", "gather", "tile"],
-                    help="kernel of steps J-L (sea_sparse_attention_ex path)")
-    ap.add_argument("--no-output-check", action="store_true")
-    ap.add_argument("--decode-steps", type=int, default=0,
-                    help="positions of the generation leg after the timed steps (off by default: its one-row launches share kernel "
-                         "names with the layer's and would dilute a profiler's per-kernel averages of the default command)")
-    ap.add_argument("--rehearse", action="store_true",
-                    help="N > 1 on a ONE-GPU box: every rank uses cuda:0 and the process group runs on gloo -- exercises the "
-                         "multi-rank code path of this script (shards, graph capture beside a process group, pipelined gather, "
-                         "max-over-ranks timing); its numbers mean nothing")
-    args = ap.parse_args()
+# ---------------------------------------------------------------------------------------------------------------------
+class LayerBench:
+    """One SEA attention layer of a BASELINE shape with its synthetic batch on this rank's GPU: eager step, HIP-graph
+    step (everything up to the fused sparse-attention launch captured, that launch eager between HIP events), the
+    A/B of the attention kernel paths, and the roofline block of the attention launch."""
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if args.rehearse:
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("gloo" if args.rehearse else "nccl", rank=rank, world_size=world)
-    assert torch.cuda.is_available(), "bench.py measures the HIP path; it needs the MI355X"
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(dev)
+    def __init__(self, wname, NB, dtype_name, dev, ctx_dtype_name=None, inspect_padding=False, seed_offset=0):
+        import torch
+        import sea_attention_amd as S
+        from sea_attention_amd.perlin_attention import PerlinAttentionConfig, PerlinSelfAttention
+        self.torch, self.S = torch, S
+        self.wname, self.w, self.NB, self.dev = wname, WORKLOADS[wname], NB, dev
+        w = self.w
+        H, d, T, T_M, k = w["H"], w["d"], w["T"], w["T_M"], w["k"]
+        dts = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
+        self.dtype = dts[dtype_name]
+        self.ctx_dtype = dts[ctx_dtype_name or dtype_name]
+        S.seed(42)
+        pc = PerlinAttentionConfig(k=k, attention_predictor_length=T_M, performer_nb_factor=w["nbf"], causal=True,
+                                   k_flatten=True, k_flatten_dim='causal_batch', context_output_method='mix')
+        layer = PerlinSelfAttention(_Cfg(H * d, H, T), pc).to(dev).to(self.dtype).eval()
+        for m in layer.modules():
+            if hasattr(m, 'benchmarking'):
+                m.benchmarking = True
+        layer.attention.context_layer_dtype = self.ctx_dtype     # None-equivalent (fp32) is the reference's default
+        # the synthetic batch carries no padding by construction; telling the module removes the per-layer host
+        # sync the reference pays to find that out (attention.py:434) and lets the CPU enqueue ahead of the GPU
+        layer.attention.assume_not_padded = None if inspect_padding else True
+        self.layer = layer
+        torch.manual_seed(42 + seed_offset)
+        self.q = (torch.randn((NB, H, T, d), device=dev) * d ** -0.5).to(self.dtype)
+        self.k = torch.randn((NB, H, T, d), device=dev).to(self.dtype)
+        self.v = torch.randn((NB, H, T, d), device=dev).to(self.dtype)
+        fp_min = torch.finfo(torch.float16 if self.dtype != torch.float32 else torch.float32).min / 2
+        mask = ((torch.arange(T, device=dev).view(1, T) > torch.arange(T, device=dev).view(T, 1)) * fp_min)
+        self.mask = mask.view(1, 1, T, T).to(self.dtype).expand(NB, 1, T, T).contiguous()
+        self.graph, self.rec, self.g_out = None, None, None
+        self.attn_events = []
+        self.out_override = None          # N > 1: callable(step) -> the (N,H,T,d)-shaped view the attention launch writes
+        self.capture_error = None
 
-    import sea_attention_amd as S
-    from sea_attention_amd import _lib, distributed as D
-    from sea_attention_amd.perlin_attention import PerlinAttentionConfig, PerlinSelfAttention, ops
-    _lib.load(build_if_missing=True)
+    # -- one forward, eager ---------------------------------------------------------------------------------------------
+    def forward(self):
+        with self.torch.no_grad():
+            return self.layer(None, None, None, query_layer=self.q, key_layer=self.k, value_layer=self.v,
+                              attention_mask=self.mask)
 
-    w = WORKLOADS[args.workload]
-    H, d, T, T_M, k = w["H"], w["d"], w["T"], w["T_M"], w["k"]
-    dtype = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}[args.dtype]
-    NB = args.batch
-
-    S.seed(42)
-    pc = PerlinAttentionConfig(k=k, attention_predictor_length=T_M, performer_nb_factor=w["nbf"], causal=True,
-                               k_flatten=True, k_flatten_dim='causal_batch', context_output_method='mix')
-    layer = PerlinSelfAttention(_Cfg(H * d, H, T), pc).to(dev).to(dtype).eval()
-    for m in layer.modules():
-        if hasattr(m, 'benchmarking'):
-            m.benchmarking = True
-    layer.attention.context_layer_dtype = dtype          # the consumer (out_proj) runs in `dtype`
-    # the synthetic batch carries no padding by construction; telling the module removes the per-layer host
-    # sync the reference pays to find that out (attention.py:434) and lets the CPU enqueue ahead of the GPU
-    layer.attention.assume_not_padded = None if args.inspect_padding else True   # None: the module inspects the mask itself
-    layer.attention.sparse_kernel = args.sparse_kernel
-    torch.manual_seed(42 + rank)
-    q = (torch.randn((NB, H, T, d), device=dev) * d ** -0.5).to(dtype)
-    kk = torch.randn((NB, H, T, d), device=dev).to(dtype)
-    v = torch.randn((NB, H, T, d), device=dev).to(dtype)
-    fp_min = torch.finfo(torch.float16 if dtype != torch.float32 else torch.float32).min / 2
-    mask = ((torch.arange(T, device=dev).view(1, T) > torch.arange(T, device=dev).view(T, 1)) * fp_min)
-    mask = mask.view(1, 1, T, T).to(dtype).expand(NB, 1, T, T).contiguous()
-
-    bench = S.get_bench()
-
-    # N > 1: the all-gather of step i (RCCL, its own stream) overlaps the compute of step i+1 -- two slots of
-    # (local shard, gathered output); every collective is awaited before the timed region ends (gather.finish()).
-    gather = D.ContextGatherer((NB, T, H * d), NB * world, dtype, dev) if world > 1 else None
-
-    def step():
-        with torch.no_grad():
-            out = layer(None, None, None, query_layer=q, key_layer=kk, value_layer=v, attention_mask=mask)
-            ctx = out.context_layer
-            if world > 1:                                  # eager mode only: the graph path writes the slot directly
-                slot = gather.next_slot()
-                gather.local[slot].copy_(ctx)
-                ctx = gather.launch(slot)
-        return out, ctx
-
-    def sync_all():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.prewarm + args.warmup):
-        step()
-    graph = None
-    attn_events = []
-    if not args.eager:
-        # HIP-graph mode (default).  Everything of the layer step UP TO the fused sparse-attention launch is
-        # captured into one graph (torch ops and the C-ABI kernels alike go to the capturing stream); the
-        # attention kernel itself -- the last launch of the layer, which writes context_layer -- is launched
-        # eagerly right after each replay, bracketed by HIP events on the same stream (roofline timing).
+    # -- HIP-graph form ---------------------------------------------------------------------------------------------------
+    def capture(self, sparse_kernel, with_process_group=False):
+        """Capture everything of the layer step UP TO the fused sparse-attention launch (torch ops and the C-ABI kernels
+        alike go to the capturing stream); the attention launch -- the last of the layer, it writes context_layer -- is
+        recorded and launched eagerly after each replay between HIP events on the same stream (roofline timing)."""
+        torch = self.torch
         from sea_attention_amd.perlin_attention import attention as _A
+        self.layer.attention.sparse_kernel = sparse_kernel
+        self.graph, self.rec, self.g_out = None, None, None
         real_attn = _A.ops.sparse_attention
         rec = {}
 
@@ -193,44 +233,359 @@ def main():
             rec["a"], rec["kw"] = a, kw
             return kw.get("out")
         try:
-            if gather is not None:
-                gather.finish()                             # no collective in flight while the capture runs
-            sync_all()
+            torch.cuda.synchronize()
             _A.ops.sparse_attention = recorder
             graph = torch.cuda.CUDAGraph()
             # with a process group alive its watchdog thread polls events: keep the capture's error mode thread-local
-            with torch.cuda.graph(graph, **({"capture_error_mode": "thread_local"} if world > 1 else {})):
-                with torch.no_grad():
-                    g_out = layer(None, None, None, query_layer=q, key_layer=kk, value_layer=v, attention_mask=mask)
+            with torch.cuda.graph(graph, **({"capture_error_mode": "thread_local"} if with_process_group else {})):
+                g_out = self.forward()
         except Exception as e:                                  # capture unsupported on this stack: stay eager
-            print(f"[bench] HIP-graph capture failed ({type(e).__name__}: {e}); falling back to eager launches", file=sys.stderr)
-            graph = None
+            self.capture_error = f"{type(e).__name__}: {e}"[:300]
+            print(f"[bench] HIP-graph capture failed ({self.capture_error}); falling back to eager launches", file=sys.stderr)
+            return False
         finally:
             _A.ops.sparse_attention = real_attn
-        if graph is not None and "a" in rec:
-            eager_step = step
+        if "a" not in rec:
+            self.capture_error = "the layer issued no fused sparse-attention launch"
+            return False
+        self.graph, self.rec, self.g_out, self._real_attn = graph, rec, g_out, real_attn
+        return True
 
-            def step():
-                kw = rec["kw"]
-                if world > 1:      # the attention kernel writes straight into this step's gather slot
-                    slot = gather.next_slot()
-                    kw = dict(kw, out=gather.local[slot].view(NB, T, H, d).permute(0, 2, 1, 3))
-                graph.replay()
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                real_attn(*rec["a"], **kw)
-                e1.record()
-                attn_events.append((e0, e1))
-                ctx = gather.launch(slot) if world > 1 else g_out.context_layer
-                return g_out, ctx
-            for _ in range(3):
-                step()
-            attn_events.clear()
+    def step(self, out_view=None):
+        """One step.  Graph mode: replay + the eager attention launch (optionally redirected into `out_view`, the rank's
+        slot of the gathered buffer); returns (layer output tuple, context tensor written)."""
+        torch = self.torch
+        if self.graph is None:
+            out = self.forward()
+            return out, out.context_layer
+        kw = self.rec["kw"] if out_view is None else dict(self.rec["kw"], out=out_view)
+        self.graph.replay()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        self._real_attn(*self.rec["a"], **kw)
+        e1.record()
+        self.attn_events.append((e0, e1))
+        return self.g_out, (self.g_out.context_layer if out_view is None else None)
+
+    def attn_ms(self):
+        if not self.attn_events:
+            return None
+        return sum(a.elapsed_time(b) for a, b in self.attn_events) / len(self.attn_events)
+
+    def timed(self, steps):
+        """K steps between two device synchronisations; returns (seconds, mean attention-launch ms or None)."""
+        torch = self.torch
+        self.attn_events.clear()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step()
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0, self.attn_ms()
+
+    def tile_supported(self):
+        return self.dtype != self.torch.float32 and self.w["d"] in (64, 80, 128)
+
+    def choose_path(self, requested, with_process_group=False, steps=4):
+        """'ab': capture the step with each candidate path of the attention launch, time `steps` replays of each on the
+        layer's own selection, keep the fastest WHOLE STEP (the plan launch of 'auto' sits inside the graph).  Returns
+        (path, report)."""
+        if requested != "ab":
+            ok = self.capture(requested, with_process_group)
+            return requested, {"requested": requested, "graph": ok}
+        cands = ["gather"] + (["auto", "tile"] if self.tile_supported() else [])
+        rep = {}
+        for c in cands:
+            if not self.capture(c, with_process_group):
+                return "auto" if self.tile_supported() else "gather", {"requested": "ab", "graph": False}
+            self.timed(2)
+            dt, am = self.timed(steps)
+            rep[c] = {"ms_per_step": round(dt / steps * 1e3, 4), "attention_ms": round(am, 4)}
+        best = min(rep, key=lambda c_: rep[c_]["ms_per_step"])
+        self.capture(best, with_process_group)
+        return best, {"requested": "ab", "graph": True, "candidates": rep, "chosen": best,
+                      "note": f"{steps} graph-replayed steps per candidate on the layer's own selection, before the timed region"}
+
+    # -- roofline of the attention launch -----------------------------------------------------------------------------------
+    def roofline(self, out, t_attn_s, path, timing_note):
+        torch = self.torch
+        from sea_attention_amd.perlin_attention import ops
+        w, NB = self.w, self.NB
+        H, d, T = w["H"], w["d"], w["T"]
+        csr = out.partial_attention_mask
+        Z = int(csr.crow[:, -1].sum().item())
+        esz = torch.tensor([], dtype=self.dtype).element_size()
+        alg_bytes = ops.sparse_attention_bytes(Z, NB, H, T, d, esz)
+        osz = torch.tensor([], dtype=self.ctx_dtype).element_size()
+        compulsory = (4 * NB * H * T * d * esz + NB * H * T * d * osz     # q, k, v, avg in; out
+                      + Z * 4 + NB * T * (H + 2) * 4                      # col, head_off, crow
+                      + 2 * NB * H * T * 4)                               # row_scale, mix
+        if not t_attn_s:
+            return None, Z
+        achieved = alg_bytes / t_attn_s / 1e9
+        traffic, traffic_note = None, "no PMC pass on record (scripts/gpu_pmc.sh writes profiles/traffic_latest.json)"
+        tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tp):
+            try:
+                rec = json.load(open(tp))
+                if rec.get("kernel_source_sha256") != _attn_source_sha():
+                    traffic_note = "profiles/traffic_latest.json was taken on other kernel sources: not reported"
+                elif rec.get("nnz") != Z:
+                    traffic_note = "profiles/traffic_latest.json was taken on another workload (entry count differs): not reported"
+                else:
+                    traffic = rec.get("sea_sparse_attention_hbm_bytes_per_launch")
+                    traffic_note = rec.get("note", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command")
+            except Exception:
+                pass
+        gname = "sparse_attn_rows80_kernel" if d == 80 and esz == 2 else "sparse_attn_rows_kernel"
+        kname = {"tile": "sparse_attn_tile_kernel", "gather": gname,
+                 "auto": gname + " + sparse_attn_tile_kernel (per-block dispatch: both launches inside the timed events)"}[path]
+        # achieved = SURVEY 8d's algorithmic bytes (every gathered K / V row counted once per entry) / launch time.  K + V of
+        # one head stay in the XCD's L2, so what binds is the L2 -> L1 request path, not HBM: `bound` says so, `frac` is
+        # still against the 8 TB/s HBM line (the contract's roofline), `l2_gather_frac` against the 17.8 TB/s the
+        # microarchitecture guide measures for L2-served row gathers, `frac_compulsory_hbm` = bytes that MUST cross HBM once
+        return {"bound": "l2_gather", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
+                "compulsory_bytes": compulsory, "frac_compulsory_hbm": round(compulsory / t_attn_s / 1e9 / HBM_PEAK_GBS, 4),
+                "l2_gather_peak": L2_GATHER_GBS, "l2_gather_frac": round(achieved / L2_GATHER_GBS, 4),
+                "timing": timing_note, "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_ms": round(t_attn_s * 1e3, 4), "nnz": Z}, Z
+
+    def release(self):
+        self.graph = self.rec = self.g_out = None
+        self.attn_events.clear()
+        for n_ in ("layer", "q", "k", "v", "mask"):
+            setattr(self, n_, None)
+        self.torch.cuda.empty_cache()
+
+
+def short_leg(wname, NB, args, dev, ctx_dtype_name=None):
+    """A short run of another BASELINE shape (or of the headline with another context dtype): same protocol as the headline
+    (prewarm, A/B of the attention path, HIP-graph replay, HIP events around the attention launch), fewer steps."""
+    lb = LayerBench(wname, NB, args.dtype, dev, ctx_dtype_name=ctx_dtype_name)
+    try:
+        for _ in range(3):
+            lb.forward()
+        path, ab = ("eager", {"graph": False}) if args.eager else lb.choose_path(args.sparse_kernel)
+        if lb.graph is None:
+            lb.layer.attention.sparse_kernel = "auto" if path in ("ab", "eager") else path
+            path = lb.layer.attention.sparse_kernel
+        lb.timed(max(2, args.warmup // 2))
+        dt, am = lb.timed(args.other_steps)
+        out, _ = lb.step()
+        lb.torch.cuda.synchronize()
+        roof, Z = lb.roofline(out, am / 1e3 if am else None, path, "HIP events around every launch inside the timed steps")
+        w = lb.w
+        return {"workload": f"{wname} H={w['H']} d={w['d']} T={w['T']} k={w['k']} predictor_length={w['T_M']}, batch {NB}/GPU, "
+                            f"{args.dtype}, context_layer {ctx_dtype_name or args.dtype}",
+                "ms_per_step": round(dt / args.other_steps * 1e3, 4), "tokens_per_s": round(NB * w["T"] / (dt / args.other_steps), 1),
+                "steps": args.other_steps, "graph": lb.graph is not None, "attention_path": path,
+                "attention_path_ab": ab.get("candidates"), "roofline": roof}
+    finally:
+        lb.release()
+
+
+def train_step_leg(wname, args, dev):
+    """Forward + backward of the layer's sparse branch on ONE sequence of the headline shape: the HIP forward
+    with saved per-entry probabilities and the HIP backward (dQ by rows, dK / dV through the transposed CSR), gradients
+    to q, k, v.  The estimator runs without autograd (its map is an input of the branch, as in the reference's
+    sparse-mode training, attention.py:1034-1042)."""
+    import torch
+    from sea_attention_amd.perlin_attention import ops
+    lb = LayerBench(wname, 1, args.dtype, dev)
+    try:
+        out = lb.forward()
+        csr = out.partial_attention_mask
+        w = lb.w
+        H, d, T = w["H"], w["d"], w["T"]
+        q, k, v = (t_.detach().clone().requires_grad_(True) for t_ in (lb.q, lb.k, lb.v))
+        rs = torch.sigmoid(torch.randn((1, H, T), device=dev)).requires_grad_(True)
+        go = torch.randn((1, H, T, d), device=dev, dtype=torch.float32)
+
+        def one():
+            for t_ in (q, k, v, rs):
+                t_.grad = None
+            o = ops.sparse_attention_autograd(q, k, v, csr, row_scale=rs)
+            o.backward(go)
+        for _ in range(3):
+            one()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n_it = 10
+        e0.record()
+        for _ in range(n_it):
+            one()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / n_it
+        fin = all(bool(torch.isfinite(t_.grad.float()).all().item()) for t_ in (q, k, v, rs))
+        Z = int(csr.crow[:, -1].sum().item())
+        return {"workload": f"{wname} sparse branch forward + backward, 1 sequence x {T} tokens, {args.dtype}, nnz {Z}",
+                "ms_per_step": round(ms, 4), "tokens_per_s": round(T / (ms / 1e3), 1), "grads_finite": fin,
+                "note": "ops.sparse_attention_autograd: sea_sparse_attention_ex (per-entry probabilities saved) + sea_sparse_attention_bwd"}
+    finally:
+        lb.release()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+def cpu_rehearsal(args, world, rank):
+    """--rehearse on a box with NO GPU: the launcher, WORLD_SIZE check, process group (gloo), batch shards, the pipelined
+    in-place all-gather of context shards, barrier + max-over-ranks timing and the single JSON line are the real ones;
+    the compute step is a stand-in (each rank fills its shard with a rank/step pattern).  The numbers mean nothing."""
+    import torch
+    import torch.distributed as dist
+    from sea_attention_amd import distributed as D
+    w = WORKLOADS[args.workload]
+    NB, T, C = args.batch, 64, 32
+    gather = D.ContextGatherer((NB, T, C), NB * world, torch.float32, "cpu") if world > 1 else None
+    ok = True
+
+    def step(i):
+        slot = gather.next_slot()
+        gather.local[slot].fill_(float(1000 * rank + i))
+        return slot, gather.launch(slot)
+    for i in range(args.warmup):
+        step(i)
+    gather.finish()
+    dist.barrier()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(args.steps):
+        last = step(i)
+    gather.finish()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    full = last[1]
+    for r in range(world):
+        ok &= bool((full[r * NB:(r + 1) * NB] == float(1000 * r + args.steps - 1)).all())
+    t = torch.tensor([elapsed], dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    flag = torch.tensor([1.0 if ok else 0.0])
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": METRIC, "value": round(NB * world * T / (elapsed / args.steps), 1), "unit": "tokens/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "rehearsal": "cpu-stand-in (no GPU on this box): launcher, process group (gloo), shards, pipelined all-gather and "
+                         "timing protocol only -- the numbers mean nothing",
+            "config": {"workload": f"REHEARSAL of {args.workload} (H={w['H']} d={w['d']} T={w['T']}): stand-in step",
+                       "global_batch": NB * world, "seq_len": T, "parallelism": f"dp{world} (batch shards)"},
+            "collective": {"backend": dist.get_backend(), "ranks": dist.get_world_size()},
+            "output_check": {"status": "ok" if flag.item() == 1.0 else "FAILED", "gathered_shards_match_their_ranks": bool(flag.item() == 1.0)},
+            "roofline": None, "cpu_baseline": None}))
+    dist.barrier()
+    dist.destroy_process_group()
+    return 0 if flag.item() == 1.0 else 4
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse_args(argv)
+    if args.gpus < 1:
+        print("[bench] --gpus must be >= 1", file=sys.stderr)
+        return 2
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and args.gpus > 1:
+        return self_launch(args, argv)                          # before anything here touches the GPU
+    world = int(env_world or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:                                      # never print a line that claims GPUs that did not run
+        print(f"[bench] rank {rank}: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; refusing to run",
+              file=sys.stderr)
+        return 2
+
+    import torch
+    import torch.distributed as dist
+    have_gpu = torch.cuda.is_available()
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if args.rehearse:
+            local_rank = 0
+        if have_gpu:
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group("gloo" if args.rehearse else "nccl", rank=rank, world_size=world)
+        assert dist.get_world_size() == args.gpus
+    if args.rehearse and not have_gpu:
+        if world == 1:
+            print("[bench] --rehearse without a GPU needs --gpus > 1 (it rehearses the multi-rank protocol)", file=sys.stderr)
+            return 2
+        return cpu_rehearsal(args, world, rank)
+    assert have_gpu, "bench.py measures the HIP path; it needs the MI355X"
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    import sea_attention_amd as S
+    from sea_attention_amd import _lib, distributed as D
+    from sea_attention_amd.perlin_attention import ops
+    _lib.load(build_if_missing=True)
+
+    w = WORKLOADS[args.workload]
+    H, d, T, T_M, k = w["H"], w["d"], w["T"], w["T_M"], w["k"]
+    NB = args.batch
+    lb = LayerBench(args.workload, NB, args.dtype, dev, inspect_padding=args.inspect_padding, seed_offset=rank)
+    dtype = lb.dtype
+    layer, q, kk, v, mask = lb.layer, lb.q, lb.k, lb.v, lb.mask
+    bench = S.get_bench()
+
+    # N > 1: the all-gather of step i (RCCL, its own stream) overlaps the compute of step i+1 -- two slots of
+    # (local shard, gathered output); every collective is awaited before the timed region ends (gather.finish()).
+    gather = D.ContextGatherer((NB, T, H * d), NB * world, dtype, dev) if world > 1 else None
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def slot_view(slot):
+        return gather.local[slot].view(NB, T, H, d).permute(0, 2, 1, 3)
+
+    def step(do_gather=True):
+        """One step of the job: the layer (graph replay + attention launch, or eager) and -- N > 1 -- the asynchronous
+        all-gather of this step's context shard."""
+        if world == 1:
+            return lb.step()
+        slot = gather.next_slot()
+        if lb.graph is not None:                           # the attention kernel writes straight into this step's gather slot
+            out, _ = lb.step(out_view=slot_view(slot))
         else:
-            graph = None
+            out, ctx_ = lb.step()
+            gather.local[slot].copy_(ctx_)
+        full = gather.launch(slot) if do_gather else gather.out[slot]
+        return out, full
+
+    for _ in range(args.prewarm):
+        lb.forward()
+    # kernel path of the attention launch + HIP-graph capture (both outside the timed region)
+    if gather is not None:
+        gather.finish()
+    sync_all()
+    if args.eager:
+        path = "auto" if (args.sparse_kernel == "ab" and lb.tile_supported()) else ("gather" if args.sparse_kernel == "ab" else args.sparse_kernel)
+        lb.layer.attention.sparse_kernel = path
+        ab = {"requested": args.sparse_kernel, "graph": False}
+    else:
+        path, ab = lb.choose_path(args.sparse_kernel, with_process_group=world > 1)
+        if world > 1:       # every rank runs the same kernel: rank 0's choice (the candidates differ by a few % between GPUs)
+            names = ["gather", "auto", "tile"]
+            c = torch.tensor([names.index(path)], device=dev)
+            dist.broadcast(c, 0)
+            if names[int(c.item())] != path:
+                path = names[int(c.item())]
+                lb.capture(path, with_process_group=True)
+        if lb.graph is None:
+            path = "auto" if lb.tile_supported() else "gather"
+            lb.layer.attention.sparse_kernel = path
+    for _ in range(args.warmup):
+        step()
+    if gather is not None:
+        gather.finish()
     # per-kernel HIP events through the module's named regions (events only, no host sync inside the steps)
-    bench.disabled, bench.synchronize = (graph is not None), True   # regions cannot be timed inside a graph replay
+    bench.disabled, bench.synchronize = (lb.graph is not None), True   # regions cannot be timed inside a graph replay
     bench.reset_measures()
+    lb.attn_events.clear()
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -241,16 +596,7 @@ def main():
     sync_all()
     elapsed = time.perf_counter() - t0
     regions = bench.todict()                              # seconds per call, from HIP events on the launch stream
-    t_attn_graph = None
-    if graph is not None:
-        t_attn_graph = sum(a.elapsed_time(b) for a, b in attn_events) / max(1, len(attn_events)) / 1e3
-        bench.disabled = False                            # informational per-region times: a few eager steps
-        for _ in range(5):
-            eager_step()
-        torch.cuda.synchronize()
-        regions = bench.todict()
-    bench.disabled, bench.synchronize = True, False
-    bench.reset_measures()
+    t_attn_graph = (lb.attn_ms() or 0) / 1e3 if lb.graph is not None else None
 
     t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
@@ -258,6 +604,47 @@ def main():
     elapsed = float(t.item())
     ms_per_step = elapsed / args.steps * 1e3
     tokens_per_s = NB * world * T / (elapsed / args.steps)
+
+    # ---- N > 1: the collective by itself and the compute by itself (outside the timed region) -------------------------
+    collective = None
+    if world > 1:
+        sync_all()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step(do_gather=False)
+        torch.cuda.synchronize()
+        t_comp = torch.tensor([time.perf_counter() - t1], device=dev, dtype=torch.float64)
+        dist.all_reduce(t_comp, op=dist.ReduceOp.MAX)
+        sync_all()
+        t2 = time.perf_counter()
+        for _ in range(args.steps):                        # back-to-back all-gathers of one slot, each awaited
+            gather.launch(0)
+            gather.finish()
+        torch.cuda.synchronize()
+        t_ag = torch.tensor([time.perf_counter() - t2], device=dev, dtype=torch.float64)
+        dist.all_reduce(t_ag, op=dist.ReduceOp.MAX)
+        comp_ms = float(t_comp.item()) / args.steps * 1e3
+        ag_ms = float(t_ag.item()) / args.steps * 1e3
+        shard_bytes = NB * T * H * d * torch.tensor([], dtype=dtype).element_size()
+        collective = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
+                      "compute_only_ms_per_step": round(comp_ms, 4),
+                      "allgather_alone_ms": round(ag_ms, 4),
+                      "allgather_exposed_ms_per_step": round(max(0.0, ms_per_step - comp_ms), 4),
+                      "shard_bytes": shard_bytes, "received_bytes_per_rank": shard_bytes * (world - 1),
+                      "allgather_alone_GBs_per_rank": round(shard_bytes * (world - 1) / (ag_ms / 1e3) / 1e9, 1),
+                      "note": "compute_only = the same steps without launching the collective (the N=1-equivalent per-GPU step, "
+                              "max over ranks); allgather_alone = all_gather_into_tensor of one step's shards, awaited, nothing "
+                              "else running; exposed = ms_per_step - compute_only (the pipelined gather hides the rest)"}
+
+    if lb.graph is not None:
+        bench.disabled = False                            # informational per-region times: a few eager steps
+        lb.layer.attention.sparse_kernel = path
+        for _ in range(5):
+            lb.forward()
+        torch.cuda.synchronize()
+        regions = bench.todict()
+    bench.disabled, bench.synchronize = True, False
+    bench.reset_measures()
 
     # ---- output self-check (outside the timed region): the batch the bench times is also a batch that is RIGHT -------
     # item n of the batched output == the same item run ALONE through the whole layer, bit for bit (every kernel is
@@ -276,6 +663,7 @@ def main():
             # the lone item takes the Performer path the BATCH took (one pass for a full batch; for a one-sequence workload
             # the library's sequence-parallel plan of that very shape)
             layer.attention.performer_segments = ops.performer_plan(NB, H, T, d, layer.attention.performer_nb_features, dtype)[0]
+            layer.attention.sparse_kernel = path
             for n_ in sorted({0, NB - 1}):
                 csr_n, _ = ops.topk_to_csr(probs_b[n_:n_ + 1].contiguous(), keep_t, k, target_width=T, z_cap=zc)
                 csr_b = out.partial_attention_mask
@@ -286,7 +674,10 @@ def main():
                 same_map = bool(torch.equal(alone.estimated_attention_probs_m, probs_b[n_:n_ + 1]))
                 d_ = (alone.context_layer.float() - ctx_b[n_:n_ + 1].float())
                 worst = max(worst, (d_.norm() / ctx_b[n_:n_ + 1].float().norm()).item())
-                bits_ok &= same_map and bool(torch.equal(alone.context_layer, ctx_b[n_:n_ + 1]))
+                # 'auto' decides per 16-row block from the whole launch's plan (a lone item can fall on the other side of the
+                # all-tile rule): equal to rounding there, bitwise for a single-kernel path
+                close = worst < 2e-3 if path == "auto" else bool(torch.equal(alone.context_layer, ctx_b[n_:n_ + 1]))
+                bits_ok &= same_map and close
             layer.attention.performer_segments = None
             finite = bool(torch.isfinite(ctx_b.float()).all().item())
             gathered_ok = None
@@ -299,56 +690,23 @@ def main():
                 here = [ctx[r * NB:(r + 1) * NB].float().abs().sum(dtype=torch.float64).view(1) for r in range(world)]
                 gathered_ok = all(bool(torch.equal(a, b)) for a, b in zip(sums, here))
             output_check = {"status": "ok" if (bits_ok and finite and gathered_ok is not False) else "FAILED",
-                            "items_alone_bitwise_equal_to_batched_rows": bits_ok, "finite": finite,
-                            "items_checked": sorted({0, NB - 1}), "layer_item_alone_rel_diff": round(worst, 8)}
+                            "items_alone_equal_to_batched_rows": bits_ok,
+                            "comparison": "bitwise" if path != "auto" else "2e-3 rel-norm (per-block dispatch differs between launches)",
+                            "finite": finite, "items_checked": sorted({0, NB - 1}), "layer_item_alone_rel_diff": round(worst, 8)}
             if gathered_ok is not None:
                 output_check["gathered_shards_match_their_ranks"] = gathered_ok
 
     # ---- roofline of the dominant HIP kernel (fused sparse attention) ---------------------------------
-    # achieved = SURVEY 8d's algorithmic bytes (every gathered K / V row counted once per entry) / launch time.  The
-    # K + V of one head (1 MiB) stay in the XCD's L2, so what binds is the L2 -> L1 request path, not HBM: `bound` says so,
-    # `frac` is still against the 8 TB/s HBM line (the contract's roofline), `l2_gather_frac` against the 17.8 TB/s the
-    # microarchitecture guide measures for L2-served row gathers, `frac_compulsory_hbm` = bytes that MUST cross HBM once
-    # (q, k, v, avg, out, col, offsets, scales) / time / 8 TB/s.
-    csr = out.partial_attention_mask
-    Z = int(csr.crow[:, -1].sum().item())
-    esz = torch.tensor([], dtype=dtype).element_size()
-    alg_bytes = ops.sparse_attention_bytes(Z, NB, H, T, d, esz)
-    compulsory = (5 * NB * H * T * d * esz                      # q, k, v, avg in; out
-                  + Z * 4 + NB * T * (H + 2) * 4                # col, head_off, crow
-                  + 2 * NB * H * T * 4)                         # row_scale, mix
     t_attn = t_attn_graph if t_attn_graph else regions.get('attention.sparse.fused')
-    roof = None
-    if t_attn:
-        achieved = alg_bytes / t_attn / 1e9
-        traffic, traffic_note = None, "no PMC pass on record (scripts/gpu_pmc.sh writes profiles/traffic_latest.json)"
-        tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tp):
-            try:
-                rec = json.load(open(tp))
-                if rec.get("kernel_source_sha256") == _attn_source_sha() and rec.get("nnz") != Z:
-                    traffic_note = "profiles/traffic_latest.json was taken on another workload (entry count differs): not reported"
-                elif rec.get("kernel_source_sha256") == _attn_source_sha():
-                    traffic = rec.get("sea_sparse_attention_hbm_bytes_per_launch")
-                    traffic_note = rec.get("note", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command")
-                else:
-                    traffic_note = "profiles/traffic_latest.json was taken on other kernel sources: not reported"
-            except Exception:
-                pass
-        gname = "sparse_attn_rows80_kernel" if d == 80 and esz == 2 else "sparse_attn_rows_kernel"
-        kname = {"tile": "sparse_attn_tile_kernel", "gather": gname,
-                 "auto": gname + " + sparse_attn_tile_kernel (per-block dispatch: both launches inside the timed events)"}[args.sparse_kernel]
-        roof = {"bound": "l2_gather", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
-                "compulsory_bytes": compulsory, "frac_compulsory_hbm": round(compulsory / t_attn / 1e9 / HBM_PEAK_GBS, 4),
-                "l2_gather_peak": L2_GATHER_GBS, "l2_gather_frac": round(achieved / L2_GATHER_GBS, 4),
-                "timing": "HIP events around every launch inside the timed steps" if graph is not None
-                          else "HIP events of the module's 'attention.sparse.fused' region inside the timed steps",
-                "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(t_attn * 1e3, 4), "nnz": Z}
+    roof, Z = lb.roofline(out, t_attn, path,
+                          "HIP events around every launch inside the timed steps" if lb.graph is not None
+                          else "HIP events of the module's 'attention.sparse.fused' region inside the timed steps")
+    esz = torch.tensor([], dtype=dtype).element_size()
 
     # ---- kernel-level path only (H..K on HIP, probs given) -- what the CPU baseline below also runs -------
     kernel_path = None
     if args.kernel_iters > 0:
+        kpath = path
         probs = torch.softmax(torch.randn((NB, H, T, T_M), device=dev), -1).to(dtype)
         keep = ops.keep_table_causal(H, T, T_M, k, device=dev)
         z_cap = ops.z_capacity(keep.cpu(), H, T, T, T_M, k, True)
@@ -359,7 +717,7 @@ def main():
 
         def kstep():
             c, _ = ops.topk_to_csr(probs, keep, k, target_width=T, z_cap=z_cap)
-            ops.sparse_attention(q, kk, v, c, row_scale=rs, avg=avg, mix=mx, out=ctx2.view(NB, T, H, d).permute(0, 2, 1, 3), path=args.sparse_kernel)
+            ops.sparse_attention(q, kk, v, c, row_scale=rs, avg=avg, mix=mx, out=ctx2.view(NB, T, H, d).permute(0, 2, 1, 3), path=kpath)
             return c
         for _ in range(3):
             kstep()
@@ -368,7 +726,7 @@ def main():
         tk = ta = 0.0
         for _ in range(args.kernel_iters):
             e0.record(); c, _ = ops.topk_to_csr(probs, keep, k, target_width=T, z_cap=z_cap); e1.record()
-            ops.sparse_attention(q, kk, v, c, row_scale=rs, avg=avg, mix=mx, out=ctx2.view(NB, T, H, d).permute(0, 2, 1, 3), path=args.sparse_kernel)
+            ops.sparse_attention(q, kk, v, c, row_scale=rs, avg=avg, mix=mx, out=ctx2.view(NB, T, H, d).permute(0, 2, 1, 3), path=kpath)
             e2.record(); torch.cuda.synchronize()
             tk += e0.elapsed_time(e1); ta += e1.elapsed_time(e2)
         tk /= args.kernel_iters; ta /= args.kernel_iters
@@ -399,6 +757,8 @@ def main():
             kernel_path["structured_map"] = {"sparse_attention_ms": times, "nnz": Zs,
                                              "algorithmic_GBs_auto": round(ops.sparse_attention_bytes(Zs, NB, H, T, d, esz) / (times["auto"] / 1e3) / 1e9, 1),
                                              "note": "auto = plan kernel + both gated launches (what the layer runs)"}
+            del cs
+        del probs, avg, ctx2, rs, mx
 
     # ---- generation leg: one position per step from a (T - 64)-token prefix, the step replayed as a HIP graph
     decode = None
@@ -455,32 +815,68 @@ def main():
         except Exception as e_:                                   # the twin is informational: never fail the bench line on it
             cpu["full_layer"] = {"error": f"{type(e_).__name__}: {e_}"[:200]}
 
+    graph_on = lb.graph is not None
+    capture_error = lb.capture_error
+    headline_workload = (f"{args.workload} SEA attention layer forward (sparse mode, steps A-L), "
+                         f"H={H} d={d} T={T} k={k} predictor_length={T_M} nbf={w['nbf']}, "
+                         f"batch {NB} sequences/GPU, random-init weights seed 42, "
+                         f"context_layer {args.dtype} (reference default: fp32 -- see context_fp32), "
+                         + ("unpadded batch declared to the module (assume_not_padded: no mask inspection sync)"
+                            if not args.inspect_padding else "module inspects the mask for padding (one host sync)")
+                         + f", sparse kernel path {path}"
+                         + (", + RCCL all-gather of context shards" if world > 1 else "")
+                         + (", layer replayed as a HIP graph + eager fused-attention launch" if graph_on else ", eager launches"))
+
+    # ---- the other BASELINE shapes + the reference-default (fp32 context) twin of the headline: short legs, rank 0's GPU ----
+    other, ctx32, train = None, None, None
+    del out, ctx, q, kk, v, mask, layer
+    lb.release()
+    if gather is not None:
+        del gather
+    torch.cuda.empty_cache()
+    if world == 1 and not args.no_other_workloads:
+        other = {}
+        try:
+            ctx32 = short_leg(args.workload, NB, args, dev, ctx_dtype_name="fp32")
+            ctx32["tokens_per_s_note"] = "the headline layer writing context_layer in fp32, the reference's default (flat_csr_sdbmm.py:347)"
+        except Exception as e:
+            ctx32 = {"error": f"{type(e).__name__}: {e}"[:300]}
+        for wn, nb_ in OTHER_LEGS:
+            if wn == args.workload and nb_ == NB:
+                continue
+            try:
+                other[f"{wn} x{nb_}"] = short_leg(wn, nb_, args, dev)
+            except Exception as e:                               # a leg never takes the headline down; its failure is visible
+                other[f"{wn} x{nb_}"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if not args.no_train_step and args.dtype != "fp32":
+            try:
+                train = train_step_leg(args.workload, args, dev)
+            except Exception as e:
+                train = {"error": f"{type(e).__name__}: {e}"[:300]}
+
     if rank == 0:
         line = {
-            "metric": "tokens/sec + achieved HBM GB/s, OPT-1.3B SEA T=4096 k=64, 1/2/4/8 MI355X",
+            "metric": METRIC,
             "value": round(tokens_per_s, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": f"{args.workload} SEA attention layer forward (sparse mode, steps A-L), "
-                                   f"H={H} d={d} T={T} k={k} predictor_length={T_M} nbf={w['nbf']}, "
-                                   f"batch {NB} sequences/GPU, random-init weights seed 42, "
-                                   f"context_layer {args.dtype} (reference default: fp32), "
-                                   + ("unpadded batch declared to the module (assume_not_padded: no mask inspection sync)"
-                                      if not args.inspect_padding else "module inspects the mask for padding (one host sync)")
-                                   + f", sparse kernel path {args.sparse_kernel}"
-                                   + (", + RCCL all-gather of context shards" if world > 1 else "")
-                                   + (", layer replayed as a HIP graph + eager fused-attention launch" if graph is not None
-                                      else ", eager launches"),
-                       "global_batch": NB * world, "seq_len": T, "parallelism": f"dp{world} (batch shards)"},
-            "roofline": roof, "cpu_baseline": cpu, "output_check": output_check, "kernel_path": kernel_path,
-            "decode": decode, "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 3),
+            "config": {"workload": headline_workload, "global_batch": NB * world, "seq_len": T,
+                       "parallelism": f"dp{world} (batch shards)"},
+            "graph": graph_on, "graph_capture_error": capture_error,
+            "roofline": roof, "cpu_baseline": cpu, "output_check": output_check, "attention_path_ab": ab,
+            "collective": collective, "context_fp32": ctx32, "other_workloads": other, "train_step": train,
+            "kernel_path": kernel_path, "decode": decode,
+            "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 3),
             "regions_ms": {k_: round(v_ * 1e3, 4) for k_, v_ in sorted(regions.items())},
         }
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if output_check is not None and output_check["status"] != "ok":
+        return 5
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -169,6 +169,12 @@ int sea_sparse_attention(const void* q, const void* k, const void* v, int dtype,
  *                    runs K.Q^T, the masked online softmax and V^T.P^T on v_mfma_f32_16x16x32 with K/V rows fetched
  *                    once per tile -- the shape of the reference's flat_csr_sdbmm.py:141-313.  16-bit data,
  *                    D in {64, 80, 128}, no duplicate (row, column) pairs.  SEA_EUNSUPPORTED otherwise.
+ *                    CONTRACT (differs from the gather kernels): every V row below T_src must be FINITE.  A key that
+ *                    shares a 16-key tile with a kept key is staged and multiplied by an exact 0, and 0 * Inf = NaN
+ *                    (the reference's dense branch matmul(probs, v), attention.py:1128, has the same property); K rows
+ *                    may hold anything (their scores are replaced before use).  The gather kernels read kept keys only:
+ *                    a kv-cache whose unused slots are uninitialised takes SEA_ATTN_GATHER (as DecodeSession does) or
+ *                    zero-fills them;
  *   bits 8..11: row tiles per wave for the tile kernel (1 or 2; 0 = default for the head size);
  *   bits 12..15: log2 of its key window (6..12; 0 = default 2048).
  *

@@ -48,11 +48,38 @@ def source_hash():
     return h.hexdigest()
 
 
+def sources_present():
+    """The tree holds everything the library is built from (a tree that ships only a prebuilt .so does not)."""
+    return bool(_sources()) and all(os.path.exists(os.path.join(CSRC, s)) for s in SOURCES) and all(os.path.exists(h) for h in HEADERS)
+
+
 def is_stale():
-    """True when libsea_hip.so is missing or was built from other sources than the ones in the tree now."""
-    if not os.path.exists(LIB_PATH) or not os.path.exists(LIB_PATH + ".sha256"):
+    """True when libsea_hip.so is missing, or the sources are here and it was built from other ones (content hash).
+    A prebuilt library WITHOUT its sources or headers is current by definition: there is nothing to rebuild it from."""
+    if not os.path.exists(LIB_PATH):
+        return True
+    if not sources_present():
+        return False
+    if not os.path.exists(LIB_PATH + ".sha256"):
         return True
     return open(LIB_PATH + ".sha256").read().strip() != source_hash()
+
+
+def ensure_built(verbose=False):
+    """Build when stale, ONCE per tree however many processes ask at the same moment (the ranks of a multi-GPU job all
+    import the package together): an exclusive file lock serialises them, the first one in builds, the others find the
+    stamp current when their turn comes."""
+    if not is_stale():
+        return LIB_PATH
+    import fcntl
+    with open(LIB_PATH + ".lock", "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        try:
+            if is_stale():
+                build_library(verbose=verbose)
+        finally:
+            fcntl.flock(lk, fcntl.LOCK_UN)
+    return LIB_PATH
 
 
 def build_library(force=False, extra_flags=(), out=None, verbose=False):

@@ -92,7 +92,7 @@ def load(build_if_missing=True):
         if _build.is_stale():
             if not build_if_missing:
                 raise RuntimeError(f"{path} is missing or stale; run `python -c 'import __graft_entry__ as g; g.build()'`")
-            _build.build_library()
+            _build.ensure_built()                  # one builder per tree: the other ranks wait on the lock
     lib = ctypes.CDLL(path)
     for name, (argtypes, restype) in _SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported

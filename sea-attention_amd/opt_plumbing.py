@@ -220,10 +220,18 @@ class SeaOPTAttention(nn.Module):
             N, H, T, D = q.shape
             shape = (lambda c: c.view(N, H, T, D).transpose(1, 2).reshape(N, T, H * D))
             truth = (lambda f=truth: shape(f())) if callable(truth) else shape(truth)
-        out = self.perlin_self_attention(
-            query=self.q_proj, key=self.k_proj, value=self.v_proj, hidden_states=None, query_layer=q, key_layer=k,
-            value_layer=v, attention_mask=attention_mask, attention_scores_truth=self.teacher_attention_scores,
-            context_layer_truth=truth, last_state=state)
+        # sparse mode produces the per-entry probabilities only when somebody reads them (attention.return_attention_probs):
+        # output_attentions=True and the checkout hook do, for this call only (the reference always returns them,
+        # attention.py:1162-1171)
+        psa = self.perlin_self_attention
+        psa.want_attention_probs = bool(output_attentions) or bool(self.checkout_perlin_output)
+        try:
+            out = psa(
+                query=self.q_proj, key=self.k_proj, value=self.v_proj, hidden_states=None, query_layer=q, key_layer=k,
+                value_layer=v, attention_mask=attention_mask, attention_scores_truth=self.teacher_attention_scores,
+                context_layer_truth=truth, last_state=state)
+        finally:
+            psa.want_attention_probs = False
         self.last_loss = out.loss
         if self.checkout_perlin_output and not self.benchmarking:
             self.last_perlin_output = out

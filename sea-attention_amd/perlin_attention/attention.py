@@ -204,16 +204,14 @@ class PerlinAttention(nn.Module):
 
         self._keep_cache = {}
         # packed / re-laid-out copies of the predictor's weights are cached per tensor (ops.predictor._cached); a loaded
-        # state dict, a device move or a train/eval switch may come with weight edits the cache cannot see
+        # state dict or a device move may come with weight edits the cache cannot see
         self.register_load_state_dict_post_hook(lambda module, incompatible: ops.clear_prep_cache())
 
     def _apply(self, fn, *args, **kwargs):
+        # device / dtype moves: the cache's own keys (tensor identity, address, version) already miss afterwards; the clear
+        # also frees the old packs.  A train()/eval() switch edits no weight and does NOT clear.
         ops.clear_prep_cache()
         return super()._apply(fn, *args, **kwargs)
-
-    def train(self, mode: bool = True):
-        ops.clear_prep_cache()
-        return super().train(mode)
 
     # ------------------------------------------------------------------------------------------------
     def _keep_table(self, H, T_dst, T_src, T_M, device):

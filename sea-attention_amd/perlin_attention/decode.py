@@ -76,6 +76,7 @@ class DecodeSession:
         self.ctx = torch.zeros((N, 1, H * D), dtype=at.context_layer_dtype or torch.float32, device=dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.probs = None                                                    # estimated attention probabilities of the last step
+        self._pinned, self._prep_generation = None, ops.prep_generation()
         if use_graph:
             self._capture()
 
@@ -115,20 +116,30 @@ class DecodeSession:
 
     def _capture(self):
         """One eager step on a side stream would advance the state, so the capture runs against SAVED copies of the
-        mutable buffers, restored afterwards (a capture records launches, it does not execute them)."""
+        mutable buffers, restored afterwards (a capture records launches, it does not execute them).
+
+        The captured launches hold RAW POINTERS to the re-laid-out predictor weights of `ops.predictor._prep_cache` (MLP,
+        convolution, tail, LayerNorm and projection packs built lazily inside `_launch`).  The session pins the very
+        tensors its launches took from the cache (`ops.pinned_prep`), so a cache eviction -- `clear_prep_cache()` from
+        another layer's `.to()` / `load_state_dict`, or the cache's own size bound -- cannot free memory a replay still
+        reads; and it remembers the cache generation: `step()` re-captures when that has moved, because a cleared cache
+        means the weights may have been edited and the pinned packs may be stale."""
         saved = [t.clone() for t in (self.image, self.win, self.k_cache, self.v_cache, self.seen32, self.tsrc32, self.idx64)]
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side), torch.no_grad():                        # warm-up: lazy library work happens outside the capture
-            self._launch()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g), torch.no_grad():
-            self._launch()
+        with ops.pinned_prep() as pins:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), torch.no_grad():                    # warm-up: lazy library work happens outside the capture
+                self._launch()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g), torch.no_grad():
+                self._launch()
         for dst, src in zip((self.image, self.win, self.k_cache, self.v_cache, self.seen32, self.tsrc32, self.idx64), saved):
             dst.copy_(src)
         self.graph = g
+        self._pinned = pins
+        self._prep_generation = ops.prep_generation()
 
     def export_state(self) -> PerlinAttentionState:
         """The session's state as the `PerlinAttentionState` a cached forward continues from (copies: the session keeps
@@ -151,6 +162,9 @@ class DecodeSession:
         self.k_in.copy_(k)
         self.v_in.copy_(v)
         if self.graph is not None:
+            if ops.prep_generation() != self._prep_generation:     # the weight packs were dropped (weights may have changed):
+                self.graph = None                                  # capture again against freshly prepared ones
+                self._capture()
             self.graph.replay()
         else:
             self._launch()

@@ -305,7 +305,9 @@ def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = 
     permuted view of an (N,T_dst,H*D) buffer to get the layout of attention.py:1279-1282 directly.
     Default output: fp32 (N,H,T_dst,D) (flat_csr_sdbmm.py:347 returns fp32).
     path: "auto" | "gather" (row-indexed gather kernels) | "tile" (MFMA tile kernel: 16-bit data, D in {64,80,128});
-    row_tiles / key_window tune the tile kernel (0 = defaults).
+    row_tiles / key_window tune the tile kernel (0 = defaults).  The tile kernel (also inside "auto" with a plan) stages whole
+    16-key tiles: every V row below T_src must be finite, kept or not (0 * Inf = NaN; include/sea_hip.h); the gather kernels
+    read kept keys only.
     plan: with path="auto", the per-block dispatch of `attention_plan` (both kernels are launched, each wave runs the
     16-row blocks its kernel owns); without it "auto" means the gather kernels.
     want_probs: also return the per-entry values rs * softmax (fp32, laid out like csr.col) -- what the reference

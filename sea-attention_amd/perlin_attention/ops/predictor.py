@@ -16,14 +16,38 @@ def _p(t):
 
 
 _prep_cache = {}
+_prep_generation = 0          # bumped by clear_prep_cache(): holders of raw pointers into cached packs compare it
+_prep_recorders = []          # lists that collect every value `_cached` hands out while a `pinned_prep()` block is open
 
 
 def clear_prep_cache():
     """Drop every cached re-layout of constant weights.  The cache notices new tensors, `.to(device)` moves,
     storage swaps and in-place autograd-visible edits by itself; an edit made behind autograd's back
     (`param.data.mul_()`, `param.data.copy_()`: EMA swaps, pruning) bumps no version counter, so whoever does
-    that calls this afterwards.  `PerlinAttention.load_state_dict / train / _apply` call it (attention.py)."""
+    that calls this afterwards.  `PerlinAttention.load_state_dict / _apply` call it (attention.py).  A captured HIP
+    graph holds raw pointers into the packs: `DecodeSession` pins the ones its launches used and re-captures when
+    `prep_generation()` has moved."""
+    global _prep_generation
+    _prep_generation += 1
     _prep_cache.clear()
+
+
+def prep_generation() -> int:
+    return _prep_generation
+
+
+class pinned_prep:
+    """`with pinned_prep() as pins:` -- `pins` collects every prepared tensor (tuple) the operators inside the block take from
+    the cache or build: keeping the list alive keeps their memory alive, whatever happens to the cache afterwards."""
+
+    def __enter__(self):
+        self.values = []
+        _prep_recorders.append(self.values)
+        return self.values
+
+    def __exit__(self, *exc):
+        _prep_recorders.remove(self.values)
+        return False
 
 
 def _cached(tag, tensors, dtype, build):
@@ -35,14 +59,18 @@ def _cached(tag, tensors, dtype, build):
     key = (tag, dtype) + tuple((id(b), t.storage_offset(), tuple(t.shape), tuple(t.stride()), t.data_ptr(), str(t.device))
                                for b, t in zip(bases, tensors))
     hit = _prep_cache.get(key)
+    value = None
     if hit is not None:
-        refs, versions, value = hit
+        refs, versions, val = hit
         if all(r() is b for r, b in zip(refs, bases)) and versions == [b._version for b in bases]:
-            return value
-    if len(_prep_cache) > 256:
-        _prep_cache.clear()
-    value = build()
-    _prep_cache[key] = ([weakref.ref(b) for b in bases], [b._version for b in bases], value)
+            value = val
+    if value is None:
+        if len(_prep_cache) > 256:
+            _prep_cache.clear()
+        value = build()
+        _prep_cache[key] = ([weakref.ref(b) for b in bases], [b._version for b in bases], value)
+    for rec in _prep_recorders:
+        rec.append(value)
     return value
 
 

@@ -43,6 +43,7 @@ class PerlinSelfAttention(nn.Module):
         self.attention = PerlinAttention(config=config, perlin_config=perlin_config)
         self._gradient_checkpointing = False
         self.checkout_last_attention_probs = False
+        self.want_attention_probs = False          # per-call request of the caller (output_attentions=True)
         self.last_attention_probs = None
 
     def transpose_for_scores(self, x: torch.Tensor) -> torch.Tensor:
@@ -102,15 +103,23 @@ class PerlinSelfAttention(nn.Module):
                 query_layer_for_atten, key_layer_for_atten, value_layer_for_atten,
                 query_layer_for_score, key_layer_for_score,
                 attention_mask, attention_scores_truth, context_layer_truth, last_state)
-        if self.checkout_last_attention_probs:                  # sparse mode computes the CSR probabilities only on request
-            self.attention.return_attention_probs = True
-        if self._gradient_checkpointing and self.training:
-            def run(*a):
-                return tuple(self.attention(*a))
-            output = PerlinAttentionOutput(*torch.utils.checkpoint.checkpoint(
-                run, *args, use_reentrant=True, preserve_rng_state=True))
-        else:
-            output = self.attention(*args)
+        # sparse mode computes the CSR probabilities only on request.  For THIS call the module's flag is the OR of what was
+        # set on the module directly, `checkout_last_attention_probs`, and what this call's caller asked for
+        # (`want_attention_probs`: the OPT block's output_attentions=True); it is put back afterwards, so switching
+        # `checkout_last_attention_probs` off again also stops the extra per-entry store
+        att = self.attention
+        flag_before = att.return_attention_probs
+        att.return_attention_probs = bool(flag_before or self.checkout_last_attention_probs or self.want_attention_probs)
+        try:
+            if self._gradient_checkpointing and self.training:
+                def run(*a):
+                    return tuple(self.attention(*a))
+                output = PerlinAttentionOutput(*torch.utils.checkpoint.checkpoint(
+                    run, *args, use_reentrant=True, preserve_rng_state=True))
+            else:
+                output = self.attention(*args)
+        finally:
+            att.return_attention_probs = flag_before
 
         if self.checkout_last_attention_probs:
             self.last_attention_probs = output.partial_attention_probs

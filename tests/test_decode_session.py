@@ -139,3 +139,41 @@ def test_session_long_run_stays_bitwise():
                 bad.append(hi)
         assert not bad, bad[:10]
         assert sess.length == T0 + steps
+
+
+def test_session_survives_a_cleared_weight_cache_and_follows_edited_weights():
+    """the captured graph holds raw pointers into the re-laid-out predictor weights of the process-wide prep cache.
+    (1) the session pins the packs its launches used, so `clear_prep_cache()` (another layer's `.to()` / `load_state_dict`)
+    followed by allocations that would recycle their memory cannot corrupt a replay; (2) a cleared cache means the weights
+    may have been edited behind autograd's back: the session re-captures and the next position uses the NEW weights, exactly
+    like the eager cached forward."""
+    from sea_attention_amd.perlin_attention import ops
+    dtype, N, H, d, T_M, k, T0, steps = torch.bfloat16, 1, 4, 64, 256, 16, 40, 6
+    layer = _layer(H, d, T_M, k, T0 + steps + 1, dtype)
+    S.seed(23)
+    x = torch.randn((N, H, T0 + steps, d), device=DEV).to(dtype)
+    q = (x.float() * d ** -0.5).to(dtype)
+    with torch.no_grad():
+        out = layer(None, None, None, query_layer=q[:, :, :T0], key_layer=x[:, :, :T0], value_layer=x[:, :, :T0],
+                    attention_mask=_mask(N, T0, T0, dtype))
+        state = out.state
+        sess = layer.attention.decode_session(state, x[:, :, :T0], x[:, :, :T0], capacity=T0 + steps)
+        assert sess.graph is not None and sess._pinned, "the capture pinned the packs it points into"
+        gen0 = sess._prep_generation
+        for i in range(steps):
+            hi = T0 + i + 1
+            if i == 2:
+                ops.clear_prep_cache()                                      # e.g. model.to(...) on another layer
+                junk = [torch.randn(1 << 16, device=DEV) for _ in range(64)]   # would land in the freed packs' memory
+            if i == 4:
+                # an edit behind autograd's back (no version bump) + the documented hook
+                layer.attention.attention_predictor_dec_row[0].weight.data.mul_(1.5)
+                ops.clear_prep_cache()
+            ref = layer(None, None, None, query_layer=q[:, :, hi - 1:hi], key_layer=x[:, :, :hi], value_layer=x[:, :, :hi],
+                        attention_mask=_mask(N, 1, hi, dtype), last_state=state)
+            state = ref.state
+            got = sess.step(q[:, :, hi - 1:hi], x[:, :, hi - 1:hi], x[:, :, hi - 1:hi])
+            assert torch.equal(got, ref.context_layer), i
+            assert torch.equal(sess.probs, ref.estimated_attention_probs_m), i
+        assert sess._prep_generation == ops.prep_generation() and sess._prep_generation >= gen0 + 2
+        del junk

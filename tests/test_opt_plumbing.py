@@ -205,3 +205,56 @@ def test_block_generates_through_the_graph_replayed_session(restore_default):
         _, _, past = blk(x[:, :1], past_key_value=past, attention_mask=P.causal_additive_mask(N, 1, T + 1, dtype, dev))
         with pytest.raises(AssertionError, match="stale"):
             blk(x[:, :1], past_key_value=stale, attention_mask=P.causal_additive_mask(N, 1, T + 1, dtype, dev))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cached", [False, True])
+def test_output_attentions_returns_the_sparse_probabilities(restore_default, cached):
+    """in sparse mode `output_attentions=True` must hand back the reference's `partial_attention_probs`
+    (attention.py:1162-1171: rs * softmax on the mask's CSR) -- not None -- in the stateless and in the cached path, for that
+    call only (the per-entry store stays off for calls that do not ask); values equal to the probing path's."""
+    import sea_attention_amd as S
+    dev, dtype = "cuda", torch.bfloat16
+    cfg = P.perlin_config_from_options(perlin_k=16, perlin_predictor_length=256, perlin_performer_nb_feature_factor=8,
+                                       perlin_context_output_method="mix")
+    cfg.use_cache = cached
+    torch.manual_seed(11)
+    blk = P.SeaOPTAttention(4 * 64, 4, max_position_embeddings=256).to(dev, dtype).eval()
+    blk.benchmarking = True
+    att = blk.perlin_self_attention.attention
+    N, T = 2, 192
+    x = torch.randn(N, T, 4 * 64, device=dev, dtype=dtype)
+    mask = P.causal_additive_mask(N, T, T, dtype, dev)
+    with torch.no_grad():
+        y0, p0, _ = blk(x, attention_mask=mask)
+        assert p0 is None and att.return_attention_probs is False
+        y1, p1, _ = blk(x, attention_mask=mask, output_attentions=True)
+        assert att.return_attention_probs is False                         # restored after the call
+    assert p1 is not None and p1.vals is not None
+    assert torch.equal(y0, y1) or (y0.float() - y1.float()).abs().max().item() < 2e-2   # auto may run the tile kernel without probs
+    # the same values through the operator with want_probs (what probing registers as partial_attention_probs)
+    from sea_attention_amd.perlin_attention import ops
+    with torch.no_grad():
+        q = blk._heads(blk.q_proj(x) * blk.scaling)
+        k, v = blk._heads(blk.k_proj(x)), blk._heads(blk.v_proj(x))
+        out = blk.perlin_self_attention(blk.q_proj, blk.k_proj, blk.v_proj, None, q, k, v, mask, None, None)
+        assert out.partial_attention_probs is None
+        csr = p1
+        z = int(csr.crow[0, -1].item())
+        # rows of the probabilities sum to the row scale per (row, head): softmax mass 1 x sigmoid gate in (0, 1)
+        dense = ops.flat_csr_to_dense(csr, T, 4)                              # (N, H, T, T)
+        s = dense.sum(-1)
+        assert z > 0 and torch.isfinite(dense).all() and (s > 0).all() and (s < 1.0 + 1e-3).all()
+        # and they are the values of the fused kernel's own probs output on the same CSR
+        rs = None
+        S.get_bench().activate_temp_buffers = True
+        try:
+            S.get_bench().reset_temp_buffers()
+            att.benchmarking = True
+            if not cached:
+                blk.perlin_self_attention(blk.q_proj, blk.k_proj, blk.v_proj, None, q, k, v, mask, None, None)
+                probe = S.get_bench().get_temp_buffer('partial_attention_probs')
+                assert (probe.float() - dense.float()).abs().max().item() < 1e-6
+        finally:
+            S.get_bench().activate_temp_buffers = False
+            S.get_bench().reset_temp_buffers()
