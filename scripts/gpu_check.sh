@@ -14,7 +14,7 @@ run() {  # run <name> <timeout_s> <cmd...>
 }
 rm -f gpurun_out/progress.log
 run smoke 300 python -c "import __graft_entry__ as g; g.smoke()"; tail -3 gpurun_out/smoke.log
-run pytest_gpu 1000 python -m pytest tests -m gpu -q -x --timeout 600 ${PYTEST_EXTRA:-}; tail -25 gpurun_out/pytest_gpu.log
+run pytest_gpu 1000 python -m pytest tests -m gpu -q ${PYTEST_X--x} --timeout 600 ${PYTEST_EXTRA:-}; tail -${PYTEST_TAIL:-25} gpurun_out/pytest_gpu.log
 if [ "${SKIP_BENCH:-0}" != "1" ]; then
   run bench 600 python bench.py --steps ${BENCH_STEPS:-10} --warmup 3 --decode-steps 32 ${BENCH_EXTRA:-}; tail -5 gpurun_out/bench.log
 fi

@@ -11,7 +11,7 @@ mkdir -p "$OUT"; cd "$GRAFT_REPO_ROOT"
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   N=$(echo $C | tr ' ' '_')
   timeout -k 10 600 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/$N" -o pmc -- \
-    python3 bench.py --steps 3 --warmup 1 --prewarm 2 --no-cpu-baseline --kernel-iters 0 --no-output-check ${BENCH_EXTRA:-} > "$OUT/$N.log" 2>&1
+    python3 bench.py --steps 3 --warmup 1 --prewarm 2 --no-cpu-baseline --kernel-iters 0 --no-output-check --no-other-workloads --no-train-step --sparse-kernel ${ATTN_PATH:-auto} ${BENCH_EXTRA:-} > "$OUT/$N.log" 2>&1
   echo "pmc $N exit=$?"; tail -c 400 "$OUT/$N.log"; echo
 done
 find "$OUT" -name "*counter_collection.csv" | head

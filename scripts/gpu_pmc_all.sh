@@ -12,7 +12,7 @@ for C in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ
          "SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VMEM_WR SQ_INSTS_SMEM SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD GRBM_GUI_ACTIVE"; do
   i=$((i+1))
   timeout -k 10 300 rocprofv3 --kernel-trace --pmc $C --output-format csv -d "$OUT/g$i" -o pmc -- \
-    python3 bench.py --steps 2 --warmup 1 --prewarm 1 --no-cpu-baseline --kernel-iters 0 --no-output-check "$@" > "$OUT/g$i.log" 2>&1
+    python3 bench.py --steps 2 --warmup 1 --prewarm 1 --no-cpu-baseline --kernel-iters 0 --no-output-check --no-other-workloads --no-train-step --sparse-kernel ${ATTN_PATH:-auto} "$@" > "$OUT/g$i.log" 2>&1
   echo "group $i exit=$?"
 done
 OUTDIR="$OUT" python3 - <<'PY'
