@@ -206,6 +206,24 @@ int sea_sparse_attention_bwd(const void* q, const void* k, const void* v, int dt
                              const float* probs, int64_t probs_stride_n, const float* out, const float* dout,
                              float* dq, float* dk, float* dv, sea_stream_t stream);
 
+/* The same backward WITHOUT float atomics (round 3): dK / dV are gathered over the transposed pattern.  The library counts
+ * the entries of every (n, head, key) column (int32 atomics), scans them into list starts, lets the row pass (dQ, plain
+ * stores) drop a 16-byte record {row, p, ds} into its key's list, and a column pass (one lane group per key) sums
+ * dK = sum ds q_row, dV = sum p dO_row with plain stores -- every dk / dv row is written, the caller does NOT zero them.
+ * Same arguments as sea_sparse_attention_bwd plus a caller-owned scratch buffer of
+ * sea_sparse_attention_bwd_workspace_bytes(N, H, T_src, col_stride_n) bytes (16-byte aligned; contents undefined afterwards).
+ * Rows wider than 16 lanes (fp32 with D > 64) are SEA_EUNSUPPORTED here and take the atomic form.  The records of a key are
+ * in the order the row pass reached them: sums agree between runs to fp32 rounding, like the atomic form.
+ * Reference shape: masked_mm.py:169-267 (gradients flow through the kept entries only). */
+int64_t sea_sparse_attention_bwd_workspace_bytes(int64_t N, int64_t H, int64_t T_src, int64_t col_stride_n);
+int sea_sparse_attention_bwd_gather(const void* q, const void* k, const void* v, int dtype,
+                                    int64_t N, int64_t H, int64_t T_dst, int64_t T_src, int64_t D,
+                                    const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                                    const int32_t* crow, const int32_t* col, int64_t col_stride_n, const int32_t* head_off,
+                                    const float* probs, int64_t probs_stride_n, const float* out, const float* dout,
+                                    float* dq, float* dk, float* dv, void* workspace, int64_t workspace_bytes,
+                                    sea_stream_t stream);
+
 /* Per-block dispatch plan for SEA_ATTN_AUTO: one byte per (n, h, 16-row block), 1 = the tile kernel owns the block, 0 = the
  * gather kernels do.  With a plan, sea_sparse_attention_ex launches BOTH kernels over all rows and every wave runs only the
  * blocks its kernel owns (no host round trip, graph-capturable).  The plan is estimated from the kept-pixel bit masks of

@@ -37,6 +37,9 @@ _SIGNATURES = {
                                  ptr, ptr, i64, ptr, ptr, ptr, _i64p, ptr, ptr, c_int, _i64p, ptr, i64, ptr, c_int, ptr], c_int),
     "sea_sparse_attention_bwd": ([ptr, ptr, ptr, c_int, i64, i64, i64, i64, i64, _i64p, _i64p, _i64p, ptr, ptr, i64, ptr,
                                   ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr], c_int),
+    "sea_sparse_attention_bwd_workspace_bytes": ([i64, i64, i64, i64], i64),
+    "sea_sparse_attention_bwd_gather": ([ptr, ptr, ptr, c_int, i64, i64, i64, i64, i64, _i64p, _i64p, _i64p, ptr, ptr, i64, ptr,
+                                         ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr, i64, ptr], c_int),
     "sea_attention_plan": ([ptr, i64, i64, i64, i64, i64, c_int, ctypes.c_float, ptr, ptr], c_int),
     "sea_sparse_attention_bytes": ([i64, i64, i64, i64, i64, c_int], i64),
     "sea_split_layernorm": ([ptr, c_int, i64, i64, i64, i64, i64, ptr, ptr, ctypes.c_float, c_int, ptr, ptr], c_int),

@@ -136,6 +136,246 @@ __global__ __launch_bounds__(256) void sparse_attn_bwd_kernel(AttnBwdParams p) {
   }
 }
 
+// ---- gather form (round 3): dK / dV without float atomics -----------------------------------------------------------------
+// The scatter of the row pass above (every (row, key) entry adds D floats to dK_key and dV_key with memory-side atomics,
+// ~1.3 TB/s chip-wide) becomes a gather over the TRANSPOSED pattern:
+//   1. csc_count_kernel    entries per (n, head * T_src + key): one int32 atomic per entry (L2 integer atomics);
+//   2. csc_scan_kernel     exclusive scan -> start of every key's list (`cptr`) + a working copy (`cursor`);
+//   3. bwd_rows_kernel     one lane group per query row (the forward's geometry): dp_j = dO . v_j, ds_j = p_j (dp_j - delta),
+//                          dQ = sum_j ds_j k_j (plain store), and a 16-byte record {t, p_j, ds_j} dropped into the key's
+//                          list at a slot taken from `cursor` (one returning int32 atomic per entry);
+//   4. bwd_cols_kernel     one lane group per (n, h, key): walks the key's records, gathers q_t (input dtype) and dO_t
+//                          (fp32) rows, dK = sum ds q, dV = sum p dO -- plain stores, every row written (no zero-fill).
+// The order of a key's records is the order the row pass reached them: sums differ between runs in fp32 rounding only,
+// like the atomic form.
+struct BwdRec { int32_t t; float p; float ds; int32_t pad; };
+
+struct BwdGatherParams {
+  AttnBwdParams a;
+  int32_t* cptr;       // (N, C + 1), C = H * T_src
+  int32_t* cursor;     // (N, C + 1)
+  BwdRec* recs;        // (N, rec_stride_n)
+  int64_t rec_stride_n;
+  int64_t C;
+};
+
+__global__ __launch_bounds__(256) void csc_count_kernel(const int32_t* __restrict__ crow, const int32_t* __restrict__ col,
+                                                        int64_t col_stride_n, int T_dst, int64_t C, int32_t* __restrict__ cnt) {
+  const int n = blockIdx.y;
+  const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int z = crow[(int64_t)n * (T_dst + 1) + T_dst];
+  if (e >= z) return;
+  atomicAdd(cnt + (int64_t)n * (C + 1) + col[n * col_stride_n + e], 1);
+}
+
+// one 1024-thread workgroup per batch item: cnt[n][0..C) -> exclusive scan in place (cnt[n][C] = total), copied to cursor
+__global__ __launch_bounds__(1024) void csc_scan_kernel(int32_t* __restrict__ cptr, int32_t* __restrict__ cursor, int64_t C) {
+  __shared__ int s_wave[16];
+  __shared__ int s_carry;
+  const int n = blockIdx.x;
+  int32_t* c = cptr + (int64_t)n * (C + 1);
+  int32_t* u = cursor + (int64_t)n * (C + 1);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_carry = 0;
+  __syncthreads();
+  for (int64_t i0 = 0; i0 < C; i0 += 1024) {
+    const int64_t i = i0 + threadIdx.x;
+    const int x = i < C ? c[i] : 0;
+    const int inc = wave_incl_scan(x);
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    int woff = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) woff += (w < wv) ? s_wave[w] : 0;
+    const int carry = s_carry;
+    const int ex = carry + woff + inc - x;
+    if (i < C) { c[i] = ex; u[i] = ex; }
+    __syncthreads();
+    if (threadIdx.x == 1023) s_carry = carry + woff + inc;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { c[C] = s_carry; u[C] = s_carry; }
+}
+
+template <typename T, int LPR, int U>
+__global__ __launch_bounds__(256) void sparse_attn_bwd_rows_kernel(BwdGatherParams g) {
+  const AttnBwdParams& p = g.a;
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int RPW = 64 / LPR, RPB = 4 * RPW;
+  int pair, tb;
+  if (!map_block(p.N * p.H, p.TB, &pair, &tb)) return;
+  const int n = pair / p.H, h = pair - n * p.H;
+  const int lane = threadIdx.x & 63;
+  const int grp = lane / LPR, sub = lane - grp * LPR;
+  const int t = tb * RPB + (threadIdx.x >> 6) * RPW + grp;
+  const bool rowok = t < p.T_dst;
+  const bool dact = sub * VEC < p.D;
+  const int tt = rowok ? t : p.T_dst - 1;
+  const int d0 = dact ? sub * VEC : 0;
+
+  float go[VEC];
+  float dl = 0.f;
+  {
+    const int64_t ro = (((int64_t)n * p.H + h) * p.T_dst + tt) * p.D + d0;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      go[j] = (dact && rowok) ? p.dout[ro + j] : 0.f;
+      const float of = (dact && rowok) ? p.out[ro + j] : 0.f;
+      dl = fmaf(go[j], of, dl);
+    }
+  }
+  const float delta = bgroup_sum<LPR>(dl);                 // dO . o = sum_j p_j dp_j
+
+  const int row_beg = p.crow[(int64_t)n * (p.T_dst + 1) + tt];
+  const int32_t* ho = p.head_off + ((int64_t)n * p.T_dst + tt) * (p.H + 1);
+  const int beg = row_beg + ho[h];
+  const int end = rowok ? row_beg + ho[h + 1] : beg;
+  const int32_t* col = p.col + n * p.col_stride_n;
+  const float* pr = p.probs + n * p.probs_stride_n;
+  const int hcol = h * p.T_src;
+  const T* kb = reinterpret_cast<const T*>(p.k) + n * p.ks[0] + h * p.ks[1] + d0;
+  const T* vb = reinterpret_cast<const T*>(p.v) + n * p.vs[0] + h * p.vs[1] + d0;
+  int32_t* cursor = g.cursor + (int64_t)n * (g.C + 1);
+  BwdRec* recs = g.recs + n * g.rec_stride_n;
+
+  float dqa[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) dqa[j] = 0.f;
+  int zmax = end - beg;                                    // the wave walks as long as its longest row
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) zmax = max(zmax, __shfl_xor(zmax, o));
+  const int grp_lane0 = (lane - sub) << 2;
+  for (int i0 = 0; i0 < zmax; i0 += LPR) {
+    // lane `sub` owns entry i0 + sub of the row: its column, its probability, and -- after the walk -- its ds
+    const int e_mine = beg + i0 + sub;
+    const bool mine = e_mine < end;
+    // lanes past the row's end re-read the row's own last entry with p = 0 (a kept key: finite rows), empty rows key 0
+    const int c_mine = mine ? col[e_mine] : (end > beg ? col[end - 1] : hcol);   // head * T_src + key
+    const float p_mine = mine ? pr[e_mine] : 0.f;
+    float ds_mine = 0.f;
+#pragma unroll
+    for (int u0 = 0; u0 < LPR; u0 += U) {
+      if (i0 + u0 < zmax) {                                // wave-uniform
+        uint4 kr[U], vr[U];
+        float pu[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int key = __builtin_amdgcn_ds_bpermute(grp_lane0 + ((u0 + u) << 2), c_mine) - hcol;
+          pu[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(grp_lane0 + ((u0 + u) << 2), __float_as_int(p_mine)));
+          kr[u] = make_uint4(0, 0, 0, 0);
+          vr[u] = make_uint4(0, 0, 0, 0);
+          if (dact) {
+            kr[u] = *reinterpret_cast<const uint4*>(kb + (int64_t)key * p.ks[2]);
+            vr[u] = *reinterpret_cast<const uint4*>(vb + (int64_t)key * p.vs[2]);
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          float kf[VEC], vf[VEC];
+          unpack16<T>(kr[u], kf);
+          unpack16<T>(vr[u], vf);
+          float dp = 0.f;
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) dp = fmaf(go[j], vf[j], dp);
+          dp = bgroup_sum<LPR>(dp);
+          const float ds = (pu[u] != 0.f) ? pu[u] * (dp - delta) : 0.f;   // p = 0: padding, or an entry that underflowed (a non-finite V row there must not reach dQ)
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) dqa[j] = fmaf(ds, kf[j], dqa[j]);
+          if (sub == u0 + u) ds_mine = ds;
+        }
+      }
+    }
+    if (mine) {
+      const int pos = atomicAdd(cursor + c_mine, 1);
+      BwdRec r;
+      r.t = t; r.p = p_mine; r.ds = ds_mine; r.pad = 0;
+      *reinterpret_cast<uint4*>(recs + pos) = __builtin_bit_cast(uint4, r);
+    }
+  }
+  if (rowok && dact) {
+    float* dqr = p.dq + (((int64_t)n * p.H + h) * p.T_dst + t) * p.D + d0;
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) dqr[j] = dqa[j];
+  }
+}
+
+// one LPR-lane group per (n, h, key): dK_key = sum over the key's records of ds * q_t, dV_key = sum of p * dO_t
+template <typename T, int LPR, int U>
+__global__ __launch_bounds__(256) void sparse_attn_bwd_cols_kernel(BwdGatherParams g) {
+  const AttnBwdParams& p = g.a;
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int RPW = 64 / LPR, RPB = 4 * RPW;
+  int pair, tb;
+  if (!map_block(p.N * p.H, p.TB, &pair, &tb)) return;
+  const int n = pair / p.H, h = pair - n * p.H;
+  const int lane = threadIdx.x & 63;
+  const int grp = lane / LPR, sub = lane - grp * LPR;
+  const int key = tb * RPB + (threadIdx.x >> 6) * RPW + grp;
+  const bool keyok = key < p.T_src;
+  const bool dact = sub * VEC < p.D;
+  const int d0 = dact ? sub * VEC : 0;
+  const int32_t* cptr = g.cptr + (int64_t)n * (g.C + 1) + (int64_t)h * p.T_src;
+  const int beg = keyok ? cptr[key] : 0;
+  const int end = keyok ? cptr[key + 1] : 0;
+  const BwdRec* recs = g.recs + n * g.rec_stride_n;
+  const T* qb = reinterpret_cast<const T*>(p.q) + n * p.qs[0] + h * p.qs[1] + d0;
+  const float* gob = p.dout + ((int64_t)n * p.H + h) * p.T_dst * p.D + d0;
+
+  float dk[VEC], dv[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { dk[j] = 0.f; dv[j] = 0.f; }
+  int zmax = end - beg;
+#pragma unroll
+  for (int o = LPR; o < 64; o <<= 1) zmax = max(zmax, __shfl_xor(zmax, o));
+  const int grp_lane0 = (lane - sub) << 2;
+  for (int i0 = 0; i0 < zmax; i0 += LPR) {
+    const int e_mine = beg + i0 + sub;
+    uint4 rm = make_uint4(0, 0, 0, 0);                     // t = 0, p = 0, ds = 0: a finite row, zero weights
+    if (e_mine < end) rm = *reinterpret_cast<const uint4*>(recs + e_mine);
+#pragma unroll
+    for (int u0 = 0; u0 < LPR; u0 += U) {
+      if (i0 + u0 < zmax) {                                // wave-uniform
+        uint4 qr[U];
+        float gf[U][VEC], pu[U], dsu[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int src = grp_lane0 + ((u0 + u) << 2);
+          const int t = __builtin_amdgcn_ds_bpermute(src, (int)rm.x);
+          pu[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, (int)rm.y));
+          dsu[u] = __int_as_float(__builtin_amdgcn_ds_bpermute(src, (int)rm.z));
+          qr[u] = make_uint4(0, 0, 0, 0);
+          if (dact) qr[u] = *reinterpret_cast<const uint4*>(qb + (int64_t)t * p.qs[2]);
+          const float* gr = gob + (int64_t)t * p.D;
+#pragma unroll
+          for (int j4 = 0; j4 < VEC; j4 += 4) {
+            float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (dact) x = *reinterpret_cast<const float4*>(gr + j4);
+            gf[u][j4] = x.x; gf[u][j4 + 1] = x.y; gf[u][j4 + 2] = x.z; gf[u][j4 + 3] = x.w;
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          float qf[VEC];
+          unpack16<T>(qr[u], qf);
+#pragma unroll
+          for (int j = 0; j < VEC; ++j) {
+            dk[j] = fmaf(dsu[u], qf[j], dk[j]);
+            dv[j] = fmaf(pu[u], gf[u][j], dv[j]);
+          }
+        }
+      }
+    }
+  }
+  if (keyok && dact) {
+    const int64_t ro = (((int64_t)n * p.H + h) * p.T_src + key) * p.D + d0;
+#pragma unroll
+    for (int j4 = 0; j4 < VEC; j4 += 4) {
+      *reinterpret_cast<float4*>(p.dk + ro + j4) = make_float4(dk[j4], dk[j4 + 1], dk[j4 + 2], dk[j4 + 3]);
+      *reinterpret_cast<float4*>(p.dv + ro + j4) = make_float4(dv[j4], dv[j4 + 1], dv[j4 + 2], dv[j4 + 3]);
+    }
+  }
+}
+
 static int blanes_per_row(int D, int vec) {
   const int need = (D + vec - 1) / vec;
   int l = 1;
@@ -158,6 +398,38 @@ static int launch_bwd(AttnBwdParams p, hipStream_t s) {
     case 32: hipLaunchKernelGGL((sparse_attn_bwd_kernel<T, 32>), grid, block, 0, s, p); break;
     case 64: hipLaunchKernelGGL((sparse_attn_bwd_kernel<T, 64>), grid, block, 0, s, p); break;
     default: return SEA_EUNSUPPORTED;
+  }
+  return SEA_OK;
+}
+
+template <typename T>
+static int launch_bwd_gather(BwdGatherParams g, hipStream_t s) {
+  AttnBwdParams& p = g.a;
+  const int lpr = blanes_per_row(p.D, Elem<T>::VEC);
+  if (lpr > 16) return SEA_EUNSUPPORTED;                    // fp32 d >= 128: the atomic form serves those
+  const int rpb = 4 * (64 / lpr);
+  const int NH8 = 8 * ((p.N * p.H + 7) / 8);
+  if (hipMemsetAsync(g.cptr, 0, (size_t)p.N * (g.C + 1) * sizeof(int32_t), s) != hipSuccess) return SEA_ELAUNCH;
+  const int64_t zb = (p.col_stride_n + 255) / 256;
+  if (zb >= (1ll << 31) || p.N > 65535) return SEA_EUNSUPPORTED;
+  hipLaunchKernelGGL(csc_count_kernel, dim3((unsigned)zb, (unsigned)p.N), dim3(256), 0, s, p.crow, p.col, p.col_stride_n, p.T_dst,
+                     g.C, g.cptr);
+  hipLaunchKernelGGL(csc_scan_kernel, dim3((unsigned)p.N), dim3(1024), 0, s, g.cptr, g.cursor, g.C);
+  p.TB = (p.T_dst + rpb - 1) / rpb;
+  int64_t blocks = (int64_t)NH8 * p.TB;
+  if (blocks >= (1ll << 31)) return SEA_EUNSUPPORTED;
+  switch (lpr) {
+    case 4: hipLaunchKernelGGL((sparse_attn_bwd_rows_kernel<T, 4, 4>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;
+    case 8: hipLaunchKernelGGL((sparse_attn_bwd_rows_kernel<T, 8, 4>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;
+    default: hipLaunchKernelGGL((sparse_attn_bwd_rows_kernel<T, 16, 4>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;
+  }
+  p.TB = (p.T_src + rpb - 1) / rpb;
+  blocks = (int64_t)NH8 * p.TB;
+  if (blocks >= (1ll << 31)) return SEA_EUNSUPPORTED;
+  switch (lpr) {
+    case 4: hipLaunchKernelGGL((sparse_attn_bwd_cols_kernel<T, 4, 4>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;
+    case 8: hipLaunchKernelGGL((sparse_attn_bwd_cols_kernel<T, 8, 4>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;
+    default: hipLaunchKernelGGL((sparse_attn_bwd_cols_kernel<T, 16, 4>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;
   }
   return SEA_OK;
 }
@@ -196,6 +468,59 @@ extern "C" int sea_sparse_attention_bwd(const void* q, const void* k, const void
   else if (dtype == SEA_F16) rc = launch_bwd<__half>(p, (hipStream_t)stream);
   else rc = launch_bwd<__hip_bfloat16>(p, (hipStream_t)stream);
   SEA_REQUIRE(rc == SEA_OK, rc, "%s: unsupported head size %lld", nm, (long long)D);
+  SEA_CHECK_LAUNCH(nm);
+  return SEA_OK;
+}
+
+static int64_t bwd_ws_ints(int64_t N, int64_t H, int64_t T_src) { return ((N * (H * T_src + 1) + 3) / 4) * 4; }   // 16-byte multiples
+
+extern "C" int64_t sea_sparse_attention_bwd_workspace_bytes(int64_t N, int64_t H, int64_t T_src, int64_t col_stride_n) {
+  if (N <= 0 || H <= 0 || T_src <= 0 || col_stride_n <= 0) return 0;
+  return 2 * bwd_ws_ints(N, H, T_src) * 4 + N * col_stride_n * (int64_t)sizeof(BwdRec);
+}
+
+extern "C" int sea_sparse_attention_bwd_gather(const void* q, const void* k, const void* v, int dtype, int64_t N, int64_t H,
+                                               int64_t T_dst, int64_t T_src, int64_t D, const int64_t* q_strides,
+                                               const int64_t* k_strides, const int64_t* v_strides, const int32_t* crow,
+                                               const int32_t* col, int64_t col_stride_n, const int32_t* head_off,
+                                               const float* probs, int64_t probs_stride_n, const float* out,
+                                               const float* dout, float* dq, float* dk, float* dv, void* workspace,
+                                               int64_t workspace_bytes, sea_stream_t stream) {
+  const char* nm = "sea_sparse_attention_bwd_gather";
+  SEA_REQUIRE(q && k && v && crow && col && head_off && probs && out && dout && dq && dk && dv && q_strides && k_strides &&
+                  v_strides && workspace, SEA_EINVAL, "%s: null pointer", nm);
+  SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_F16 || dtype == SEA_BF16, SEA_EINVAL, "%s: bad dtype %d", nm, dtype);
+  SEA_REQUIRE(N > 0 && H > 0 && T_dst > 0 && T_src > 0 && D > 0 && col_stride_n > 0, SEA_EINVAL, "%s: bad shape", nm);
+  const int vec = dtype == SEA_F32 ? 4 : 8;
+  SEA_REQUIRE(D % vec == 0 && D <= 16 * vec, SEA_EUNSUPPORTED, "%s: D=%lld must be a multiple of %d and <= %d", nm,
+              (long long)D, vec, 16 * vec);
+  for (int i = 0; i < 3; ++i)
+    SEA_REQUIRE(q_strides[i] % vec == 0 && k_strides[i] % vec == 0 && v_strides[i] % vec == 0, SEA_EUNSUPPORTED,
+                "%s: row strides must be multiples of %d elements", nm, vec);
+  SEA_REQUIRE((((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)workspace | (uintptr_t)dout | (uintptr_t)dk |
+                (uintptr_t)dv) & 15) == 0, SEA_EUNSUPPORTED, "%s: q/k/v/dout/dk/dv/workspace must be 16-byte aligned", nm);
+  SEA_REQUIRE(workspace_bytes >= sea_sparse_attention_bwd_workspace_bytes(N, H, T_src, col_stride_n), SEA_EINVAL,
+              "%s: workspace of %lld bytes, need %lld", nm, (long long)workspace_bytes,
+              (long long)sea_sparse_attention_bwd_workspace_bytes(N, H, T_src, col_stride_n));
+  SEA_REQUIRE(H * T_src < (1ll << 31) && N * (H * T_src + 1) < (1ll << 40), SEA_EUNSUPPORTED, "%s: column space too large", nm);
+  BwdGatherParams g;
+  AttnBwdParams& p = g.a;
+  p.q = q; p.k = k; p.v = v;
+  for (int i = 0; i < 3; ++i) { p.qs[i] = q_strides[i]; p.ks[i] = k_strides[i]; p.vs[i] = v_strides[i]; }
+  p.N = (int)N; p.H = (int)H; p.T_dst = (int)T_dst; p.T_src = (int)T_src; p.D = (int)D;
+  p.crow = crow; p.col = col; p.col_stride_n = col_stride_n; p.head_off = head_off;
+  p.probs = probs; p.probs_stride_n = probs_stride_n; p.out = out; p.dout = dout; p.dq = dq; p.dk = dk; p.dv = dv;
+  p.TB = 0;
+  g.C = H * T_src;
+  g.cptr = reinterpret_cast<int32_t*>(workspace);
+  g.cursor = g.cptr + bwd_ws_ints(N, H, T_src);
+  g.recs = reinterpret_cast<BwdRec*>(g.cursor + bwd_ws_ints(N, H, T_src));
+  g.rec_stride_n = col_stride_n;
+  int rc;
+  if (dtype == SEA_F32) rc = launch_bwd_gather<float>(g, (hipStream_t)stream);
+  else if (dtype == SEA_F16) rc = launch_bwd_gather<__half>(g, (hipStream_t)stream);
+  else rc = launch_bwd_gather<__hip_bfloat16>(g, (hipStream_t)stream);
+  SEA_REQUIRE(rc == SEA_OK, rc, "%s: unsupported shape (rows wider than 16 lanes take sea_sparse_attention_bwd)", nm);
   SEA_CHECK_LAUNCH(nm);
   return SEA_OK;
 }

@@ -132,6 +132,11 @@ class PerlinAttention(nn.Module):
         self.performer_segments = None
         # debugging / parity: run the estimator's LayerNorm / conv tail through the torch modules even on GPU
         self.force_torch_estimator = False
+        # dense mode (training / evaluation): None = the reference's form, every (N,H,T,T) tensor materialised at once
+        # (scores, both masks, both probability tensors: 5 x 8.6 GB in fp32 at one OPT-2.7B sequence of 8192 tokens);
+        # an integer = that many heads at a time: same context and same loss (the KD terms are means over heads, summed
+        # chunk by chunk), the T x T tensors live for one chunk only and the three T x T OUTPUT fields are None
+        self.dense_head_chunk = None
         self._fused_gates = None            # (row_scale, average_scale) when the fused predictor MLP produced them
         self._fused_selection = None        # (bits, row_nnz, head_off) when the tail kernel also ran the top-k selection
         self._avg_ahead = None              # cumulative average of v when the Performer launch produced it
@@ -526,13 +531,24 @@ class PerlinAttention(nn.Module):
 
             loss = 0
             estimated_attention_probs_resized = None
+            head_chunk = None if self.benchmarking else self.dense_head_chunk
             if not self.benchmarking and attention_scores_truth is not None:
-                estimated_attention_probs_resized = resize_dense(estimated_attention_probs, 0, False)
-                estimated_attention_score_resized = resize_dense(estimated_attention_score, FP_MIN, False).float()
-                loss = loss + _kl_and_mse(estimated_attention_score_resized, attention_scores_truth,
-                                          causal_attention_mask, FP_MIN)
-                bench.register_temp_buffer('estimated_attention_probs_resized', estimated_attention_probs_resized)
-                bench.register_temp_buffer('estimated_attention_score_resized', estimated_attention_score_resized)
+                if head_chunk:
+                    # KD loss of the estimator (:741-763) a few heads at a time: both terms are means over (n, h, t[, s]),
+                    # so the chunks' values weighted by their share of the heads add up to the unchunked loss
+                    for h0 in range(0, H, int(head_chunk)):
+                        h1 = min(H, h0 + int(head_chunk))
+                        sc = resize_dense(estimated_attention_score[:, h0:h1], FP_MIN, False).float()
+                        loss = loss + _kl_and_mse(sc, attention_scores_truth[:, h0:h1], causal_attention_mask, FP_MIN) \
+                            * ((h1 - h0) / H)
+                        del sc
+                else:
+                    estimated_attention_probs_resized = resize_dense(estimated_attention_probs, 0, False)
+                    estimated_attention_score_resized = resize_dense(estimated_attention_score, FP_MIN, False).float()
+                    loss = loss + _kl_and_mse(estimated_attention_score_resized, attention_scores_truth,
+                                              causal_attention_mask, FP_MIN)
+                    bench.register_temp_buffer('estimated_attention_probs_resized', estimated_attention_probs_resized)
+                    bench.register_temp_buffer('estimated_attention_score_resized', estimated_attention_score_resized)
 
             if not not_padded:
                 estimated_attention_probs = estimated_attention_probs * (dst_attention_mask > -1)
@@ -546,7 +562,7 @@ class PerlinAttention(nn.Module):
             else:
                 out = self._forward_dense(q, v, q_for_score, k_for_score, t_attention_predictor,
                                           estimated_attention_probs, causal_attention_mask, dst_attention_mask,
-                                          attention_scores_truth, FP_MIN, T_SRC, T_M, resize_dense)
+                                          attention_scores_truth, FP_MIN, T_SRC, T_M, resize_dense, head_chunk=head_chunk)
                 partial_context_layer, partial_attention_probs, partial_attention_mask, attention_probs_dense, l2 = out
                 loss = loss + l2
 
@@ -557,7 +573,9 @@ class PerlinAttention(nn.Module):
             if not self.benchmarking and context_layer_truth is not None:
                 loss = loss + F.mse_loss(context_layer_truth, partial_context_layer)
 
-            estimated_for_output = estimated_attention_probs if self.benchmarking else estimated_attention_probs_resized
+            # (head-chunked dense mode never forms the resized T x T estimate: it hands out the T_M-wide map, like sparse mode)
+            estimated_for_output = (estimated_attention_probs if (self.benchmarking or head_chunk)
+                                    else estimated_attention_probs_resized)
             bench.register_temp_buffer('partial_context_layer', partial_context_layer)
             assert partial_context_layer.shape[-2] == q.shape[-2]
 
@@ -883,8 +901,11 @@ class PerlinAttention(nn.Module):
 
     # ------------------------------------------------------------------------------------------------
     def _forward_dense(self, q, v, q_for_score, k_for_score, t_attention_predictor, probs, causal_attention_mask,
-                       dst_attention_mask, attention_scores_truth, FP_MIN, T_SRC, T_M, resize_dense):
-        """The reference's dense branch (:774-947 sort-based top-k, :948-959 gather resize, :1061-1133)."""
+                       dst_attention_mask, attention_scores_truth, FP_MIN, T_SRC, T_M, resize_dense, head_chunk=None):
+        """The reference's dense branch (:774-947 sort-based top-k, :948-959 gather resize, :1061-1133).
+        `head_chunk`: the T x T part (mask resize, scores, both softmaxes, P.V, KD loss) runs that many heads at a time --
+        same arithmetic per head, bounded memory; `partial_attention_probs`, `partial_attention_mask` and
+        `dense_attention_probs` (the (N,H,T,T) outputs) are then None."""
         bench = get_bench()
         N, H, T, HID = q.shape
         k_, os_ = self.pconfig.k, self.pconfig.k_oversample
@@ -903,6 +924,10 @@ class PerlinAttention(nn.Module):
             partial_attention_mask = (t_dead_mask.to(q.dtype) * FP_MIN).view(N, T, H, T_M).transpose(1, 2)
             partial_attention_mask = partial_attention_mask.masked_fill(dst_attention_mask < -1, FP_MIN)
         bench.register_temp_buffer('partial_attention_mask_before_interp', partial_attention_mask)
+        if head_chunk:
+            return self._dense_attention_by_head_chunks(int(head_chunk), v, q_for_score, k_for_score, t_attention_predictor,
+                                                        partial_attention_mask, causal_attention_mask, dst_attention_mask,
+                                                        attention_scores_truth, FP_MIN, resize_dense)
         with timer("interp"):
             partial_attention_mask = resize_dense(partial_attention_mask, FP_MIN, True)
             partial_attention_mask = partial_attention_mask.masked_fill(causal_attention_mask < -1, FP_MIN)
@@ -938,3 +963,49 @@ class PerlinAttention(nn.Module):
         with timer("context_permute"):
             partial_context_layer = partial_context_layer.permute(0, 2, 1, 3).contiguous().view(N, T, H * HID)
         return partial_context_layer, partial_attention_probs, partial_attention_mask, attention_probs_dense, loss
+
+    def _dense_attention_by_head_chunks(self, chunk, v, q_for_score, k_for_score, t_attention_predictor, mask_m,
+                                        causal_attention_mask, dst_attention_mask, attention_scores_truth, FP_MIN,
+                                        resize_dense):
+        """Steps I..L of the dense branch (:948-959, :1061-1133, :1236-1244) `chunk` heads at a time.  The top-k mask `mask_m`
+        (N,H,T,T_M) pooled over ALL heads is already there (it lives on the T_M-wide map); everything T x T exists for one
+        chunk only.  Returns the tuple of `_forward_dense` with None for the three T x T outputs."""
+        bench = get_bench()
+        N, H, T, HID = v.shape[0], v.shape[1], q_for_score.shape[2], v.shape[3]
+        loss = 0
+        estimated_scales = self.attention_predictor_dec_scaler(t_attention_predictor)
+        bench.register_temp_buffer('q_for_score', q_for_score)
+        bench.register_temp_buffer('k_for_score', k_for_score)
+        parts = []
+        with timer("attention"):
+            for h0 in range(0, H, chunk):
+                h1 = min(H, h0 + chunk)
+                with timer("interp"):
+                    pm = resize_dense(mask_m[:, h0:h1], FP_MIN, True)
+                    pm = pm.masked_fill(causal_attention_mask < -1, FP_MIN)
+                scores = torch.matmul(q_for_score[:, h0:h1], k_for_score[:, h0:h1].transpose(-1, -2))
+                if attention_scores_truth is not None:
+                    loss = loss + _kl_and_mse(scores, attention_scores_truth[:, h0:h1], causal_attention_mask, FP_MIN) \
+                        * ((h1 - h0) / H)
+                ps = scores + pm
+                pp = torch.softmax(ps.float(), -1).to(ps.dtype)
+                pp = pp.masked_fill(pm < -1, 0)
+                del ps, pm, scores
+                if self.pconfig.partial_attention_scaler:
+                    pp = pp * torch.sigmoid(estimated_scales[:, h0:h1, :, 0:1])
+                parts.append(torch.matmul(pp, v[:, h0:h1]))
+                del pp
+            partial_context_layer = torch.cat(parts, dim=1)
+            bench.register_temp_buffer('partial_context_layer_1', partial_context_layer)
+            with timer("attention.avg_pool"):
+                avg_v = v * (dst_attention_mask > -1)
+                average_context_layer = (avg_v.cumsum(-2) / torch.arange(1, T + 1, device=v.device).view(1, 1, -1, 1)).to(v.dtype)
+                average_scale = torch.sigmoid(estimated_scales[..., 1:2])
+                partial_context_layer = partial_context_layer * average_scale + (1 - average_scale) * average_context_layer
+                bench.register_temp_buffer('estimated_scales', estimated_scales)
+                bench.register_temp_buffer('average_scale', average_scale)
+                bench.register_temp_buffer('average_context_layer', average_context_layer)
+                bench.register_temp_buffer('partial_context_layer_2', partial_context_layer)
+        with timer("context_permute"):
+            partial_context_layer = partial_context_layer.permute(0, 2, 1, 3).contiguous().view(N, T, H * HID)
+        return partial_context_layer, None, None, None, loss

@@ -228,8 +228,11 @@ class _SparseAttentionFn(torch.autograd.Function):
 
     Forward: the gather kernels with the per-entry probabilities kept (they ARE the saved activations: one fp32 per entry
     instead of the dense branch's (N,H,T,T) probability tensor, attention.py:1120-1128).  Backward:
-    `sea_sparse_attention_bwd` (csrc/sea_attn_bwd.hip) -- dQ by rows, dK / dV by fp32 atomics.  Row scale and the average
-    mix stay outside (plain torch ops on the result), so autograd owns their gradients."""
+    `sea_sparse_attention_bwd_gather` (csrc/sea_attn_bwd.hip) -- dQ by rows, dK / dV gathered over the transposed pattern;
+    `backward_form = "atomic"` selects the first version (`sea_sparse_attention_bwd`: dK / dV by fp32 atomics), which also
+    serves rows wider than 16 lanes.  Row scale and the average mix stay outside (plain torch ops on the result), so
+    autograd owns their gradients."""
+    backward_form = "gather"
 
     @staticmethod
     def forward(ctx, q, k, v, csr):
@@ -249,15 +252,30 @@ class _SparseAttentionFn(torch.autograd.Function):
         qd, kd, vd = (t.detach() if t.stride(-1) == 1 else t.detach().contiguous() for t in (q, k, v))
         dout = dout.to(torch.float32).contiguous()
         dq = torch.empty((N, H, T_dst, D), dtype=torch.float32, device=q.device)
-        dk = torch.zeros((N, H, T_src, D), dtype=torch.float32, device=q.device)
-        dv = torch.zeros((N, H, T_src, D), dtype=torch.float32, device=q.device)
+        vec = 4 if q.dtype == torch.float32 else 8
+        gather = _SparseAttentionFn.backward_form != "atomic" and D <= 16 * vec
         with torch.cuda.device(q.device):
-            _lib.check(lib.sea_sparse_attention_bwd(
-                _p(qd), _p(kd), _p(vd), _lib.dtype_code(q.dtype), N, H, T_dst, T_src, D,
-                _lib.strides3(qd), _lib.strides3(kd), _lib.strides3(vd),
-                _p(csr.crow), _p(csr.col), csr.col.stride(0), _p(csr.head_off),
-                _p(probs), probs.stride(0), _p(out), _p(dout), _p(dq), _p(dk), _p(dv), _lib.stream_ptr()),
-                "sea_sparse_attention_bwd")
+            if gather:
+                # dK / dV gathered over the transposed pattern (no float atomics): every row is written by the column pass
+                dk = torch.empty((N, H, T_src, D), dtype=torch.float32, device=q.device)
+                dv = torch.empty((N, H, T_src, D), dtype=torch.float32, device=q.device)
+                nb = int(lib.sea_sparse_attention_bwd_workspace_bytes(N, H, T_src, csr.col.stride(0)))
+                ws = torch.empty((nb,), dtype=torch.uint8, device=q.device)
+                _lib.check(lib.sea_sparse_attention_bwd_gather(
+                    _p(qd), _p(kd), _p(vd), _lib.dtype_code(q.dtype), N, H, T_dst, T_src, D,
+                    _lib.strides3(qd), _lib.strides3(kd), _lib.strides3(vd),
+                    _p(csr.crow), _p(csr.col), csr.col.stride(0), _p(csr.head_off),
+                    _p(probs), probs.stride(0), _p(out), _p(dout), _p(dq), _p(dk), _p(dv), _p(ws), nb, _lib.stream_ptr()),
+                    "sea_sparse_attention_bwd_gather")
+            else:
+                dk = torch.zeros((N, H, T_src, D), dtype=torch.float32, device=q.device)
+                dv = torch.zeros((N, H, T_src, D), dtype=torch.float32, device=q.device)
+                _lib.check(lib.sea_sparse_attention_bwd(
+                    _p(qd), _p(kd), _p(vd), _lib.dtype_code(q.dtype), N, H, T_dst, T_src, D,
+                    _lib.strides3(qd), _lib.strides3(kd), _lib.strides3(vd),
+                    _p(csr.crow), _p(csr.col), csr.col.stride(0), _p(csr.head_off),
+                    _p(probs), probs.stride(0), _p(out), _p(dout), _p(dq), _p(dk), _p(dv), _lib.stream_ptr()),
+                    "sea_sparse_attention_bwd")
         return dq.to(q.dtype), dk.to(k.dtype), dv.to(v.dtype), None
 
 

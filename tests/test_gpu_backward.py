@@ -31,10 +31,19 @@ def _dense_reference(q, k, v, dense_mask, rs, avg, mix):
     return o
 
 
+@pytest.fixture(params=["gather", "atomic"])
+def form(request, monkeypatch):
+    """both backward forms: dK / dV gathered over the transposed pattern (default) and the first version's fp32 atomics"""
+    from sea_attention_amd.perlin_attention.ops import flat_csr
+    monkeypatch.setattr(flat_csr._SparseAttentionFn, "backward_form", request.param)
+    return request.param
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,H,T_dst,T_src,T_M,k,d", [(2, 4, 128, 128, 32, 8, 32), (1, 3, 100, 256, 64, 16, 64),
-                                                     (1, 2, 64, 64, 16, 4, 128), (1, 5, 33, 90, 32, 8, 80)])
-def test_backward_matches_dense_autograd(ops, dtype, N, H, T_dst, T_src, T_M, k, d):
+                                                     (1, 2, 64, 64, 16, 4, 128), (1, 5, 33, 90, 32, 8, 80),
+                                                     (2, 9, 700, 700, 64, 16, 64)])     # long key lists, nine heads on eight XCDs
+def test_backward_matches_dense_autograd(ops, form, dtype, N, H, T_dst, T_src, T_M, k, d):
     g = torch.Generator().manual_seed(17)
     probs = torch.softmax(torch.randn((N, H, T_dst, T_M), generator=g), -1)
     keep = O.keep_counts_module(H, T_src, T_M, k)[-T_dst:].contiguous()
@@ -68,7 +77,32 @@ def test_backward_matches_dense_autograd(ops, dtype, N, H, T_dst, T_src, T_M, k,
     assert torch.all(leaves[0].grad[:, :, 20:24] == 0) if T_dst > 40 else True             # empty rows: no gradient to q
 
 
-def test_backward_is_deterministic_up_to_atomic_order_and_gradcheck_small(ops):
+def test_gather_and_atomic_backward_agree_at_a_layer_sized_case(ops, monkeypatch):
+    """One OPT-1.3B-shaped sequence cut to 1024 tokens (bf16, 32 heads, k = 64): the two forms give the same dQ / dK / dV up to
+    fp32 summation order, and the gather form writes every dK / dV row itself (no zero-fill: poison the allocator first)."""
+    from sea_attention_amd.perlin_attention.ops import flat_csr
+    N, H, T, T_M, k, d = 1, 32, 1024, 256, 64, 64
+    g = torch.Generator().manual_seed(3)
+    probs = torch.softmax(torch.randn((N, H, T, T_M), generator=g), -1)
+    keep = O.keep_counts_module(H, T, T_M, k).clamp_max(H * T_M)
+    csr, _ = ops.topk_to_csr(probs.to(DEV), keep.to(torch.int32).to(DEV), k, target_width=T)
+    mk = lambda sc=1.0: (torch.randn((N, H, T, d), generator=g) * sc).bfloat16().to(DEV)
+    q, kk, v = mk(d ** -0.5), mk(), mk()
+    w = torch.randn((N, H, T, d), generator=g).to(DEV)
+    res = {}
+    for form_ in ("atomic", "gather"):
+        monkeypatch.setattr(flat_csr._SparseAttentionFn, "backward_form", form_)
+        junk = torch.full((N, H, T, d), float("nan"), device=DEV); del junk          # what a fresh torch.empty may hand out
+        a, b, c = (t.clone().requires_grad_(True) for t in (q, kk, v))
+        (ops.sparse_attention_autograd(a, b, c, csr) * w).sum().backward()
+        res[form_] = (a.grad.float(), b.grad.float(), c.grad.float())
+        assert all(torch.isfinite(t).all() for t in res[form_])
+    for nm, x, y in zip(("dq", "dk", "dv"), res["atomic"], res["gather"]):
+        rel = ((x - y).norm() / x.norm()).item()
+        assert rel < 4e-3, (nm, rel)                       # both are rounded to bf16 at the end: one rounding step apart at most
+
+
+def test_backward_is_deterministic_up_to_atomic_order_and_gradcheck_small(ops, form):
     """fp32 finite-difference check on a small case (the kernels are fp32, so gradcheck runs at loose fp32 settings)."""
     N, H, T, T_M, k, d = 1, 2, 24, 8, 4, 16
     g = torch.Generator().manual_seed(5)

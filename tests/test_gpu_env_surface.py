@@ -117,7 +117,7 @@ def test_dynamic_k_on_the_fused_bf16_fast_path(monkeypatch, d):
     assert calls == {"predictor_mlp": 1, "predictor_tail_select": 1, "predictor_tail": 0, "topk_to_csr": 0}
     csr = out.partial_attention_mask
     keep = O.keep_counts_module(H, T, T_M, 32)
-    assert torch.equal(_keep_counts(csr, H, T_M).cpu().view(-1), keep.view(-1).long())
+    assert torch.equal(_keep_counts(csr, H, T_M).cpu().view(-1), keep.view(-1).long().clamp_max(H * T_M))   # the table is unclamped
     probs = out.estimated_attention_probs_m.float().cpu()
     crow, col = O.resize_m_to_t_csr(O.grouped_topk_mask(probs, keep), 32, T, True)
     assert torch.equal(csr.crow.cpu().long(), crow)

@@ -209,6 +209,40 @@ def test_kd_losses_in_dense_training_mode():
     assert m.attention.attention_predictor_enc[0].weight.grad is not None
 
 
+@pytest.mark.parametrize("chunk", [1, 3, 4])
+def test_dense_mode_head_chunked_equals_the_unchunked_form(chunk):
+    """`dense_head_chunk` bounds the memory of dense (training) mode -- the T x T scores, masks and
+    probabilities exist for `chunk` heads at a time -- without changing context, loss or gradients (the KD terms are means
+    over heads; training mode with the reference's 10 % resize jitter off so that both runs see the same mask)."""
+    m = make_layer().eval()
+    N, H, T, d = 2, 4, 48, 16
+    torch.manual_seed(8)
+    q, k, v = torch.randn(N, H, T, d) * d ** -0.5, torch.randn(N, H, T, d), torch.randn(N, H, T, d)
+    cm = causal_mask(N, T)
+    truth = torch.matmul(q, k.transpose(-1, -2)) + cm
+    ctx_truth = torch.matmul(torch.softmax(truth, -1), v).permute(0, 2, 1, 3).reshape(N, T, H * d)
+    res = {}
+    for hc in (None, chunk):
+        m.attention.dense_head_chunk = hc
+        m.zero_grad()
+        out = m(None, None, None, query_layer=q, key_layer=k, value_layer=v, attention_mask=cm,
+                attention_scores_truth=truth, context_layer_truth=ctx_truth)
+        out.loss.backward()
+        res[hc] = (out, m.attention.attention_predictor_enc[0].weight.grad.clone(),
+                   m.attention.attention_predictor_dec_scaler[0].weight.grad.clone())
+    a, b = res[None][0], res[chunk][0]
+    assert torch.allclose(a.context_layer, b.context_layer, atol=1e-6, rtol=1e-5)
+    assert abs(a.loss.item() - b.loss.item()) < 1e-5 * max(1.0, abs(a.loss.item()))
+    for ga, gb in zip(res[None][1:], res[chunk][1:]):
+        assert torch.allclose(ga, gb, atol=1e-6, rtol=1e-4)
+    # the reference's form returns the three (N,H,T,T) tensors; the bounded form does not build them
+    assert a.partial_attention_mask.shape == (N, H, T, T) and a.partial_attention_probs.shape == (N, H, T, T)
+    assert a.dense_attention_probs.shape == (N, H, T, T) and a.estimated_attention_probs.shape == (N, H, T, T)
+    assert b.partial_attention_mask is None and b.partial_attention_probs is None and b.dense_attention_probs is None
+    assert b.estimated_attention_probs.shape == (N, H, T, 32)
+    m.attention.dense_head_chunk = None
+
+
 def test_sparse_mode_requires_gpu():
     m = make_layer()
     for mod in m.modules():
