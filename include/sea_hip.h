@@ -362,16 +362,23 @@ int sea_performer_causal_segmented(const void* q, const void* k, const void* v, 
                                    int64_t pos_stride, void* out, void* avg_out, int64_t n_segments,
                                    void* workspace, int64_t workspace_bytes, sea_stream_t stream);
 
-/* Stateful form of the causal Performer for kv-cache decoding (role of the reference's StatefulCausalPerformer,
- * attention_state.py:43-140, called from attention.py:559-566 when pconfig.use_cache): the T rows handed in CONTINUE a
- * sequence of which t_base rows have been seen.  state_in (NULL for t_base = 0) / state_out (NULL: not wanted) are
- * opaque images of sea_performer_state_bytes(N,H,D,nb,dtype) bytes holding, per (n,h), the running sums
- * sum phi(k)^T [pos|v], sum phi(k) and sum v in FP32 -- the kernel's own accumulators, so decoding continues the very
- * sums the one-pass kernel would have formed (the reference keeps them in FP64 on the torch side).  q,k,v bring the
- * NEW rows only; pos points at the value embedding's row t_base.  avg_out as in sea_performer_causal (its divisor
- * uses the absolute row index); pass it whenever the state is to carry the column sums of v (16-bit kernel).
- * state_in and state_out may alias when n_segments = 1.  n_segments / workspace as in sea_performer_causal_segmented (1 / NULL for the
- * few rows of a decode step; a prefill may cut). */
+/* Stateful, CHUNK-ALIGNED form of the causal Performer for kv-cache decoding (role of the reference's
+ * StatefulCausalPerformer, attention_state.py:43-140, called from attention.py:559-566 when pconfig.use_cache; parity
+ * protocol test_perlin_opt_cache.py:7-32: cached decoding reproduces the stateless forward).  The T rows handed in CONTINUE
+ * sequences of which t_base rows have been seen.  The kernels walk the rows in chunks of C = sea_performer_chunk_rows(...)
+ * rows (64 for D = 64, 32 for D = 80 / 128); an image -- sea_performer_state_bytes(N,H,D,nb,dtype) bytes holding, per
+ * (n,h), the kernel's own FP32 accumulators sum phi(k)^T [pos|v], sum phi(k), sum v -- is always the state at a CHUNK
+ * BOUNDARY: state_in at c0 = floor(t_base / C) * C (NULL only at t_base = 0), state_out at floor((t_base + T) / C) * C.
+ * The open chunk's old rows c0 .. t_base-1 are walked AGAIN:
+ *   k, v, pos   point at ROW c0 of the caller's kv-cache / value embedding: T + t_base % C rows are read;
+ *   q, out, avg_out point at the first NEW row: T rows.
+ * Every new row is thereby computed by the very instruction sequence the one-pass kernel runs for it (same chunk, same
+ * operand tiles, same summation order): outputs and images are BITWISE those of sea_performer_causal over the whole
+ * sequence, however the sequence is cut into calls.  16-bit data, D in {64, 80, 128} (fp32 data: SEA_EUNSUPPORTED -- the
+ * torch-side state of attention_state.py serves it).  state_in and state_out may alias when n_segments = 1.
+ * n_segments / workspace as in sea_performer_causal_segmented (1 / NULL for the few rows of a decode step; a prefill may
+ * cut: its image then sums the segments' increments in segment order). */
+int64_t sea_performer_chunk_rows(int64_t D, int64_t nb, int dtype);
 int64_t sea_performer_state_bytes(int64_t N, int64_t H, int64_t D, int64_t nb, int dtype);
 int sea_performer_causal_step(const void* q, const void* k, const void* v, const void* pos, int dtype,
                               const float* proj, int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb,
@@ -387,13 +394,15 @@ int sea_performer_causal_step(const void* q, const void* k, const void* v, const
  * (an int32 the captured step itself increments).  Everything else of the step -- predictor MLP, the two convolutions
  * over the cached window, row scan, fused attention over K / V caches of fixed capacity -- has static arguments already.
  *
- * sea_performer_causal_step_at: sea_performer_causal_step with t_base = *t_base_dev; pos_table is the BASE of the value
- *   embedding (the kernel reads rows *t_base_dev ..); state_in / state_out may be one image (updated in place).
+ * sea_performer_causal_step_at: sea_performer_causal_step with t_base = *t_base_dev.  k_cache / v_cache are the BASES (row 0)
+ *   of the kv-caches -- they already hold the new rows -- and pos_table the BASE of the value embedding: the kernel finds
+ *   the chunk boundary itself and walks the open chunk from there.  q / out / avg_out: the T new rows.  state_in / state_out
+ *   may be one image (updated in place; it changes only when a chunk completes).
  * sea_predictor_tail_select_at: sea_predictor_tail_select for the LAST T rows of sequences of *t_src_dev tokens;
  *   keep_table[i] = K of the row that sees i+1 keys, for every position the session can reach (attention.py:849-866).
  * sea_csr_emit_at: sea_csr_emit with the row widths following *t_src_dev and column ids = head * T_cap + key for a FIXED
  *   capacity T_cap >= *t_src_dev (the K / V caches' row count), so sea_sparse_attention is called with T_src = T_cap. */
-int sea_performer_causal_step_at(const void* q, const void* k, const void* v, const void* pos_table, int dtype,
+int sea_performer_causal_step_at(const void* q, const void* k_cache, const void* v_cache, const void* pos_table, int dtype,
                                  const float* proj, int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb,
                                  const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                                  int64_t pos_stride, void* out, void* avg_out, const void* state_in, void* state_out,

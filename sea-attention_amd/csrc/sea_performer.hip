@@ -55,6 +55,12 @@ struct PerfParams {
   // device-resident form of t_base (a captured decode step replayed as a HIP graph: the position lives in memory).  When
   // set, `pos` is the BASE of the embedding table and the kernel reads its rows from row *t_base_dev on.
   const int32_t* t_base_dev;
+  // chunk-aligned step (the 16-bit MFMA kernels): the state image is the state at the last CHUNK BOUNDARY c0 =
+  // floor(t_base / C) * C, and the open chunk's rows c0 .. t_base-1 are walked again (k, v, pos from the caller's kv-cache,
+  // no q, no output), so that every new row is computed by the very instruction sequence the stateless pass runs for it --
+  // bitwise the stateless result for any split of the sequence into calls.  k / v / pos then point at row c0 (with
+  // t_base_dev: at row 0 of the caches / the table, the kernel adds c0); q / out / avg at the first new row.
+  int aligned;
 };
 
 typedef __attribute__((ext_vector_type(8))) __bf16 pbf8;
@@ -519,13 +525,19 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   const int nh = blockIdx.x;
   const int n = nh / p.H, h = nh - n * p.H;
   const int seg = blockIdx.y;                              // sequence-parallel form, see PerfParams
-  const int t_begin = seg * p.seg_len, t_end = min(p.T, t_begin + p.seg_len);
-  const T* qb = reinterpret_cast<const T*>(p.q) + n * p.qs[0] + h * p.qs[1];
-  const T* kb = reinterpret_cast<const T*>(p.k) + n * p.ks[0] + h * p.ks[1];
-  const T* vb = reinterpret_cast<const T*>(p.v) + n * p.vs[0] + h * p.vs[1];
   const int tb = p.t_base_dev ? *p.t_base_dev : p.t_base;       // rows the state has already seen (block-uniform)
-  const T* pb = reinterpret_cast<const T*>(p.pos) + (p.t_base_dev ? (int64_t)tb * p.pos_stride : 0);
-  T* ob = reinterpret_cast<T*>(p.out) + (int64_t)nh * p.T * (3 * D);
+  // chunk-aligned step: local row 0 is the chunk boundary at or below tb; the `lead` rows up to tb are the open chunk's old
+  // rows (k, v, pos only).  Otherwise lead = 0 and local row 0 is row tb.
+  const int lead = p.aligned ? tb % C : 0;
+  const int row_base = tb - lead;                          // absolute index of local row 0
+  const int TL = p.T + lead;                               // local rows of this call
+  const int t_begin = seg * p.seg_len, t_end = min(TL, t_begin + p.seg_len);
+  const T* qb = reinterpret_cast<const T*>(p.q) + n * p.qs[0] + h * p.qs[1] - (int64_t)lead * p.qs[2];   // rows < lead are never read
+  const int64_t cache_row = (p.aligned && p.t_base_dev) ? row_base : 0;      // k / v given as cache bases: start at the boundary
+  const T* kb = reinterpret_cast<const T*>(p.k) + n * p.ks[0] + h * p.ks[1] + cache_row * p.ks[2];
+  const T* vb = reinterpret_cast<const T*>(p.v) + n * p.vs[0] + h * p.vs[1] + cache_row * p.vs[2];
+  const T* pb = reinterpret_cast<const T*>(p.pos) + (p.t_base_dev ? (int64_t)row_base * p.pos_stride : 0);
+  T* ob = reinterpret_cast<T*>(p.out) + (int64_t)nh * p.T * (3 * D) - (int64_t)lead * (3 * D);           // rows < lead are never stored
   const float cnorm = powf((float)D, -0.25f);
 
   // projection (its values are bf16-exact: the reference casts the buffer to the data dtype), zero padded rows
@@ -575,19 +587,19 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   // pessimistic: the wait for the prefetched chunk then also waits for every output store of the previous one.)
   constexpr unsigned OOB = 0x7FFFFF00u;
   auto mk = [&](const T* base, int64_t row_stride) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (int)(((int64_t)(p.T - 1) * row_stride + D) * 2), 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (int)(((int64_t)(TL - 1) * row_stride + D) * 2), 0x00020000);
   };
   const __amdgpu_buffer_rsrc_t rq = mk(qb, p.qs[2]), rk = mk(kb, p.ks[2]), rv = mk(vb, p.vs[2]), rp = mk(pb, p.pos_stride);
-  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((int64_t)p.T * 3 * D * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((int64_t)TL * 3 * D * 2), 0x00020000);
   typedef __attribute__((ext_vector_type(4))) unsigned int bu4;
   const bool want_avg = p.avg != nullptr;                  // block-uniform
-  T* gb = reinterpret_cast<T*>(p.avg) + (want_avg ? (int64_t)nh * p.T * D : 0);
-  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(gb, 0, want_avg ? (int)((int64_t)p.T * D * 2) : 0, 0x00020000);
+  T* gb = reinterpret_cast<T*>(p.avg) + (want_avg ? (int64_t)nh * p.T * D - (int64_t)lead * D : 0);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(gb, 0, want_avg ? (int)((int64_t)TL * D * 2) : 0, 0x00020000);
   bu4 pq, pk, pv, pp;
   auto issue_loads = [&](int t0n) {
     const int t = t0n + sr;
     const bool ok = t < t_end;
-    pq = __builtin_amdgcn_raw_buffer_load_b128(rq, (ok && !STATE_ONLY) ? (int)((t * p.qs[2] + sc * 8) * 2) : (int)OOB, 0, 0);
+    pq = __builtin_amdgcn_raw_buffer_load_b128(rq, (ok && !STATE_ONLY && t >= lead) ? (int)((t * p.qs[2] + sc * 8) * 2) : (int)OOB, 0, 0);
     pk = __builtin_amdgcn_raw_buffer_load_b128(rk, ok ? (int)((t * p.ks[2] + sc * 8) * 2) : (int)OOB, 0, 0);
     pv = __builtin_amdgcn_raw_buffer_load_b128(rv, ok ? (int)((t * p.vs[2] + sc * 8) * 2) : (int)OOB, 0, 0);
     pp = __builtin_amdgcn_raw_buffer_load_b128(rp, ok ? (int)((t * p.pos_stride + sc * 8) * 2) : (int)OOB, 0, 0);
@@ -603,12 +615,12 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
     for (int i = tid; i < C * (E / 8); i += NTH) {
       const int row = i / (E / 8), ch = i - row * (E / 8);
       const bu4 v = *reinterpret_cast<const bu4*>(sO + row * LDO + ch * 8);
-      __builtin_amdgcn_raw_buffer_store_b128(v, ro, row < rowsp ? ((t0p + row) * (3 * D) + ch * 8) * 2 : (int)OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(v, ro, (row < rowsp && t0p + row >= lead) ? ((t0p + row) * (3 * D) + ch * 8) * 2 : (int)OOB, 0, 0);
     }
     if (want_avg) {                                        // C * D / 8 = 512 pieces: one per thread
       const int row = tid / (D / 8), ch = tid - row * (D / 8);
       const bu4 v = *reinterpret_cast<const bu4*>(sAvg + row * LDG + ch * 8);
-      __builtin_amdgcn_raw_buffer_store_b128(v, rg, row < rowsp ? ((t0p + row) * D + ch * 8) * 2 : (int)OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(v, rg, (row < rowsp && t0p + row >= lead) ? ((t0p + row) * D + ch * 8) * 2 : (int)OOB, 0, 0);
     }
   };
   // swizzled chunk position inside a 256-byte row of the V image (conflict-free transposing reads)
@@ -631,10 +643,24 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 #pragma unroll
     for (int ks = 0; ks < C / 32; ++ks) tril[ib][ks] = tril_frag(ib, ks);
 
+  auto write_state = [&]() {                               // this thread's part of the (n, h) image
+    float* cw = p.state_out + (int64_t)nh * CARRY;
+#pragma unroll
+    for (int b = 0; b < NBT; ++b)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cw[(b * 4 + r) * NTH + tid] = S[b][r];
+    if (tid < FP) cw[NBT * 4 * NTH + tid] = sKsum[tid];
+    cw[NBT * 4 * NTH + FP + tid] = csum;
+  };
+
   for (int t0 = t_begin; t0 < t_end; t0 += C) {
     const int rows = min(C, t_end - t0);
+    // aligned step, open chunk (always the call's last): its rows produce output but do NOT enter the state -- S, the k-sum
+    // and the column sums stay the state AT THE BOUNDARY, which is the image the next call continues from (it walks this
+    // chunk's rows again).  Block-uniform.
+    const bool upd = !(p.aligned && rows < C);
     // ---- (a) staging ---------------------------------------------------------------------------------
-    if (!STATE_ONLY) __builtin_amdgcn_raw_buffer_store_b128(pv, ro, sr < rows ? ((t0 + sr) * (3 * D) + 2 * D + sc * 8) * 2 : (int)OOB, 0, 0);
+    if (!STATE_ONLY) __builtin_amdgcn_raw_buffer_store_b128(pv, ro, (sr < rows && t0 + sr >= lead) ? ((t0 + sr) * (3 * D) + 2 * D + sc * 8) * 2 : (int)OOB, 0, 0);
     // row slot XOR 2 * chunk: the 16 lanes of a b128 store (2 rows x 8 chunks; chunk images are 1 KB = 0 mod 64 banks apart)
     // land in 16 different 4-bank groups instead of 2 (8-way conflicts); the reads below permute inside their 16-row runs
     *reinterpret_cast<bu4*>(sQ + (sc * C + (sr ^ (2 * sc))) * 8) = pq;
@@ -770,13 +796,13 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 #pragma unroll
       for (int i = 0; i < DSL; ++i) s += sDenP[tid * DSL + i];
       sDen[tid] = 1.0f / s;                                  // the 16 column waves multiply by the reciprocal
-      sRinv[tid] = 1.0f / (float)(tb + t0 + tid + 1);
+      sRinv[tid] = 1.0f / (float)(row_base + t0 + tid + 1);
     } else if (tid >= C && tid < C + FP) {
       const int f = tid - C;
       float s = sKsum[f];
 #pragma unroll
       for (int i = 0; i < NW; ++i) s += sKsP[i * FP + f];         // fixed order: bitwise reproducible
-      sKsum[f] = s;
+      if (upd) sKsum[f] = s;
     }
     __syncthreads();
     PSTAMP(2);   // (c) A + denominators + k-sum
@@ -863,11 +889,11 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
             const int row = ib * 16 + lg * 4 + r;
             sAvg[row * LDG + gcol] = S16<T>::bits((cum[ib][r] + csum) * sRinv[row]);
           }
-        csum += __shfl(cum[RB - 1][3], 48 + li);           // column total of the chunk = its last row's prefix
+        if (upd) csum += __shfl(cum[RB - 1][3], 48 + li);  // column total of the chunk = its last row's prefix
       }
       }
       // (e) S[f][e] += sum_s phi(k_s)[f] V[s][e]: A operand = phi(K)^T by transposing reads of the row-major images
-      {
+      if (upd) {
         const int q = li >> 2, pp_ = li & 3;
 #pragma unroll
         for (int rb = 0; rb < NBT; ++rb) {
@@ -897,15 +923,8 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   } else {
     const int t0l = t_begin + ((t_end - t_begin - 1) / C) * C;
     flush_out(t0l, t_end - t0l);
-    if (p.state_out && seg == p.nseg - 1) {                // the block that walked the last rows holds the final state
-      float* cw = p.state_out + (int64_t)nh * CARRY;
-#pragma unroll
-      for (int b = 0; b < NBT; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cw[(b * 4 + r) * NTH + tid] = S[b][r];
-      if (tid < FP) cw[NBT * 4 * NTH + tid] = sKsum[tid];
-      cw[NBT * 4 * NTH + FP + tid] = csum;
-    }
+    // the block that walked the last rows holds the final state (aligned step: the state at the last chunk boundary)
+    if (p.state_out && seg == p.nseg - 1) write_state();
   }
 }
 
@@ -963,13 +982,19 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
   const int nh = blockIdx.x;
   const int n = nh / p.H, h = nh - n * p.H;
   const int seg = blockIdx.y;                              // sequence-parallel form, see PerfParams
-  const int t_begin = seg * p.seg_len, t_end = min(p.T, t_begin + p.seg_len);
-  const T* qb = reinterpret_cast<const T*>(p.q) + n * p.qs[0] + h * p.qs[1];
-  const T* kb = reinterpret_cast<const T*>(p.k) + n * p.ks[0] + h * p.ks[1];
-  const T* vb = reinterpret_cast<const T*>(p.v) + n * p.vs[0] + h * p.vs[1];
   const int tb = p.t_base_dev ? *p.t_base_dev : p.t_base;       // rows the state has already seen (block-uniform)
-  const T* pb = reinterpret_cast<const T*>(p.pos) + (p.t_base_dev ? (int64_t)tb * p.pos_stride : 0);
-  T* ob = reinterpret_cast<T*>(p.out) + (int64_t)nh * p.T * (3 * D);
+  // chunk-aligned step: local row 0 is the chunk boundary at or below tb; the `lead` rows up to tb are the open chunk's old
+  // rows (k, v, pos only).  Otherwise lead = 0 and local row 0 is row tb.
+  const int lead = p.aligned ? tb % C : 0;
+  const int row_base = tb - lead;                          // absolute index of local row 0
+  const int TL = p.T + lead;                               // local rows of this call
+  const int t_begin = seg * p.seg_len, t_end = min(TL, t_begin + p.seg_len);
+  const T* qb = reinterpret_cast<const T*>(p.q) + n * p.qs[0] + h * p.qs[1] - (int64_t)lead * p.qs[2];   // rows < lead are never read
+  const int64_t cache_row = (p.aligned && p.t_base_dev) ? row_base : 0;      // k / v given as cache bases: start at the boundary
+  const T* kb = reinterpret_cast<const T*>(p.k) + n * p.ks[0] + h * p.ks[1] + cache_row * p.ks[2];
+  const T* vb = reinterpret_cast<const T*>(p.v) + n * p.vs[0] + h * p.vs[1] + cache_row * p.vs[2];
+  const T* pb = reinterpret_cast<const T*>(p.pos) + (p.t_base_dev ? (int64_t)row_base * p.pos_stride : 0);
+  T* ob = reinterpret_cast<T*>(p.out) + (int64_t)nh * p.T * (3 * D) - (int64_t)lead * (3 * D);           // rows < lead are never stored
   const float cnorm = powf((float)D, -0.25f);
 
   // projection (its values are bf16-exact: the reference casts the buffer to the data dtype), zero padded rows
@@ -1031,19 +1056,19 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
   // pessimistic: the wait for the prefetched chunk then also waits for every output store of the previous one.)
   constexpr unsigned OOB = 0x7FFFFF00u;
   auto mk = [&](const T* base, int64_t row_stride) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (int)(((int64_t)(p.T - 1) * row_stride + D) * 2), 0x00020000);
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<T*>(base), 0, (int)(((int64_t)(TL - 1) * row_stride + D) * 2), 0x00020000);
   };
   const __amdgpu_buffer_rsrc_t rq = mk(qb, p.qs[2]), rk = mk(kb, p.ks[2]), rv = mk(vb, p.vs[2]), rp = mk(pb, p.pos_stride);
-  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((int64_t)p.T * 3 * D * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((int64_t)TL * 3 * D * 2), 0x00020000);
   typedef __attribute__((ext_vector_type(4))) unsigned int bu4;
   const bool want_avg = p.avg != nullptr;                  // block-uniform
-  T* gb = reinterpret_cast<T*>(p.avg) + (want_avg ? (int64_t)nh * p.T * D : 0);
-  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(gb, 0, want_avg ? (int)((int64_t)p.T * D * 2) : 0, 0x00020000);
+  T* gb = reinterpret_cast<T*>(p.avg) + (want_avg ? (int64_t)nh * p.T * D - (int64_t)lead * D : 0);
+  const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(gb, 0, want_avg ? (int)((int64_t)TL * D * 2) : 0, 0x00020000);
   bu4 pq, pk, pv, pp;
   auto issue_loads = [&](int t0n) {
     const int t = t0n + sr;
     const bool ok = t < t_end && (STG == NTH || tid < STG);
-    pq = __builtin_amdgcn_raw_buffer_load_b128(rq, (ok && !STATE_ONLY) ? (int)((t * p.qs[2] + sc * 8) * 2) : (int)OOB, 0, 0);
+    pq = __builtin_amdgcn_raw_buffer_load_b128(rq, (ok && !STATE_ONLY && t >= lead) ? (int)((t * p.qs[2] + sc * 8) * 2) : (int)OOB, 0, 0);
     pk = __builtin_amdgcn_raw_buffer_load_b128(rk, ok ? (int)((t * p.ks[2] + sc * 8) * 2) : (int)OOB, 0, 0);
     pv = __builtin_amdgcn_raw_buffer_load_b128(rv, ok ? (int)((t * p.vs[2] + sc * 8) * 2) : (int)OOB, 0, 0);
     pp = __builtin_amdgcn_raw_buffer_load_b128(rp, ok ? (int)((t * p.pos_stride + sc * 8) * 2) : (int)OOB, 0, 0);
@@ -1056,11 +1081,11 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
     for (int i = tid; i < C * (E / 8); i += NTH) {
       const int row = i / (E / 8), ch = i - row * (E / 8);
       const bu4 v = *reinterpret_cast<const bu4*>(sO + row * LDO + ch * 8);
-      __builtin_amdgcn_raw_buffer_store_b128(v, ro, row < rowsp ? ((t0p + row) * (3 * D) + ch * 8) * 2 : (int)OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(v, ro, (row < rowsp && t0p + row >= lead) ? ((t0p + row) * (3 * D) + ch * 8) * 2 : (int)OOB, 0, 0);
     }
     if (want_avg && (STG == NTH || tid < STG)) {           // C * D / 8 pieces: one per staging thread
       const bu4 v = *reinterpret_cast<const bu4*>(sAvg + sr * LDG + sc * 8);
-      __builtin_amdgcn_raw_buffer_store_b128(v, rg, sr < rowsp ? ((t0p + sr) * D + sc * 8) * 2 : (int)OOB, 0, 0);
+      __builtin_amdgcn_raw_buffer_store_b128(v, rg, (sr < rowsp && t0p + sr >= lead) ? ((t0p + sr) * D + sc * 8) * 2 : (int)OOB, 0, 0);
     }
   };
   // swizzled chunk position inside a row of the V image (conflict-free transposing reads):
@@ -1085,10 +1110,24 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
 #pragma unroll
     for (int ks = 0; ks < C / 32; ++ks) tril[ib][ks] = tril_frag(ib, ks);
 
+  auto write_state = [&]() {                               // this thread's part of the (n, h) image
+    float* cw = p.state_out + (int64_t)nh * CARRY;
+#pragma unroll
+    for (int jq = 0; jq < JB; ++jq) {
+#pragma unroll
+      for (int b = 0; b < NBT; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cw[((jq * NBT + b) * 4 + r) * NTH + tid] = S[jq][b][r];
+      cw[JB * NBT * 4 * NTH + FP + jq * NTH + tid] = csum[jq];
+    }
+    if (tid < FP) cw[JB * NBT * 4 * NTH + tid] = sKsum[tid];
+  };
+
   for (int t0 = t_begin; t0 < t_end; t0 += C) {
     const int rows = min(C, t_end - t0);
+    const bool upd = !(p.aligned && rows < C);             // an open last chunk leaves the state at the boundary (see the d = 64 kernel)
     // ---- (a) staging ---------------------------------------------------------------------------------
-    if (!STATE_ONLY) __builtin_amdgcn_raw_buffer_store_b128(pv, ro, sr < rows ? ((t0 + sr) * (3 * D) + 2 * D + sc * 8) * 2 : (int)OOB, 0, 0);
+    if (!STATE_ONLY) __builtin_amdgcn_raw_buffer_store_b128(pv, ro, (sr < rows && t0 + sr >= lead) ? ((t0 + sr) * (3 * D) + 2 * D + sc * 8) * 2 : (int)OOB, 0, 0);
     if (STG == NTH || tid < STG) {
       // row slot XOR chunk: the 16 lanes of a b128 store (one row x 16 chunks at D = 128; chunk images are 512 B = 0 mod 64
       // banks apart) land in 16 different 4-bank groups instead of one; the reads below permute inside their 16-row runs
@@ -1226,13 +1265,13 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
 #pragma unroll
       for (int i = 0; i < DSL; ++i) s += sDenP[tid * DSL + i];
       sDen[tid] = 1.0f / s;                                  // the 16 column waves multiply by the reciprocal
-      sRinv[tid] = 1.0f / (float)(tb + t0 + tid + 1);
+      sRinv[tid] = 1.0f / (float)(row_base + t0 + tid + 1);
     } else if (tid >= C && tid < C + FP) {
       const int f = tid - C;
       float s = sKsum[f];
 #pragma unroll
       for (int i = 0; i < NW; ++i) s += sKsP[i * FP + f];         // fixed order: bitwise reproducible
-      sKsum[f] = s;
+      if (upd) sKsum[f] = s;
     }
     __syncthreads();
 
@@ -1320,11 +1359,11 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
             const int row = ib * 16 + lg * 4 + r;
             sAvg[row * LDG + gcol] = S16<T>::bits((cum[ib][r] + csum[jq]) * sRinv[row]);
           }
-        csum[jq] += __shfl(cum[RB - 1][3], 48 + li);       // column total of the chunk = its last row's prefix
+        if (upd) csum[jq] += __shfl(cum[RB - 1][3], 48 + li);   // column total of the chunk = its last row's prefix
       }
       }
       // (e) S[f][e] += sum_s phi(k_s)[f] V[s][e]: A operand = phi(K)^T by transposing reads of the row-major images
-      {
+      if (upd) {
         const int q = li >> 2, pp_ = li & 3;
 #pragma unroll
         for (int rb = 0; rb < NBT; ++rb) {
@@ -1356,18 +1395,7 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
   } else {
     const int t0l = t_begin + ((t_end - t_begin - 1) / C) * C;
     flush_out(t0l, t_end - t0l);
-    if (p.state_out && seg == p.nseg - 1) {                // the block that walked the last rows holds the final state
-      float* cw = p.state_out + (int64_t)nh * CARRY;
-#pragma unroll
-      for (int jq = 0; jq < JB; ++jq) {
-#pragma unroll
-        for (int b = 0; b < NBT; ++b)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) cw[((jq * NBT + b) * 4 + r) * NTH + tid] = S[jq][b][r];
-        cw[JB * NBT * 4 * NTH + FP + jq * NTH + tid] = csum[jq];
-      }
-      if (tid < FP) cw[JB * NBT * 4 * NTH + tid] = sKsum[tid];
-    }
+    if (p.state_out && seg == p.nseg - 1) write_state();
   }
 }
 
@@ -1494,6 +1522,19 @@ static int64_t perf_carry_floats_for(int dtype, int D, int nbt) {
   return 0;
 }
 
+// rows per chunk of the 16-bit MFMA kernel dispatch_perf picks (0: no chunk-aligned step for this shape / dtype)
+static int perf_chunk_rows_for(int dtype, int D, int nbt) {
+  if (dtype == SEA_F32) return 0;
+  if (D == 64 && nbt <= 5) return 64;
+  if ((D == 80 || D == 128) && nbt <= 5) return 32;
+  return 0;
+}
+
+extern "C" int64_t sea_performer_chunk_rows(int64_t D, int64_t nb, int dtype) {
+  if (D <= 0 || nb <= 0) return 0;
+  return perf_chunk_rows_for(dtype, (int)D, (int)((nb + 15) / 16));
+}
+
 // rows per segment: whole 64-row chunks (a multiple of every kernel's chunk size), segments as even as possible
 static int64_t perf_seg_len(int64_t T, int64_t nseg) {
   const int64_t chunks = (T + 63) / 64;
@@ -1533,7 +1574,7 @@ static int perf_entry(const char* nm, const void* q, const void* k, const void* 
                       const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                       int64_t pos_stride, void* out, void* avg_out, int64_t n_segments, void* workspace,
                       int64_t workspace_bytes, const void* state_in, void* state_out, int64_t state_bytes, int64_t t_base,
-                      const int32_t* t_base_dev,
+                      const int32_t* t_base_dev, int aligned,
                       sea_stream_t stream) {
   SEA_REQUIRE(q && k && v && pos && proj && out && q_strides && k_strides && v_strides, SEA_EINVAL, "%s: null pointer", nm);
   SEA_REQUIRE(dtype == SEA_F32 || dtype == SEA_F16 || dtype == SEA_BF16, SEA_EINVAL, "%s: bad dtype %d", nm, dtype);
@@ -1553,7 +1594,16 @@ static int perf_entry(const char* nm, const void* q, const void* k, const void* 
   const int nbt = (int)((nb + 15) / 16);
   SEA_REQUIRE(n_segments >= 1 && n_segments <= 64, SEA_EINVAL, "%s: n_segments %lld outside 1..64", nm, (long long)n_segments);
   p.nseg = (int)n_segments;
-  p.seg_len = (int)perf_seg_len(T, n_segments);
+  // local rows of the call: the new rows plus, for a chunk-aligned step, the open chunk's old rows in front of them (with the
+  // position in device memory the host cannot know how many: up to a chunk -- one segment, any length covers it)
+  int64_t TL = T;
+  p.aligned = aligned;
+  if (aligned) {
+    const int C = perf_chunk_rows_for(dtype, (int)D, nbt);
+    SEA_REQUIRE(C > 0, SEA_EUNSUPPORTED, "%s: the chunk-aligned step runs on the 16-bit MFMA kernels (bf16 / fp16 data, D = 64, 80, 128)", nm);
+    TL = T + (t_base_dev ? C - 1 : t_base % C);
+  }
+  p.seg_len = (int)perf_seg_len(TL, n_segments);
   p.carry = reinterpret_cast<float*>(workspace);
   p.state_in = reinterpret_cast<const float*>(state_in);
   p.state_out = reinterpret_cast<float*>(state_out);
@@ -1567,8 +1617,8 @@ static int perf_entry(const char* nm, const void* q, const void* k, const void* 
     SEA_REQUIRE(n_segments == 1 || state_in != state_out, SEA_EINVAL, "%s: state_in and state_out may alias only with one segment", nm);
   }
   if (n_segments > 1) {
-    SEA_REQUIRE((n_segments - 1) * (int64_t)p.seg_len < T, SEA_EINVAL, "%s: %lld segments leave one empty at T=%lld (use sea_performer_plan)",
-                nm, (long long)n_segments, (long long)T);
+    SEA_REQUIRE((n_segments - 1) * (int64_t)p.seg_len < TL, SEA_EINVAL, "%s: %lld segments leave one empty at T=%lld (use sea_performer_plan)",
+                nm, (long long)n_segments, (long long)TL);
     const int64_t need = N * H * (n_segments - 1) * perf_carry_floats_for(dtype, (int)D, nbt) * (int64_t)sizeof(float);
     SEA_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= need, SEA_EINVAL,
                 "%s: workspace of %lld bytes needed (16-byte aligned), got %lld", nm, (long long)need, (long long)workspace_bytes);
@@ -1588,7 +1638,7 @@ extern "C" int sea_performer_causal(const void* q, const void* k, const void* v,
                                     const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                                     int64_t pos_stride, void* out, void* avg_out, sea_stream_t stream) {
   return perf_entry("sea_performer_causal", q, k, v, pos, dtype, proj, N, H, T, D, nb, q_strides, k_strides, v_strides,
-                    pos_stride, out, avg_out, 1, nullptr, 0, nullptr, nullptr, 0, 0, nullptr, stream);
+                    pos_stride, out, avg_out, 1, nullptr, 0, nullptr, nullptr, 0, 0, nullptr, 0, stream);
 }
 
 extern "C" int sea_performer_causal_segmented(const void* q, const void* k, const void* v, const void* pos, int dtype,
@@ -1597,7 +1647,7 @@ extern "C" int sea_performer_causal_segmented(const void* q, const void* k, cons
                                               int64_t pos_stride, void* out, void* avg_out, int64_t n_segments,
                                               void* workspace, int64_t workspace_bytes, sea_stream_t stream) {
   return perf_entry("sea_performer_causal_segmented", q, k, v, pos, dtype, proj, N, H, T, D, nb, q_strides, k_strides,
-                    v_strides, pos_stride, out, avg_out, n_segments, workspace, workspace_bytes, nullptr, nullptr, 0, 0, nullptr, stream);
+                    v_strides, pos_stride, out, avg_out, n_segments, workspace, workspace_bytes, nullptr, nullptr, 0, 0, nullptr, 0, stream);
 }
 
 extern "C" int64_t sea_performer_state_bytes(int64_t N, int64_t H, int64_t D, int64_t nb, int dtype) {
@@ -1605,6 +1655,12 @@ extern "C" int64_t sea_performer_state_bytes(int64_t N, int64_t H, int64_t D, in
   return N * H * perf_carry_floats_for(dtype, (int)D, (int)((nb + 15) / 16)) * (int64_t)sizeof(float);
 }
 
+// Stateful step, CHUNK ALIGNED (kv-cache decoding that reproduces the stateless pass bit for bit, attention_state.py:43-140 /
+// test_perlin_opt_cache.py:7-32): the sequences have seen `t_base` rows, the image is the state at the last chunk boundary
+// c0 = floor(t_base / C) * C (C = sea_performer_chunk_rows), and the call walks the open chunk again from c0.
+//   k, v, pos  point at ROW c0 (the caller's kv-cache / embedding table hold those rows), T + t_base % C rows are read;
+//   q, out, avg_out point at the first NEW row, T rows.
+// state_out = the image at the last chunk boundary at or below t_base + T.  16-bit data, D in {64, 80, 128}.
 extern "C" int sea_performer_causal_step(const void* q, const void* k, const void* v, const void* pos, int dtype,
                                          const float* proj, int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb,
                                          const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
@@ -1613,20 +1669,21 @@ extern "C" int sea_performer_causal_step(const void* q, const void* k, const voi
                                          void* workspace, int64_t workspace_bytes, sea_stream_t stream) {
   return perf_entry("sea_performer_causal_step", q, k, v, pos, dtype, proj, N, H, T, D, nb, q_strides, k_strides,
                     v_strides, pos_stride, out, avg_out, n_segments, workspace, workspace_bytes, state_in, state_out,
-                    state_bytes, t_base, nullptr, stream);
+                    state_bytes, t_base, nullptr, 1, stream);
 }
 
 // The same step with the position in DEVICE memory (SURVEY 8f-3 / opt_generate.py:131: the decode loop captured once as
 // a HIP graph and replayed per token -- nothing position-dependent may live in kernel arguments).  *t_base_dev = rows the
-// state has seen; pos_table is the BASE of the value-embedding table (the kernel reads rows *t_base_dev ..); state_in
-// and state_out may be the same image (updated in place); one segment.
-extern "C" int sea_performer_causal_step_at(const void* q, const void* k, const void* v, const void* pos_table, int dtype,
+// state has seen; k_cache / v_cache are the BASES (row 0) of the kv-caches, which already hold the new rows, pos_table the
+// BASE of the value-embedding table: the kernel finds the chunk boundary itself.  q / out / avg_out: the T new rows.
+// state_in and state_out may be the same image (updated in place); one segment.
+extern "C" int sea_performer_causal_step_at(const void* q, const void* k_cache, const void* v_cache, const void* pos_table, int dtype,
                                             const float* proj, int64_t N, int64_t H, int64_t T, int64_t D, int64_t nb,
                                             const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                                             int64_t pos_stride, void* out, void* avg_out, const void* state_in,
                                             void* state_out, int64_t state_bytes, const int32_t* t_base_dev,
                                             sea_stream_t stream) {
   SEA_REQUIRE(t_base_dev && state_in && state_out, SEA_EINVAL, "sea_performer_causal_step_at: null pointer");
-  return perf_entry("sea_performer_causal_step_at", q, k, v, pos_table, dtype, proj, N, H, T, D, nb, q_strides, k_strides,
-                    v_strides, pos_stride, out, avg_out, 1, nullptr, 0, state_in, state_out, state_bytes, 0, t_base_dev, stream);
+  return perf_entry("sea_performer_causal_step_at", q, k_cache, v_cache, pos_table, dtype, proj, N, H, T, D, nb, q_strides, k_strides,
+                    v_strides, pos_stride, out, avg_out, 1, nullptr, 0, state_in, state_out, state_bytes, 0, t_base_dev, 1, stream);
 }

@@ -237,6 +237,8 @@ def _phase_a_increment(attention, q, k, v, lo, hi):
     """State image of the Performer over rows [lo, hi) started from zero (phase A)."""
     from .perlin_attention import ops
     pos = attention.v_eye_learned_causal[0, 0, lo:, :]
+    # (rows lo .. hi from zero: a step at t_base = 0 over the slices; cuts are whole Performer chunks, so the image it returns
+    # -- the state at the last chunk boundary -- covers all of the rank's rows for every rank whose increment is used)
     _pv, _avg, image = ops.performer_step(q[:, :, lo:hi], k[:, :, lo:hi], v[:, :, lo:hi], pos,
                                           attention.performer.projection_matrix, state_in=None, t_base=0,
                                           n_segments=attention.performer_segments or 1)

@@ -675,9 +675,13 @@ class PerlinAttention(nn.Module):
                 v_new = v[..., sl, :]
                 avg_rows = None
                 if hip_all:
-                    nseg = self.performer_segments or ops.performer_plan(N, H, T_DST, HID, self.performer_nb_features, q.dtype)[0]
+                    C_ = ops.performer_chunk_rows(HID, self.performer_nb_features, q.dtype)
+                    nseg = self.performer_segments or ops.performer_plan(N, H, T_DST + seen % C_, HID, self.performer_nb_features, q.dtype)[0]
+                    # chunk-aligned step: the image is the state at the last Performer chunk boundary and the open chunk's
+                    # rows are walked again from the kv-cache, so the new rows come out BITWISE as the stateless pass
+                    # computes them, whatever the piece sizes (attention_state.py:43-140, test_perlin_opt_cache.py:7-32)
                     performer_value, avg_rows, image = ops.performer_step(
-                        q_for_atten, k_for_atten[..., sl, :], v_new, self.v_eye_learned_causal[0, 0, seen:, :],
+                        q_for_atten, k_for_atten, v, self.v_eye_learned_causal[0, 0],
                         self.performer.projection_matrix, state_in=ps.image, t_base=seen, n_segments=nseg)
                     ps = PerformerState()
                     ps.image, ps.seq_index = image, T_SRC

@@ -85,8 +85,9 @@ class DecodeSession:
         at, H, D, T_M = self.attention, self.H, self.D, self.T_M
         self.k_cache.index_copy_(2, self.idx64, self.k_in)
         self.v_cache.index_copy_(2, self.idx64, self.v_in)
+        # chunk-aligned step: the kernel walks the open Performer chunk again from the caches (which hold the new row already)
         performer_value, avg_rows, _ = ops.performer_step(
-            self.q_in, self.k_in, self.v_in, at.v_eye_learned_causal[0, 0], at.performer.projection_matrix,
+            self.q_in, self.k_cache, self.v_cache, at.v_eye_learned_causal[0, 0], at.performer.projection_matrix,
             state_in=self.image, t_base_dev=self.seen32)
         x, _t, row_scale, avg_scale = ops.predictor_mlp(
             performer_value, at.attention_predictor_enc[0], at.attention_predictor_enc[1],

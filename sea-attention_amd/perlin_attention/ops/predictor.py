@@ -285,35 +285,52 @@ def performer_value(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torc
     return (out, avg) if want_avg else out
 
 
+def performer_chunk_rows(D: int, nb: int, dtype) -> int:
+    """Rows per chunk of the 16-bit Performer kernel for this shape (`sea_performer_chunk_rows`; 0 = no chunk-aligned step)."""
+    return int(_lib.load().sea_performer_chunk_rows(int(D), int(nb), _lib.dtype_code(dtype)))
+
+
 @_lib.device_guarded
 def performer_step(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torch.Tensor, projection: torch.Tensor,
                    state_in: torch.Tensor = None, t_base: int = 0, want_avg: bool = True, n_segments: int = 1,
                    t_base_dev: Optional[torch.Tensor] = None):
-    """Stateful causal Performer (`sea_performer_causal_step`): q,k,v (N,H,T_new,D) are the NEW rows of sequences
-    that have seen `t_base` rows, `state_in` the image a previous call returned (None at t_base = 0), pos the value
-    embedding's rows t_base .. t_base+T_new-1.  Returns (performer_value (N,H,T_new,3D), cumulative average of v for
-    the new rows or None, state_out).  Images are opaque fp32 tensors; a new one is returned (the input is kept).
+    """Stateful, chunk-aligned causal Performer (`sea_performer_causal_step`).  q (N,H,T_new,D) are the NEW rows of sequences
+    that have seen `t_base` rows; k, v (N,H,>=t_base+T_new,D) are the kv-cache FROM ROW 0 (the call reads them from the last
+    chunk boundary c0 <= t_base on: the open chunk is walked again, which is what makes the rows bitwise the stateless
+    pass's); `pos` is the value-embedding table from row 0; `state_in` the image a previous call returned (the state at c0;
+    None while no chunk has completed).  Returns (performer_value (N,H,T_new,3D), cumulative average of v for the new rows
+    or None, state_out = the image at the last chunk boundary <= t_base + T_new; a new tensor, the input is kept).
     Decode form (`sea_performer_causal_step_at`, a step replayed as a HIP graph): `t_base_dev` is a one-element int32
-    device tensor holding the rows seen so far, `pos` the WHOLE embedding table, and `state_in` is updated in place."""
+    device tensor holding the rows seen so far, k / v the fixed-capacity caches (already holding the new row), and
+    `state_in` is updated in place."""
     lib = _lib.load()
     _lib.require_gpu(q, k, v, pos, projection)
     N, H, T, D = q.shape
-    assert k.shape == q.shape and v.shape == q.shape and pos.shape[-1] == D and pos.shape[0] >= T
     nb = projection.shape[0]
-    q, k, v = (t if t.stride(-1) == 1 else t.contiguous() for t in (q, k, v))
+    assert k.shape[:2] == (N, H) and k.shape[-1] == D and v.shape == k.shape and pos.shape[-1] == D
+    C = performer_chunk_rows(D, nb, q.dtype)
+    assert C > 0, "the stateful Performer runs on the 16-bit MFMA kernels (bf16 / fp16 data, D in {64, 80, 128})"
+    q = q if q.stride(-1) == 1 else q.contiguous()
     k = k if k.dtype == q.dtype else k.to(q.dtype)
     v = v if v.dtype == q.dtype else v.to(q.dtype)
     pos = pos if pos.dtype == q.dtype else pos.to(q.dtype)
-    pos = pos if pos.stride(-1) == 1 else pos.contiguous()
-    assert pos.data_ptr() % 16 == 0, "value-embedding rows must start 16-byte aligned"
     proj = _cached("proj", (projection,), q.dtype, lambda: projection.to(q.dtype).float().contiguous())
     sb = int(lib.sea_performer_state_bytes(N, H, D, nb, _lib.dtype_code(q.dtype)))
     assert sb > 0, "unsupported head size / feature count"
     if t_base_dev is not None:
         assert t_base_dev.dtype == torch.int32 and t_base_dev.numel() == 1 and t_base_dev.is_cuda
         assert state_in is not None and t_base == 0 and n_segments == 1
+        kc, vc, pc = k, v, pos                                   # cache / table bases: the kernel finds the boundary
+        assert pos.shape[0] >= k.shape[2]
     else:
+        c0 = (int(t_base) // C) * C
+        assert k.shape[2] >= t_base + T and pos.shape[0] >= t_base + T, "k / v / pos must cover the rows seen plus the new ones"
         assert (state_in is None) == (t_base == 0), "a state image goes with the number of rows it has seen"
+        kc, vc, pc = k[:, :, c0:t_base + T], v[:, :, c0:t_base + T], pos[c0:t_base + T]
+    kc = kc if kc.stride(-1) == 1 else kc.contiguous()
+    vc = vc if vc.stride(-1) == 1 else vc.contiguous()
+    pc = pc if pc.stride(-1) == 1 else pc.contiguous()
+    assert pc.data_ptr() % 16 == 0 and kc.data_ptr() % 16 == 0 and vc.data_ptr() % 16 == 0, "rows must start 16-byte aligned"
     if state_in is not None:
         assert state_in.dtype == torch.float32 and state_in.numel() * 4 == sb and state_in.is_contiguous()
     state_out = state_in if t_base_dev is not None else torch.empty((sb // 4,), dtype=torch.float32, device=q.device)
@@ -329,13 +346,13 @@ def performer_step(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, pos: torch
         ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=q.device)
     if t_base_dev is not None:
         _lib.check(lib.sea_performer_causal_step_at(
-            _p(q), _p(k), _p(v), _p(pos), _lib.dtype_code(q.dtype), _p(proj), N, H, T, D, nb, _lib.strides3(q), _lib.strides3(k),
-            _lib.strides3(v), pos.stride(0), _p(out), _p(avg), _p(state_in), _p(state_out), sb, _p(t_base_dev),
+            _p(q), _p(kc), _p(vc), _p(pc), _lib.dtype_code(q.dtype), _p(proj), N, H, T, D, nb, _lib.strides3(q), _lib.strides3(kc),
+            _lib.strides3(vc), pc.stride(0), _p(out), _p(avg), _p(state_in), _p(state_out), sb, _p(t_base_dev),
             _lib.stream_ptr()), "sea_performer_causal_step_at")
         return out, avg, state_out
     _lib.check(lib.sea_performer_causal_step(
-        _p(q), _p(k), _p(v), _p(pos), _lib.dtype_code(q.dtype), _p(proj), N, H, T, D, nb, _lib.strides3(q), _lib.strides3(k),
-        _lib.strides3(v), pos.stride(0), _p(out), _p(avg), _p(state_in), _p(state_out), sb, int(t_base), int(n_segments),
+        _p(q), _p(kc), _p(vc), _p(pc), _lib.dtype_code(q.dtype), _p(proj), N, H, T, D, nb, _lib.strides3(q), _lib.strides3(kc),
+        _lib.strides3(vc), pc.stride(0), _p(out), _p(avg), _p(state_in), _p(state_out), sb, int(t_base), int(n_segments),
         _p(ws), ws_bytes, _lib.stream_ptr()), "sea_performer_causal_step")
     return out, avg, state_out
 

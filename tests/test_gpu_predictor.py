@@ -434,10 +434,10 @@ def test_performer_sequence_parallel_equals_sequential(ops, dtype, N, H, T, D, n
                                            (torch.bfloat16, 1, 3, 448, 128), (torch.float16, 2, 2, 300, 128),
                                            (torch.bfloat16, 1, 3, 448, 80), (torch.float16, 1, 2, 300, 80)])
 def test_performer_step_continues_the_sequence(ops, dtype, N, H, T, D):
-    """`sea_performer_causal_step` (kv-cache decoding): feeding the rows in pieces with the carried state image gives
-    the rows -- and the cumulative average of v -- of the one-pass kernel.  Pieces that end on 64-row chunk boundaries
-    continue the very same fp32 sums (bitwise equal); single rows / ragged pieces regroup the in-chunk sums (one
-    rounding step of the output dtype on a small fraction of the elements)."""
+    """`sea_performer_causal_step` (kv-cache decoding), chunk aligned: the state image is the state at the last chunk
+    boundary and every call walks the open chunk again from the kv-cache, so feeding the rows in ANY pieces -- chunk
+    aligned, ragged, single rows -- gives the rows and the cumulative average of v of the one-pass kernel BIT FOR BIT
+    (reference protocol test_perlin_opt_cache.py:7-32)."""
     import math
     from sea_attention_amd.perlin_attention.performer import FastAttention
     torch.manual_seed(31)
@@ -446,28 +446,47 @@ def test_performer_step_continues_the_sequence(ops, dtype, N, H, T, D):
     q = (torch.randn(N, H, T, D, device=DEV) * D ** -0.5).to(dtype); k = torch.randn(N, H, T, D, device=DEV).to(dtype)
     v = torch.randn(N, H, T, D, device=DEV).to(dtype); pos = torch.randn(T + 8, D, device=DEV).to(dtype)
     ref, ref_avg = ops.performer_value(q, k, v, pos, fa.projection_matrix, want_avg=True, n_segments=1)
+    C = ops.performer_chunk_rows(D, nb, dtype)
+    assert C == (64 if D == 64 else 32)
 
     def feed(cuts, nseg_first=1):
-        state, t0, outs, avgs = None, 0, [], []
+        state, t0, outs, avgs, states = None, 0, [], [], []
         for i, t1 in enumerate(cuts):
-            o, a, state = ops.performer_step(q[:, :, t0:t1], k[:, :, t0:t1], v[:, :, t0:t1], pos[t0:], fa.projection_matrix,
+            # the kv-cache up to the new rows, from row 0; the call reads it from the last chunk boundary on
+            o, a, state = ops.performer_step(q[:, :, t0:t1], k[:, :, :t1], v[:, :, :t1], pos, fa.projection_matrix,
                                              state_in=state, t_base=t0, n_segments=nseg_first if i == 0 else 1)
-            outs.append(o); avgs.append(a); t0 = t1
-        return torch.cat(outs, 2), torch.cat(avgs, 2)
+            outs.append(o); avgs.append(a); states.append(state); t0 = t1
+        return torch.cat(outs, 2), torch.cat(avgs, 2), states
 
-    out, avg = feed((128, 320, T) if T > 320 else (64, 256, T))         # chunk-aligned pieces
+    out, avg, st_aligned = feed((128, 320, T) if T > 320 else (64, 256, T))   # chunk-aligned pieces
     assert torch.equal(out, ref) and torch.equal(avg, ref_avg)
-    eps = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
     cuts = [200] + list(range(201, 216)) + [T - 37, T]                   # a ragged prefill, 15 single rows, two longer pieces
-    for nseg_first in (1, 2):                                            # the prefill piece may itself be cut into segments
-        out, avg = feed(cuts, nseg_first)
-        for g, s in ((out, ref), (avg, ref_avg)):
-            g, s = g.float(), s.float()
-            assert ((g - s).abs() <= s.abs() * eps + 1e-6).all(), (g - s).abs().max().item()
-            assert (g != s).float().mean().item() < 0.02
-        assert torch.equal(out[..., 2 * D:], v)
+    out, avg, st_ragged = feed(cuts)
+    assert torch.equal(out, ref), (out.float() - ref.float()).abs().max().item()
+    assert torch.equal(avg, ref_avg)
+    assert torch.equal(out[..., 2 * D:], v)
+    # every image is the state at a chunk boundary: two feeds that end at the same row count hold the same image, and a
+    # single-row step inside a chunk leaves it untouched
+    assert torch.equal(st_aligned[-1], st_ragged[-1])
+    for a, b, t_prev, t_now in zip(st_ragged[1:], st_ragged[:-1], cuts[:-1], cuts[1:]):
+        if t_now // C == t_prev // C:
+            assert torch.equal(a, b), (t_prev, t_now)
+    # one token at a time across two chunk boundaries, from a one-row prefill
+    lo = 2 * C - 3
+    out1, avg1, _ = feed([1] + list(range(2, lo)) + list(range(lo, lo + C + 6)) + [T])
+    assert torch.equal(out1, ref) and torch.equal(avg1, ref_avg)
+    # the prefill piece may itself be cut into segments (another fp32 summation order of the carried sums, as in the
+    # sequence-parallel stateless kernel): equal to a rounding step of the output dtype
+    eps = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -10
+    out2, avg2, _ = feed(cuts, 2)
+    for g, s in ((out2, ref), (avg2, ref_avg)):
+        g, s = g.float(), s.float()
+        assert ((g - s).abs() <= s.abs() * eps + 1e-6).all(), (g - s).abs().max().item()
+        assert (g != s).float().mean().item() < 0.02
     with pytest.raises(AssertionError):                                  # an image without its row count
-        ops.performer_step(q[:, :, :8], k[:, :, :8], v[:, :, :8], pos, fa.projection_matrix, state_in=None, t_base=5)
+        ops.performer_step(q[:, :, 5:13], k[:, :, :13], v[:, :, :13], pos, fa.projection_matrix, state_in=None, t_base=5)
+    with pytest.raises(AssertionError):                                  # fp32 data: no chunk-aligned step (torch-side state serves it)
+        ops.performer_step(q[:, :, :8].float(), k[:, :, :8].float(), v[:, :, :8].float(), pos.float(), fa.projection_matrix)
 
 
 @pytest.mark.gpu

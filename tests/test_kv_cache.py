@@ -114,10 +114,9 @@ def test_cached_decoding_with_the_deeper_predictor_cnn(monkeypatch, dtype):
         assert (maps - ref_map).abs().max().item() < 1e-5             # an 8-row window would differ at 1e-2 .. 1e-1 here
         assert ((got - ref).norm() / ref.norm()).item() < 1e-4
     else:
-        # whole 64-row chunks reproduce the stateless map bit for bit (T0 = 64 and the last chunk); ragged pieces regroup
-        # fp32 sums inside a Performer chunk, so their maps agree to bf16 rounding
-        assert torch.equal(maps[:, :, :64], ref_map[:, :, :64])
-        assert (maps - ref_map).abs().max().item() < 2e-2
+        # the HIP estimator's cached path is bitwise the stateless one for any piece sizes (chunk-aligned Performer step)
+        assert torch.equal(maps, ref_map)
+        assert torch.equal(got, ref)
 
 
 def test_state_is_copy_on_write_and_cnn_window_is_enough():
@@ -148,12 +147,13 @@ def test_cached_call_checks_its_bookkeeping():
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,H,T,T_M,k,T0,chunks", [(2, 4, 400, 128, 16, 300, (1, 1, 1, 7, 30, 60)),
-                                                   (1, 8, 330, 256, 32, 1, (1, 2, 6, 20, 300))])
+                                                   (1, 8, 330, 256, 32, 1, (1, 2, 6, 20, 300)),
+                                                   (1, 4, 200, 256, 16, 70, (1,) * 20 + (36, 74))])
 def test_cached_decoding_on_the_hip_estimator(dtype, N, H, T, T_M, k, T0, chunks):
     """16-bit inference with d = 64: the cached path runs the stateless path's own estimator kernels on the new rows
-    (one-launch MLP, MFMA convolutions over [8-row window | new rows], tail), so MLP / CNN / softmax round exactly as in
-    the stateless forward; only the Performer differs (float64 running sums in torch vs the one-pass MFMA kernel).
-    The window state is the channel-blocked post-LayerNorm tensor; rows match the stateless forward."""
+    (chunk-aligned Performer step, one-launch MLP, MFMA convolutions over [8-row window | new rows], tail + selection,
+    emit, gather attention): BITWISE the stateless forward for pieces of 1 ... 300 tokens.
+    The window state is the channel-blocked post-LayerNorm tensor."""
     d = 64
     assert T0 + sum(chunks) == T
     full = _layer(H, d, T_M, k, T + 1, dtype, use_cache=False)
@@ -178,26 +178,15 @@ def test_cached_decoding_on_the_hip_estimator(dtype, N, H, T, T_M, k, T0, chunks
             got.append(out.context_layer.float()); bits.append(out.partial_attention_mask.bits)
             pos = hi
     got, bits = torch.cat(got, dim=1), torch.cat(bits, dim=1)
-    # What separates cached from stateless rows is the TOP-K CHOICE, not arithmetic: the cached Performer regroups its
-    # fp32 sums inside a 64-row chunk, a map value lands on the neighbouring 16-bit number now and then, and where that
-    # value sat next to the K_t-th largest the kept pixel set changes.  So the comparison is split: (1) the share of rows
-    # whose kept set differs at all (the flip rate) is reported and bounded; (2) rows that kept the SAME set must agree
-    # to the 16-bit rounding of the context; (3) the whole context stays close.
+    # The cached path runs the stateless path's own kernels on the new rows, and the Performer step is chunk aligned (the
+    # image is the state at the last chunk boundary; the open chunk is walked again from the kv-cache): every row is
+    # computed by the very instruction sequence the stateless forward runs for it.  So the reference's bar -- cached
+    # decoding REPRODUCES the full forward, test_perlin_opt_cache.py:7-32 -- holds to the bit: no top-k flips, equal context
+    # (round 2 allowed a flip rate of 0.30 / 0.08 here).
     same = (bits == ref_bits).all(-1)                                   # (N, T) kept-pixel set identical
     flip_rate = 1.0 - same.float().mean().item()
-    err = (got - ref).abs().amax(-1)
-    scale = ref.abs().amax(-1).clamp_min(1.0)
-    row_tol = 2.0 ** -7 if dtype == torch.bfloat16 else 2.0 ** -9       # two rounding steps of the 16-bit context
-    tight = (err[same] <= row_tol * scale[same]).float().mean().item() if same.any() else 1.0
-    rel_same = ((got[same] - ref[same]).norm() / ref[same].norm()).item() if same.any() else 0.0
-    rel = ((got - ref).norm() / ref.norm()).item()
-    print(f"hip-estimator decode {dtype} T_M={T_M}: top-k flip rate {flip_rate:.3f} of rows, rows with the same set: "
-          f"{tight:.4f} within {row_tol:.4f}, rel {rel_same:.5f}; all rows rel {rel:.4f}")
-    lim_flip = 0.30 if dtype == torch.bfloat16 else 0.08
-    assert flip_rate < lim_flip, flip_rate
-    assert tight > 0.995 and rel_same < 6e-3, (tight, rel_same)         # same keys -> same context up to 16-bit rounding
-    lim_rel = 0.08 if dtype == torch.bfloat16 else 0.03
-    assert rel < lim_rel, rel
+    assert flip_rate == 0.0, flip_rate
+    assert torch.equal(got, ref), (got - ref).abs().max().item()
     # a state written by the HIP estimator cannot continue on the torch estimator (different window contents)
     cached.attention.force_torch_estimator = True
     with torch.no_grad(), pytest.raises(AssertionError, match="HIP estimator"):
