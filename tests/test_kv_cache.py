@@ -184,8 +184,7 @@ def test_cached_decoding_on_the_hip_estimator(dtype, N, H, T, T_M, k, T0, chunks
     # decoding REPRODUCES the full forward, test_perlin_opt_cache.py:7-32 -- holds to the bit: no top-k flips, equal context
     # (round 2 allowed a flip rate of 0.30 / 0.08 here).
     same = (bits == ref_bits).all(-1)                                   # (N, T) kept-pixel set identical
-    flip_rate = 1.0 - same.float().mean().item()
-    assert flip_rate == 0.0, flip_rate
+    assert bool(same.all()), f"top-k flips in {int((~same).sum())} of {same.numel()} rows"
     assert torch.equal(got, ref), (got - ref).abs().max().item()
     # a state written by the HIP estimator cannot continue on the torch estimator (different window contents)
     cached.attention.force_torch_estimator = True
