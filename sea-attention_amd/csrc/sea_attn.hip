@@ -180,6 +180,14 @@ __global__ __launch_bounds__(256) void sparse_attn_kernel(AttnParams p) {
   }
 }
 
+// natural-order length of slot gi's row for rows_by_length (sea_attn.hpp): -1 for slots past T_dst or rows the per-block
+// dispatch gave to the other kernel
+__device__ inline int slot_length(const AttnParams& p, int n, int h, int tn) {
+  if (tn >= p.T_dst || block_is_foreign(p, n, h, tn)) return -1;
+  const int32_t* hon = p.head_off + ((int64_t)n * p.T_dst + tn) * (p.H + 1);
+  return hon[h + 1] - hon[h];
+}
+
 // ---- variant B: one LPR-lane GROUP per query row (64/LPR rows per wave) -----------------------------------
 // Each group walks its own row's entries, one key per instruction step, U keys in flight, with its own online
 // softmax; nothing is merged across groups.  A wave therefore has 64/LPR independent
@@ -192,14 +200,17 @@ __global__ __launch_bounds__(NWB * 64) void sparse_attn_rows_kernel(AttnParams p
   constexpr int RPB = NWB * RPW;      // rows per workgroup
   int pair, tb;
   if (!map_block(p.N * p.H, p.TB, &pair, &tb)) return;
-  const int n = pair / p.H, h = pair - n * p.H;
+  const int n = pair / p.H;
+  // heads rotated over the XCDs per batch item: the pair index is congruent to the XCD label (map_block), so without the
+  // rotation an XCD would serve the same residue class of heads for every item and a heavy head would load one XCD only
+  const int h = (pair - n * p.H + n) % p.H;
   const int lane = threadIdx.x & 63;
   const int grp = lane / LPR, sub = lane - grp * LPR;
-  const int t = tb * RPB + (threadIdx.x >> 6) * RPW + grp;
-  if (block_is_foreign(p, n, h, min(tb * RPB + (int)(threadIdx.x >> 6) * RPW, p.T_dst - 1))) return;   // RPW divides 16
-  const bool rowok = t < p.T_dst;
+  const int gi = (int)(threadIdx.x >> 6) * RPW + grp;      // lane group index inside the block
+  bool rowok;
+  const int t = tb * RPB + rows_by_length<LPR, RPB>(slot_length(p, n, h, tb * RPB + gi), gi, sub, &rowok);
   const bool dact = sub * VEC < p.D;
-  const int tt = rowok ? t : p.T_dst - 1;
+  const int tt = t < p.T_dst ? t : p.T_dst - 1;
   const int sube = dact ? sub : 0;    // lanes beyond D re-read fragment 0 (their q fragment is zero)
 
   // wave-uniform 64-bit bases + per-lane 32-bit byte offsets (launcher guarantees T_src*stride*sizeof(T) < 2^31)
@@ -335,13 +346,14 @@ __global__ __launch_bounds__(NWB * 64) void sparse_attn_rows80_kernel(AttnParams
   constexpr int RPW = 64 / LPR, RPB = NWB * RPW;
   int pair, tb;
   if (!map_block(p.N * p.H, p.TB, &pair, &tb)) return;
-  const int n = pair / p.H, h = pair - n * p.H;
+  const int n = pair / p.H;
+  const int h = (pair - n * p.H + n) % p.H;                // heads rotated over the XCDs per item (see sparse_attn_rows_kernel)
   const int lane = threadIdx.x & 63;
   const int grp = lane / LPR, sub = lane - grp * LPR;
-  const int t = tb * RPB + (threadIdx.x >> 6) * RPW + grp;
-  if (block_is_foreign(p, n, h, min(tb * RPB + (int)(threadIdx.x >> 6) * RPW, p.T_dst - 1))) return;
-  const bool rowok = t < p.T_dst;
-  const int tt = rowok ? t : p.T_dst - 1;
+  const int gi = (int)(threadIdx.x >> 6) * RPW + grp;
+  bool rowok;
+  const int t = tb * RPB + rows_by_length<LPR, RPB>(slot_length(p, n, h, tb * RPB + gi), gi, sub, &rowok);
+  const int tt = t < p.T_dst ? t : p.T_dst - 1;
 
   const char* kbase = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.k) + n * p.ks[0] + h * p.ks[1]);
   const char* vbase = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.v) + n * p.vs[0] + h * p.vs[1]);
@@ -580,22 +592,25 @@ static int launch_attn_wp(AttnParams p, hipStream_t s) {
                      (int64_t)p.T_src * p.ks[2] * esz < (1ll << 31) && (int64_t)p.T_src * p.vs[2] * esz < (1ll << 31);
   if constexpr (sizeof(T) == 2) {
     if (p.D == 80 && small) {                          // d = 80: 8 lanes x (8 + 2) elements per row
-      const int rpb = 4 * 8;
+      const int rpb = 8 * 8;                               // 8 waves x 8 rows, sorted by length
       p.TB = (p.T_dst + rpb - 1) / rpb;
       const int64_t blocks = (int64_t)8 * ((NH + 7) / 8) * p.TB;
-      hipLaunchKernelGGL((sparse_attn_rows80_kernel<T, TO, 4, WP>), dim3((unsigned)blocks), dim3(256), 0, s, p);
+      hipLaunchKernelGGL((sparse_attn_rows80_kernel<T, TO, 4, WP, 8>), dim3((unsigned)blocks), dim3(512), 0, s, p);
       return SEA_OK;
     }
   }
   if (lpr <= 16 && small) {
-    const int rpb = 4 * (64 / lpr);
+    // rows per workgroup (sorted by length inside the kernel): 64 for rows of 4 or 8 lanes, 32 for rows of 16 lanes.
+    // Measured at the headline shape (layer's own selection, bf16 d = 64): 32 / 64 / 128 rows per block 0.99 / 0.96 / 1.00 ms.
+    const int nwb = lpr == 4 ? 4 : 8;
+    const int rpb = nwb * (64 / lpr);
     p.TB = (p.T_dst + rpb - 1) / rpb;
     const int64_t blocks = (int64_t)8 * ((NH + 7) / 8) * p.TB;
-    dim3 grid((unsigned)blocks), block(256);
+    dim3 grid((unsigned)blocks), block(nwb * 64);
     switch (lpr) {
-      case 4: hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 4, 4, WP>), grid, block, 0, s, p); break;
-      case 8: hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 8, 4, WP>), grid, block, 0, s, p); break;
-      default: hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 16, 4, WP>), grid, block, 0, s, p); break;
+      case 4: hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 4, 4, WP, 4>), grid, block, 0, s, p); break;
+      case 8: hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 8, 4, WP, 8>), grid, block, 0, s, p); break;
+      default: hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 16, 4, WP, 8>), grid, block, 0, s, p); break;
     }
     return SEA_OK;
   }

@@ -197,20 +197,31 @@ __global__ __launch_bounds__(1024) void csc_scan_kernel(int32_t* __restrict__ cp
   if (threadIdx.x == 0) { c[C] = s_carry; u[C] = s_carry; }
 }
 
-template <typename T, int LPR, int U>
-__global__ __launch_bounds__(256) void sparse_attn_bwd_rows_kernel(BwdGatherParams g) {
+template <typename T, int LPR, int U, int NWB>
+__global__ __launch_bounds__(NWB * 64) void sparse_attn_bwd_rows_kernel(BwdGatherParams g) {
   const AttnBwdParams& p = g.a;
   constexpr int VEC = Elem<T>::VEC;
-  constexpr int RPW = 64 / LPR, RPB = 4 * RPW;
+  constexpr int RPW = 64 / LPR, RPB = NWB * RPW;
   int pair, tb;
   if (!map_block(p.N * p.H, p.TB, &pair, &tb)) return;
-  const int n = pair / p.H, h = pair - n * p.H;
+  const int n = pair / p.H;
+  const int h = (pair - n * p.H + n) % p.H;                // heads rotated over the XCDs per item, as in the forward
   const int lane = threadIdx.x & 63;
   const int grp = lane / LPR, sub = lane - grp * LPR;
-  const int t = tb * RPB + (threadIdx.x >> 6) * RPW + grp;
-  const bool rowok = t < p.T_dst;
+  // the block's rows dealt to the lane groups by length (sea_attn.hpp: rows_by_length), as in the forward
+  const int gi = (int)(threadIdx.x >> 6) * RPW + grp;
+  int len = -1;
+  {
+    const int tn = tb * RPB + gi;
+    if (tn < p.T_dst) {
+      const int32_t* hon = p.head_off + ((int64_t)n * p.T_dst + tn) * (p.H + 1);
+      len = hon[h + 1] - hon[h];
+    }
+  }
+  bool rowok;
+  const int t = tb * RPB + rows_by_length<LPR, RPB>(len, gi, sub, &rowok);
   const bool dact = sub * VEC < p.D;
-  const int tt = rowok ? t : p.T_dst - 1;
+  const int tt = t < p.T_dst ? t : p.T_dst - 1;
   const int d0 = dact ? sub * VEC : 0;
 
   float go[VEC];
@@ -300,21 +311,29 @@ __global__ __launch_bounds__(256) void sparse_attn_bwd_rows_kernel(BwdGatherPara
 }
 
 // one LPR-lane group per (n, h, key): dK_key = sum over the key's records of ds * q_t, dV_key = sum of p * dO_t
-template <typename T, int LPR, int U>
-__global__ __launch_bounds__(256) void sparse_attn_bwd_cols_kernel(BwdGatherParams g) {
+template <typename T, int LPR, int U, int NWB>
+__global__ __launch_bounds__(NWB * 64) void sparse_attn_bwd_cols_kernel(BwdGatherParams g) {
   const AttnBwdParams& p = g.a;
   constexpr int VEC = Elem<T>::VEC;
-  constexpr int RPW = 64 / LPR, RPB = 4 * RPW;
+  constexpr int RPW = 64 / LPR, RPB = NWB * RPW;
   int pair, tb;
   if (!map_block(p.N * p.H, p.TB, &pair, &tb)) return;
-  const int n = pair / p.H, h = pair - n * p.H;
+  const int n = pair / p.H;
+  const int h = (pair - n * p.H + n) % p.H;
   const int lane = threadIdx.x & 63;
   const int grp = lane / LPR, sub = lane - grp * LPR;
-  const int key = tb * RPB + (threadIdx.x >> 6) * RPW + grp;
-  const bool keyok = key < p.T_src;
+  // the block's keys dealt to the lane groups by the length of their record lists (same lockstep argument as for rows)
+  const int32_t* cptr = g.cptr + (int64_t)n * (g.C + 1) + (int64_t)h * p.T_src;
+  const int gi = (int)(threadIdx.x >> 6) * RPW + grp;
+  int len = -1;
+  {
+    const int kn = tb * RPB + gi;
+    if (kn < p.T_src) len = cptr[kn + 1] - cptr[kn];
+  }
+  bool keyok;
+  const int key = tb * RPB + rows_by_length<LPR, RPB>(len, gi, sub, &keyok);
   const bool dact = sub * VEC < p.D;
   const int d0 = dact ? sub * VEC : 0;
-  const int32_t* cptr = g.cptr + (int64_t)n * (g.C + 1) + (int64_t)h * p.T_src;
   const int beg = keyok ? cptr[key] : 0;
   const int end = keyok ? cptr[key + 1] : 0;
   const BwdRec* recs = g.recs + n * g.rec_stride_n;
@@ -407,7 +426,8 @@ static int launch_bwd_gather(BwdGatherParams g, hipStream_t s) {
   AttnBwdParams& p = g.a;
   const int lpr = blanes_per_row(p.D, Elem<T>::VEC);
   if (lpr > 16) return SEA_EUNSUPPORTED;                    // fp32 d >= 128: the atomic form serves those
-  const int rpb = 4 * (64 / lpr);
+  const int nwb = lpr == 4 ? 4 : 8;                          // rows (keys) per block, sorted by length inside the kernels
+  const int rpb = nwb * (64 / lpr);
   const int NH8 = 8 * ((p.N * p.H + 7) / 8);
   if (hipMemsetAsync(g.cptr, 0, (size_t)p.N * (g.C + 1) * sizeof(int32_t), s) != hipSuccess) return SEA_ELAUNCH;
   const int64_t zb = (p.col_stride_n + 255) / 256;
@@ -419,17 +439,17 @@ static int launch_bwd_gather(BwdGatherParams g, hipStream_t s) {
   int64_t blocks = (int64_t)NH8 * p.TB;
   if (blocks >= (1ll << 31)) return SEA_EUNSUPPORTED;
   switch (lpr) {
-    case 4: hipLaunchKernelGGL((sparse_attn_bwd_rows_kernel<T, 4, 4>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;
-    case 8: hipLaunchKernelGGL((sparse_attn_bwd_rows_kernel<T, 8, 4>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;
-    default: hipLaunchKernelGGL((sparse_attn_bwd_rows_kernel<T, 16, 4>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;
+    case 4: hipLaunchKernelGGL((sparse_attn_bwd_rows_kernel<T, 4, 4, 4>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;
+    case 8: hipLaunchKernelGGL((sparse_attn_bwd_rows_kernel<T, 8, 4, 8>), dim3((unsigned)blocks), dim3(512), 0, s, g); break;
+    default: hipLaunchKernelGGL((sparse_attn_bwd_rows_kernel<T, 16, 4, 8>), dim3((unsigned)blocks), dim3(512), 0, s, g); break;
   }
   p.TB = (p.T_src + rpb - 1) / rpb;
   blocks = (int64_t)NH8 * p.TB;
   if (blocks >= (1ll << 31)) return SEA_EUNSUPPORTED;
   switch (lpr) {
-    case 4: hipLaunchKernelGGL((sparse_attn_bwd_cols_kernel<T, 4, 4>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;
-    case 8: hipLaunchKernelGGL((sparse_attn_bwd_cols_kernel<T, 8, 4>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;
-    default: hipLaunchKernelGGL((sparse_attn_bwd_cols_kernel<T, 16, 4>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;
+    case 4: hipLaunchKernelGGL((sparse_attn_bwd_cols_kernel<T, 4, 4, 4>), dim3((unsigned)blocks), dim3(256), 0, s, g); break;
+    case 8: hipLaunchKernelGGL((sparse_attn_bwd_cols_kernel<T, 8, 4, 8>), dim3((unsigned)blocks), dim3(512), 0, s, g); break;
+    default: hipLaunchKernelGGL((sparse_attn_bwd_cols_kernel<T, 16, 4, 8>), dim3((unsigned)blocks), dim3(512), 0, s, g); break;
   }
   return SEA_OK;
 }
