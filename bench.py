@@ -295,16 +295,20 @@ class LayerBench:
             return requested, {"requested": requested, "graph": ok}
         cands = ["gather"] + (["auto", "tile"] if self.tile_supported() else [])
         rep = {}
-        for c in cands:
-            if not self.capture(c, with_process_group):
-                return "auto" if self.tile_supported() else "gather", {"requested": "ab", "graph": False}
-            self.timed(2)
-            dt, am = self.timed(steps)
-            rep[c] = {"ms_per_step": round(dt / steps * 1e3, 4), "attention_ms": round(am, 4)}
+        for rnd in range(2):                                   # two interleaved rounds, the better of each candidate: whoever
+            for c in cands:                                    # is measured first pays the process's one-time costs
+                if not self.capture(c, with_process_group):
+                    return "auto" if self.tile_supported() else "gather", {"requested": "ab", "graph": False}
+                self.timed(2)
+                dt, am = self.timed(steps)
+                cur = {"ms_per_step": round(dt / steps * 1e3, 4), "attention_ms": round(am, 4)}
+                if c not in rep or cur["ms_per_step"] < rep[c]["ms_per_step"]:
+                    rep[c] = cur
         best = min(rep, key=lambda c_: rep[c_]["ms_per_step"])
         self.capture(best, with_process_group)
         return best, {"requested": "ab", "graph": True, "candidates": rep, "chosen": best,
-                      "note": f"{steps} graph-replayed steps per candidate on the layer's own selection, before the timed region"}
+                      "note": f"2 x {steps} graph-replayed steps per candidate (interleaved, the better round counts) on the "
+                              "layer's own selection, before the timed region"}
 
     # -- roofline of the attention launch -----------------------------------------------------------------------------------
     def roofline(self, out, t_attn_s, path, timing_note):
@@ -339,7 +343,8 @@ class LayerBench:
                 pass
         gname = "sparse_attn_rows80_kernel" if d == 80 and esz == 2 else "sparse_attn_rows_kernel"
         kname = {"tile": "sparse_attn_tile_kernel", "gather": gname,
-                 "auto": gname + " + sparse_attn_tile_kernel (per-block dispatch: both launches inside the timed events)"}[path]
+                 "auto": "attn_plan_kernel + " + gname + " + sparse_attn_tile_kernel (kernel choice on the device: the plan, the "
+                         "running kernel and the idle kernel's exit all sit inside the timed events)"}[path]
         # achieved = SURVEY 8d's algorithmic bytes (every gathered K / V row counted once per entry) / launch time.  K + V of
         # one head stay in the XCD's L2, so what binds is the L2 -> L1 request path, not HBM: `bound` says so, `frac` is
         # still against the 8 TB/s HBM line (the contract's roofline), `l2_gather_frac` against the 17.8 TB/s the
@@ -674,8 +679,8 @@ def main(argv=None):
                 same_map = bool(torch.equal(alone.estimated_attention_probs_m, probs_b[n_:n_ + 1]))
                 d_ = (alone.context_layer.float() - ctx_b[n_:n_ + 1].float())
                 worst = max(worst, (d_.norm() / ctx_b[n_:n_ + 1].float().norm()).item())
-                # 'auto' decides per 16-row block from the whole launch's plan (a lone item can fall on the other side of the
-                # all-tile rule): equal to rounding there, bitwise for a single-kernel path
+                # 'auto' picks the kernel from the whole launch's plan (a lone item can fall on the other side of the cut):
+                # equal to rounding there, bitwise for a fixed kernel path
                 close = worst < 2e-3 if path == "auto" else bool(torch.equal(alone.context_layer, ctx_b[n_:n_ + 1]))
                 bits_ok &= same_map and close
             layer.attention.performer_segments = None
@@ -691,7 +696,7 @@ def main(argv=None):
                 gathered_ok = all(bool(torch.equal(a, b)) for a, b in zip(sums, here))
             output_check = {"status": "ok" if (bits_ok and finite and gathered_ok is not False) else "FAILED",
                             "items_alone_equal_to_batched_rows": bits_ok,
-                            "comparison": "bitwise" if path != "auto" else "2e-3 rel-norm (per-block dispatch differs between launches)",
+                            "comparison": "bitwise" if path != "auto" else "2e-3 rel-norm (the kernel choice may differ between a lone item and the batch)",
                             "finite": finite, "items_checked": sorted({0, NB - 1}), "layer_item_alone_rel_diff": round(worst, 8)}
             if gathered_ok is not None:
                 output_check["gathered_shards_match_their_ranks"] = gathered_ok
@@ -824,7 +829,7 @@ def main(argv=None):
                          + ("unpadded batch declared to the module (assume_not_padded: no mask inspection sync)"
                             if not args.inspect_padding else "module inspects the mask for padding (one host sync)")
                          + f", sparse kernel path {path}"
-                         + (", + RCCL all-gather of context shards" if world > 1 else "")
+                         + (f", + {'gloo (rehearsal)' if args.rehearse else 'RCCL'} all-gather of context shards" if world > 1 else "")
                          + (", layer replayed as a HIP graph + eager fused-attention launch" if graph_on else ", eager launches"))
 
     # ---- the other BASELINE shapes + the reference-default (fp32 context) twin of the headline: short legs, rank 0's GPU ----

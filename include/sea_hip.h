@@ -159,9 +159,9 @@ int sea_sparse_attention(const void* q, const void* k, const void* v, int dtype,
 /* The same operator with two more knobs.
  *
  * flags, low byte = kernel path:
- *   SEA_ATTN_AUTO    with a `block_path` plan (sea_attention_plan): per 16-row block, the kernel the plan names;
- *                    without one: the gather kernels (the tile kernel pays off only where neighbouring query rows
- *                    share most of their keys: >= ~30 entries per staged 16-key tile);
+ *   SEA_ATTN_AUTO    with a `block_path` plan (sea_attention_plan): the ONE kernel the plan's statistics favour for this
+ *                    launch, decided on the device; without a plan: the gather kernels (the tile kernel pays off only
+ *                    where neighbouring query rows share most of their keys);
  *   SEA_ATTN_GATHER  row-indexed gather kernels (sea_attn.hip): one lane group per (n,h,t) row walks the row's entries,
  *                    every K / V row is fetched per entry (L2-served); any dtype, any D <= 64*vec, duplicates counted;
  *   SEA_ATTN_TILE    MFMA tile kernel (sea_attn_tile.hip): a wave owns 16 (or 32) consecutive query rows of one (n,h),
@@ -224,14 +224,16 @@ int sea_sparse_attention_bwd_gather(const void* q, const void* k, const void* v,
                                     float* dq, float* dk, float* dv, void* workspace, int64_t workspace_bytes,
                                     sea_stream_t stream);
 
-/* Per-block dispatch plan for SEA_ATTN_AUTO: one byte per (n, h, 16-row block), 1 = the tile kernel owns the block, 0 = the
- * gather kernels do.  With a plan, sea_sparse_attention_ex launches BOTH kernels over all rows and every wave runs only the
- * blocks its kernel owns (no host round trip, graph-capturable).  The plan is estimated from the kept-pixel bit masks of
- * sea_topk_select / sea_predictor_tail_select (`bits`, (N,T_dst,ceil(H*T_m/32))): entries a block walks against the 16-key
- * tiles it would stage; the tile kernel gets the block when entries >= entries_per_tile * tiles (<= 0: the measured
- * cross-over, 30).  When the plan gives the tile kernel more than half of the blocks it gets all of them (two partly
- * filled launches cost more than the remaining blocks win back): the count is kept in an int32 behind the bytes, so
- * `block_path` must hold ((N*H*ceil(T_dst/16) + 3) & ~3) + 4 bytes.  T_m % 32 == 0, H <= 64. */
+/* Kernel-choice plan for SEA_ATTN_AUTO, made on the device (no host round trip, graph-capturable).  One byte per (n, h,
+ * 16-row block): 1 where the block's entries per staged 16-key tile favour the MFMA tile kernel -- estimated from the
+ * kept-pixel bit masks of sea_topk_select / sea_predictor_tail_select (`bits`, (N,T_dst,ceil(H*T_m/32))): entries the block
+ * walks against the 16-key tiles it would stage, favourable when entries >= entries_per_tile * tiles (<= 0: 30) -- followed,
+ * 4-byte aligned, by the int32 COUNT of such blocks: `block_path` holds ((N*H*ceil(T_dst/16) + 3) & ~3) + 4 bytes.
+ * With a plan, sea_sparse_attention_ex launches BOTH kernels over all rows; each reads the count, and ONE of them runs
+ * the launch while the other's workgroups exit at once: the tile kernel when the favourable blocks' share exceeds 1/2
+ * (D <= 80) or 13/20 (D = 128), else the gather kernels.  (Round 2 split a launch per block between the two kernels; since
+ * the gather kernels deal their rows by length that mix is slower than the better kernel alone -- scripts/
+ * sweep_plan_threshold.py -- and the bytes only feed the count.)  T_m % 32 == 0, H <= 64. */
 int sea_attention_plan(const uint32_t* bits, int64_t N, int64_t H, int64_t T_dst, int64_t T_src, int64_t T_m,
                        int is_causal, float entries_per_tile, uint8_t* block_path, sea_stream_t stream);
 

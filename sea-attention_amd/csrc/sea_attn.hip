@@ -72,7 +72,7 @@ __global__ __launch_bounds__(256) void sparse_attn_kernel(AttnParams p) {
   const int n = pair / p.H, h = pair - n * p.H;
   const int t = tb * 4 + (threadIdx.x >> 6);
   if (t >= p.T_dst) return;
-  if (block_is_foreign(p, n, h, t)) return;
+  if (kernel_is_idle(p)) return;
   const int lane = threadIdx.x & 63;
   const int grp = lane / LPR, sub = lane - grp * LPR;
   const bool dact = sub * VEC < p.D;
@@ -180,10 +180,9 @@ __global__ __launch_bounds__(256) void sparse_attn_kernel(AttnParams p) {
   }
 }
 
-// natural-order length of slot gi's row for rows_by_length (sea_attn.hpp): -1 for slots past T_dst or rows the per-block
-// dispatch gave to the other kernel
+// natural-order length of slot gi's row for rows_by_length (sea_attn.hpp): -1 for slots past T_dst
 __device__ inline int slot_length(const AttnParams& p, int n, int h, int tn) {
-  if (tn >= p.T_dst || block_is_foreign(p, n, h, tn)) return -1;
+  if (tn >= p.T_dst) return -1;
   const int32_t* hon = p.head_off + ((int64_t)n * p.T_dst + tn) * (p.H + 1);
   return hon[h + 1] - hon[h];
 }
@@ -199,7 +198,7 @@ __global__ __launch_bounds__(NWB * 64) void sparse_attn_rows_kernel(AttnParams p
   constexpr int RPW = 64 / LPR;       // rows per wave
   constexpr int RPB = NWB * RPW;      // rows per workgroup
   int pair, tb;
-  if (!map_block(p.N * p.H, p.TB, &pair, &tb)) return;
+  if (kernel_is_idle(p) || !map_block(p.N * p.H, p.TB, &pair, &tb)) return;      // (grid / workgroup uniform: before any barrier)
   const int n = pair / p.H;
   // heads rotated over the XCDs per batch item: the pair index is congruent to the XCD label (map_block), so without the
   // rotation an XCD would serve the same residue class of heads for every item and a heavy head would load one XCD only
@@ -345,7 +344,7 @@ __global__ __launch_bounds__(NWB * 64) void sparse_attn_rows80_kernel(AttnParams
   constexpr int LPR = 8, VEC = 8, XT = 2, DM = LPR * VEC;     // DM = 64 elements in the 16-byte fragments
   constexpr int RPW = 64 / LPR, RPB = NWB * RPW;
   int pair, tb;
-  if (!map_block(p.N * p.H, p.TB, &pair, &tb)) return;
+  if (kernel_is_idle(p) || !map_block(p.N * p.H, p.TB, &pair, &tb)) return;
   const int n = pair / p.H;
   const int h = (pair - n * p.H + n) % p.H;                // heads rotated over the XCDs per item (see sparse_attn_rows_kernel)
   const int lane = threadIdx.x & 63;
@@ -715,6 +714,10 @@ extern "C" int sea_sparse_attention_ex(const void* q, const void* k, const void*
   p.probs = probs_out; p.probs_stride_n = probs_stride_n;
   p.sel = nullptr; p.sel_want = 0; p.TB16 = (int)((T_dst + 15) / 16);
   p.sel_count = nullptr; p.sel_total = (int)(N * H * p.TB16);
+  // share of tile-favouring blocks above which the tile kernel takes the launch (scripts/sweep_plan_threshold.py, round 3:
+  // with the plan's cut at 30 entries per staged tile the structured map gives 0.53 / 0.71 / 0.51 at d = 64 / 80 / 128 and
+  // the tile kernel wins by 4 % / 13 % / loses by 13 %; the layer's own and independent rows give <= 0.33 and lose always)
+  p.sel_num = D >= 128 ? 13 : 1; p.sel_den = D >= 128 ? 20 : 2;
   p.TB = (int)((T_dst + 3) / 4);
   hipStream_t s = (hipStream_t)stream;
   const bool tile_ok = attn_tile_supported(dtype, (int)D, (int)T_src, p) && probs_out == nullptr;
@@ -728,8 +731,8 @@ extern "C" int sea_sparse_attention_ex(const void* q, const void* k, const void*
     SEA_CHECK_LAUNCH(nm);
     return SEA_OK;
   }
-  if (path == SEA_ATTN_AUTO && block_path && tile_ok) {      // per-block dispatch: both kernels over the same rows, each
-    p.sel = block_path;                                     // wave runs only the 16-row blocks the plan gave its kernel
+  if (path == SEA_ATTN_AUTO && block_path && tile_ok) {      // both kernels over the same rows; the plan's tile-block count
+    p.sel = block_path;                                     // decides ON THE DEVICE which of them runs this launch
     p.sel_count = reinterpret_cast<const int32_t*>(block_path + plan_count_offset(N, H, p.TB16));
     p.sel_want = 1;
     rc = launch_attn_tile(p, dtype, out_dtype, flags, s);

@@ -20,12 +20,15 @@ struct AttnParams {
   int64_t os[3];
   float* probs;            // optional (N, probs_stride_n): rs * softmax per entry (gather kernels only)
   int64_t probs_stride_n;
-  // per-block dispatch (sea_attention_plan): sel[(n * H + h) * TB16 + t / 16] says which kernel owns the 16-row block; a
-  // wave whose block belongs to the other kernel exits at once (both kernels are launched over the same rows)
+  // kernel choice by plan (sea_attention_plan): `sel` = one byte per (n, h, 16-row block), 1 where the block's entries per
+  // staged 16-key tile favour the MFMA tile kernel, followed by the int32 count of such blocks.  BOTH kernels are launched
+  // over the same rows and read the count: when the tile blocks' share exceeds sel_num / sel_den the tile kernel runs the
+  // whole launch and the gather kernel's workgroups exit at once, otherwise the other way round (round 3: since the gather
+  // kernels deal rows by length, a launch split per block between the two kernels is slower than the better of them alone)
   const uint8_t* sel;
   int sel_want, TB16;
-  const int32_t* sel_count;  // blocks the plan gave the tile kernel; when that is most of them (sel_total / 2), ALL go there
-  int sel_total;
+  const int32_t* sel_count;
+  int sel_total, sel_num, sel_den;
   int TB;  // row blocks per (n, h): ceil(T_dst / 4)
 };
 
@@ -73,13 +76,11 @@ __device__ inline bool map_block(int NH, int TB, int* pair, int* tb) {
   return *pair < NH;
 }
 
-// true when the 16-row block of query row t is NOT this kernel's (wave-uniform when the wave's rows share a block)
-__device__ inline bool block_is_foreign(const AttnParams& p, int n, int h, int t) {
+// true when the plan hands this launch to the OTHER kernel (uniform over the whole grid: every workgroup returns at once)
+__device__ inline bool kernel_is_idle(const AttnParams& p) {
   if (p.sel == nullptr) return false;
-  // a map whose rows mostly share their keys runs best on the tile kernel alone (two partly filled launches cost more
-  // than the few blocks the gather kernels would win back): measured, scripts/sweep_plan_cut.py
-  if (2 * (int64_t)p.sel_count[0] > (int64_t)p.sel_total) return p.sel_want != 1;
-  return p.sel[((int64_t)n * p.H + h) * p.TB16 + (t >> 4)] != (uint8_t)p.sel_want;
+  const bool tile_runs = (int64_t)p.sel_count[0] * p.sel_den > (int64_t)p.sel_total * p.sel_num;
+  return tile_runs ? (p.sel_want != 1) : (p.sel_want != 0);
 }
 
 // ---- rows of a block dealt to the lane groups BY LENGTH ---------------------------------------------------------------

@@ -117,13 +117,12 @@ __global__ __launch_bounds__(NW * 64) void sparse_attn_tile_kernel(AttnParams p,
   constexpr float LOG2E = 1.4426950408889634f;
   extern __shared__ __attribute__((aligned(16))) char at_smem[];
   int pair, tb;
-  if (!map_block(p.N * p.H, p.TB, &pair, &tb)) return;
+  if (kernel_is_idle(p) || !map_block(p.N * p.H, p.TB, &pair, &tb)) return;
   const int n = pair / p.H, h = pair - n * p.H;
   const int lane = threadIdx.x & 63, li = lane & 15, g = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   const int t0 = (tb * NW + wave) * ROWS;
   if (t0 >= p.T_dst) return;                               // wave-uniform; the kernel has no workgroup barrier
-  if (RT == 1 && block_is_foreign(p, n, h, t0)) return;    // per-block dispatch (plans are per 16 rows: RT = 1 only)
 
   const int WPR = KW >> 5, BST = WPR + 1;                  // bitmap words per row, padded row stride (banks)
   char* wbase = at_smem + wave * wave_lds;

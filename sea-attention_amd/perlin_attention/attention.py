@@ -780,7 +780,7 @@ class PerlinAttention(nn.Module):
                 want_p = self.return_attention_probs
                 plan = None
                 if (self.sparse_kernel == "auto" and not want_p and qs.dtype != torch.float32 and HID in (64, 80, 128)
-                        and T_DST >= 16):                    # same per-block dispatch as the stateless path
+                        and T_DST >= 16):                    # same kernel choice as the stateless path
                     plan = ops.attention_plan(csr, T_M, is_causal=True)
                 res = ops.sparse_attention(qs, ks, vs, csr, row_scale=row_scale, avg=average_context_layer.to(qs.dtype).contiguous(),
                                            mix=average_scale, out=ctx.view(N, T_DST, H, HID).permute(0, 2, 1, 3),
@@ -888,8 +888,9 @@ class PerlinAttention(nn.Module):
                     plan = None
                     if (self.sparse_kernel == "auto" and not want_probs and qs.dtype != torch.float32
                             and HID in (64, 80, 128)):
-                        # per-block dispatch: 16-row blocks whose rows share most of their keys go to the MFMA tile
-                        # kernel, the rest to the gather kernels (one small launch over the selection's pixel masks)
+                        # kernel choice on the device: a small launch over the selection's pixel masks counts the 16-row
+                        # blocks whose rows share most of their keys; the MFMA tile kernel runs the launch when they are
+                        # the majority, the gather kernels otherwise (the idle kernel's workgroups exit at once)
                         plan = ops.attention_plan(csr, T_M, is_causal=True)
                     res = ops.sparse_attention(qs, ks, vs, csr, row_scale=row_scale, avg=average_context_layer,
                                                mix=average_scale, out=ctx.view(N, T, H, HID).permute(0, 2, 1, 3),

@@ -293,11 +293,12 @@ def sparse_attention_autograd(q, k, v, csr: FlatCSR, row_scale=None, avg=None, m
 
 @_lib.device_guarded
 def attention_plan(csr: FlatCSR, T_m: int, is_causal: bool = True, entries_per_tile: float = 0.0):
-    """Per-block dispatch plan (`sea_attention_plan`): a flat uint8 buffer -- N*H*ceil(T_dst/16) bytes, 1 = the MFMA tile
-    kernel owns the 16-row block, 0 = the gather kernels, followed (4-byte aligned) by the int32 count of tile blocks
-    (`plan_blocks(plan, N, H, T_dst)` views the bytes as (N, H, blocks)).  Needs the kept-pixel bit masks of the selection (`csr.bits`); returns None
-    when there are none (a CSR that did not come from topk_to_csr / csr_from_selection) or the shape is outside the plan
-    kernel (T_m % 32, H <= 64)."""
+    """Kernel-choice plan (`sea_attention_plan`): a flat uint8 buffer -- N*H*ceil(T_dst/16) bytes, 1 = the block's entries per
+    staged tile favour the MFMA tile kernel, followed (4-byte aligned) by the int32 count of such blocks
+    (`plan_blocks(plan, N, H, T_dst)` views the bytes as (N, H, blocks)).  `sparse_attention(path="auto", plan=...)` launches
+    both kernels and the count decides on the device which ONE runs the launch.  Needs the kept-pixel bit masks of the
+    selection (`csr.bits`); returns None when there are none (a CSR that did not come from topk_to_csr / csr_from_selection)
+    or the shape is outside the plan kernel (T_m % 32, H <= 64)."""
     if csr.bits is None or T_m % 32 != 0 or csr.H > 64 or csr.H * T_m > 32768:
         return None
     lib = _lib.load()
@@ -326,8 +327,9 @@ def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = 
     row_tiles / key_window tune the tile kernel (0 = defaults).  The tile kernel (also inside "auto" with a plan) stages whole
     16-key tiles: every V row below T_src must be finite, kept or not (0 * Inf = NaN; include/sea_hip.h); the gather kernels
     read kept keys only.
-    plan: with path="auto", the per-block dispatch of `attention_plan` (both kernels are launched, each wave runs the
-    16-row blocks its kernel owns); without it "auto" means the gather kernels.
+    plan: with path="auto", the kernel choice of `attention_plan` (both kernels are launched, the plan's count of
+    tile-favouring blocks decides on the device which one runs; the other exits at once); without it "auto" means the
+    gather kernels.
     want_probs: also return the per-entry values rs * softmax (fp32, laid out like csr.col) -- what the reference
     hands out as `partial_attention_probs` (attention.py:1162-1171); returns (out, probs)."""
     lib = _lib.load()

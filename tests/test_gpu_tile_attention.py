@@ -188,8 +188,9 @@ def test_probs_output_matches_golden_elmul(golden, ops):
 
 @pytest.mark.parametrize("dtype,d", [(torch.bfloat16, 64), (torch.float16, 80), (torch.bfloat16, 128)])
 def test_per_block_dispatch_any_plan_gives_the_same_answer(ops, dtype, d):
-    """path="auto" with a plan launches both kernels; each 16-row block of each head is computed by exactly one of them.
-    Whatever the plan says (all gather, all tile, random, the library's own estimate), the output is the oracle's."""
+    """path="auto" with a plan launches both kernels; the plan's count of tile-favouring blocks decides on the device which
+    ONE of them runs the launch (the other exits at once).  Whatever the plan says (all gather, all tile, random shares on
+    either side of the cut, the library's own estimate), every row is written exactly once and the output is the oracle's."""
     N, H, T_dst, T_src, T_M, k = 2, 6, 200, 333, 64, 16
     probs, q, kk, v, rs, mx, avg, keep, crow, col = _case(N, H, T_dst, T_src, T_M, k, d, dtype, structured=True)
     sparse = O.sparse_attention(q.float(), kk.float(), v.float(), crow, col, rs)
@@ -202,7 +203,7 @@ def test_per_block_dispatch_any_plan_gives_the_same_answer(ops, dtype, d):
     ob = ops.plan_blocks(own, N, H, T_dst)
     assert ob.shape == (N, H, TB16) and int(ob.max()) <= 1
     assert int(own[-4:].view(torch.int32)[0]) == int(ob.sum())            # the count behind the bytes
-    half = torch.zeros((N, H, TB16), dtype=torch.uint8); half[:, :, : TB16 // 2 - 1] = 1   # < half: stays per block
+    half = torch.zeros((N, H, TB16), dtype=torch.uint8); half[:, :, : TB16 // 2 - 1] = 1   # just under half: the gather kernels run
     plans = {"gather": ops.make_plan(torch.zeros((N, H, TB16), dtype=torch.uint8)),
              "tile": ops.make_plan(torch.ones((N, H, TB16), dtype=torch.uint8)),
              "random": ops.make_plan((torch.rand((N, H, TB16), generator=g) < 0.4).to(torch.uint8)),
