@@ -24,7 +24,7 @@ for sub in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum_TCC_MISS_sum_TCC_REQ_sum"):
         w = csv.DictWriter(fo, fieldnames=rd.fieldnames); w.writeheader(); w.writerows(keep)
 log = [l for l in open(os.path.join(src, "FETCH_SIZE.log")).read().splitlines() if l.startswith("{")]
 bench_line = json.loads(log[-1]) if log else {}
-out = {"round": 2, "build": note, "kernel_source_sha256": _attn_source_sha(),
+out = {"round": 3, "build": note, "kernel_source_sha256": _attn_source_sha(),
        "command": "rocprofv3 --kernel-trace --pmc <C> -- python3 bench.py --steps 3 --warmup 1 --prewarm 2 --no-cpu-baseline "
                   "--kernel-iters 0 --no-output-check  (opt-1.3b, batch 8, bf16; one pass per counter set; in-layer launches)",
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the bench command itself (in-layer launches), gfx950 correction applied",
