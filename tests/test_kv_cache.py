@@ -40,11 +40,16 @@ def _layer(H, d, T_M, k, T, dtype, use_cache):
     return layer
 
 
-@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
 @pytest.mark.parametrize("N,H,T,d,T_M,k,T0,chunks", [(2, 4, 96, 32, 32, 8, 64, (1, 1, 6, 8, 16)),
                                                      (1, 8, 300, 64, 64, 16, 257, (1, 10, 32)),
                                                      (1, 4, 40, 32, 32, 8, 1, (1, 2, 36))])
-def test_cached_decoding_matches_stateless(dtype, tol, N, H, T, d, T_M, k, T0, chunks):
+def test_cached_decoding_matches_stateless(N, H, T, d, T_M, k, T0, chunks):
+    """The torch-module estimator with the reference's kind of state (float64 Performer sums, raw CNN-input window, running
+    sum of v: attention_state.py:43-236) -- the path fp32 data and shapes outside the HIP estimator take: every row of the
+    cached decoding equals the stateless forward to 2e-4.  (16-bit data runs the HIP estimator, whose cached path is held
+    to BITWISE equality below; round 2's loose bf16 bar on this torch path -- rel < 0.2, 35 % of rows off -- is gone with
+    it: it measured bf16 rounding of two different summation precisions, not the state logic.)"""
+    dtype, tol = torch.float32, 2e-4
     assert T0 + sum(chunks) == T
     full = _layer(H, d, T_M, k, T, dtype, use_cache=False)
     cached = _layer(H, d, T_M, k, T, dtype, use_cache=True)
@@ -65,17 +70,11 @@ def test_cached_decoding_matches_stateless(dtype, tol, N, H, T, d, T_M, k, T0, c
             got.append(out.context_layer.float())
             pos = hi
     got = torch.cat(got, dim=1)
-    # fp32: every row agrees.  bf16: the estimator's outputs are rounded to 8 significant bits, so the float64 state and
-    # the one-pass fp32 sums land on neighbouring bf16 values now and then, a near-tied top-k choice flips and that
-    # row attends to a slightly different key set -- judged by the relative error of the whole context instead
     err = (got - ref).abs().amax(-1)                      # (N, T) worst element per row
     scale = ref.abs().amax(-1).clamp_min(1.0)
     bad = (err > tol * scale).float().mean().item()
     rel = ((got - ref).norm() / ref.norm()).item()
-    if dtype == torch.float32:
-        assert bad == 0.0 and rel < 1e-4, (bad, rel, err.max().item())
-    else:
-        assert rel < 0.2 and bad < 0.35, (bad, rel, err.max().item())
+    assert bad == 0.0 and rel < 1e-4, (bad, rel, err.max().item())
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
