@@ -561,6 +561,8 @@ __global__ __launch_bounds__(TK_THREADS) void csr_emit_kernel(EmitParams p) {
   __syncthreads();
   auto bnd = [&](int m) { return table ? s_bound[m] : (int)interp_bound(m, scale); };
   const bool aligned = (p.T_m & 31) == 0;             // a mask word never straddles two heads
+  // (row-uniform) every pixel at least 4 keys wide and none wider than max_k, int32 columns, no values output
+  const bool direct = sizeof(I) == 4 && vals == nullptr && aligned && w_t >= 4 * p.T_m && (w_t + p.T_m - 1) / p.T_m <= p.max_k;
 
   // the row is walked in passes of 256 mask words (flat order); carry = entries of the earlier passes
   int carry = 0;
@@ -570,16 +572,66 @@ __global__ __launch_bounds__(TK_THREADS) void csr_emit_kernel(EmitParams p) {
     const int f0 = wi * 32;
     const int h0 = f0 / p.T_m, b0 = f0 - h0 * p.T_m;
     int nent = 0;
-    for (uint32_t m = word; m;) {
-      const int bit = __ffs(m) - 1;
-      m &= m - 1;
-      int b = b0 + bit;
-      if (!aligned) b %= p.T_m;
-      const int wd = bnd(b + 1) - bnd(b);
-      nent += wd < p.max_k ? wd : p.max_k;
+    if (direct) {                                                   // wave-uniform trip count, no thinning (see below)
+      const int npmax = __builtin_amdgcn_readfirstlane(wave_max(__popc(word)));
+      uint32_t m = word;
+      for (int it = 0; it < npmax; ++it) {
+        const bool act = m != 0u;
+        const int b = b0 + (act ? __ffs(m) - 1 : 0);
+        m &= m - 1;
+        const int wd = bnd(b + 1) - bnd(b);
+        nent += act ? wd : 0;
+      }
+    } else {
+      for (uint32_t m = word; m;) {
+        const int bit = __ffs(m) - 1;
+        m &= m - 1;
+        int b = b0 + bit;
+        if (!aligned) b %= p.T_m;
+        const int wd = bnd(b + 1) - bnd(b);
+        nent += wd < p.max_k ? wd : p.max_k;
+      }
     }
     int total;
     const int excl = block_excl_scan(nent, s_wave, &total);
+    if (direct) {
+      // Wide pixels (every pixel of the row spans >= 4 keys, none is thinned): each thread writes its runs STRAIGHT to
+      // memory, four entries per 16-byte store -- no LDS window, no flush, no barrier -- and with WAVE-UNIFORM loops:
+      // this kernel is bound by SCALAR instruction issue (one scalar unit per CU: 8.6e7 scalar against 8.2e7 vector
+      // instructions per launch, profiles/r02d_pmc_per_kernel.txt = 334 k cycles per CU of its 190 us), and what issues
+      // them is the exec-mask bookkeeping of per-lane trip counts (a run loop of 16 iterations costs 3 scalar instructions
+      // each).  Every pixel of the row is wlo or wlo + 1 keys wide (wlo = floor(w_t / T_m)), so a run is written as
+      // ceil((wlo + 1) / 4) four-entry stores for every lane alike, the last one pulled back to end at the run's end
+      // (it overlaps its predecessor with the same values); the walk over a word's kept pixels runs to the wave's maximum.
+      const int wlo = w_t / p.T_m;
+      const int nst = (wlo + 1 + 3) >> 2;                           // stores per run (row-uniform)
+      const int npmax = __builtin_amdgcn_readfirstlane(wave_max(__popc(word)));                     // kept pixels of the busiest lane (wave-uniform)
+      int64_t off = row_beg + carry + excl;
+      uint32_t m = word;
+      const int hb = h0 * p.T_enc;
+      for (int it = 0; it < npmax; ++it) {
+        const bool act = m != 0u;
+        const int bit = act ? __ffs(m) - 1 : 0;
+        m &= m - 1;
+        const int b = b0 + bit;                                     // (direct requires T_m % 32 == 0: no straddling)
+        const int lo = bnd(b), hi = bnd(b + 1);
+        const int wd = hi - lo;
+        if (act && off + wd <= p.z_cap) {
+          int32_t* dst = reinterpret_cast<int32_t*>(col) + off;
+          const int c0 = hb + hi - 1;
+          typedef int ei4 __attribute__((ext_vector_type(4), aligned(4)));   // a run starts on any 4-byte boundary
+          for (int i = 0; i < nst; ++i) {
+            const int j = min(4 * i, wd - 4);
+            const int c = c0 - j;
+            const ei4 v = {c, c - 1, c - 2, c - 3};
+            *reinterpret_cast<ei4*>(dst + j) = v;
+          }
+        }
+        off += act ? wd : 0;
+      }
+      carry += total;
+      continue;
+    }
     // windows of the row covered by this pass: [carry, carry + total)
     for (int win = (carry / EM_WIN) * EM_WIN; win < carry + total; win += EM_WIN) {
       int off = carry + excl;                                       // row-relative offset of this thread's first entry
