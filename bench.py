@@ -207,6 +207,7 @@ class LayerBench:
         mask = ((torch.arange(T, device=dev).view(1, T) > torch.arange(T, device=dev).view(T, 1)) * fp_min)
         self.mask = mask.view(1, 1, T, T).to(self.dtype).expand(NB, 1, T, T).contiguous()
         self.graph, self.rec, self.g_out = None, None, None
+        self._pending = None
         self.attn_events = []
         self.out_override = None          # N > 1: callable(step) -> the (N,H,T,d)-shaped view the attention launch writes
         self.capture_error = None
@@ -249,6 +250,9 @@ class LayerBench:
             self.capture_error = "the layer issued no fused sparse-attention launch"
             return False
         self.graph, self.rec, self.g_out, self._real_attn = graph, rec, g_out, real_attn
+        # sparse_kernel = "gather": the layer leaves the CSR's column array to the attention launch (steps I + J fused), and
+        # the handle says so; a replayed step selects afresh, so the handle is put back into that state before every launch
+        self._pending = rec["a"][3]._pending
         return True
 
     def step(self, out_view=None):
@@ -260,6 +264,8 @@ class LayerBench:
             return out, out.context_layer
         kw = self.rec["kw"] if out_view is None else dict(self.rec["kw"], out=out_view)
         self.graph.replay()
+        if self._pending is not None:
+            self.rec["a"][3]._pending = self._pending
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         self._real_attn(*self.rec["a"], **kw)
@@ -485,6 +491,17 @@ def cpu_rehearsal(args, world, rank):
     return 0 if flag.item() == 1.0 else 4
 
 
+def _stage(msg):
+    """progress marker on stderr (a fault in a later stage is then attributed to it); synchronises first"""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+    except Exception:
+        pass
+    print(f"[bench] {time.strftime('%H:%M:%S')} {msg}", file=sys.stderr, flush=True)
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse_args(argv)
@@ -561,8 +578,10 @@ def main(argv=None):
         full = gather.launch(slot) if do_gather else gather.out[slot]
         return out, full
 
+    _stage("layer built; prewarm")
     for _ in range(args.prewarm):
         lb.forward()
+    _stage("attention path A/B + graph capture")
     # kernel path of the attention launch + HIP-graph capture (both outside the timed region)
     if gather is not None:
         gather.finish()
@@ -583,6 +602,7 @@ def main(argv=None):
         if lb.graph is None:
             path = "auto" if lb.tile_supported() else "gather"
             lb.layer.attention.sparse_kernel = path
+    _stage(f"path {path}; warmup + timed steps")
     for _ in range(args.warmup):
         step()
     if gather is not None:
@@ -651,6 +671,7 @@ def main(argv=None):
     bench.disabled, bench.synchronize = True, False
     bench.reset_measures()
 
+    _stage("timed region done; output check")
     # ---- output self-check (outside the timed region): the batch the bench times is also a batch that is RIGHT -------
     # item n of the batched output == the same item run ALONE through the whole layer, bit for bit (every kernel is
     # deterministic and treats batch items independently; the Performer is told to take the one-pass kernel the batch
@@ -708,6 +729,7 @@ def main(argv=None):
                           else "HIP events of the module's 'attention.sparse.fused' region inside the timed steps")
     esz = torch.tensor([], dtype=dtype).element_size()
 
+    _stage("kernel-level leg")
     # ---- kernel-level path only (H..K on HIP, probs given) -- what the CPU baseline below also runs -------
     kernel_path = None
     if args.kernel_iters > 0:
@@ -765,6 +787,7 @@ def main(argv=None):
             del cs
         del probs, avg, ctx2, rs, mx
 
+    _stage("generation leg / CPU baseline")
     # ---- generation leg: one position per step from a (T - 64)-token prefix, the step replayed as a HIP graph
     decode = None
     if args.decode_steps > 0 and world == 1 and dtype != torch.float32:
@@ -839,6 +862,7 @@ def main(argv=None):
     if gather is not None:
         del gather
     torch.cuda.empty_cache()
+    _stage("short legs")
     if world == 1 and not args.no_other_workloads:
         other = {}
         try:
@@ -849,11 +873,13 @@ def main(argv=None):
         for wn, nb_ in OTHER_LEGS:
             if wn == args.workload and nb_ == NB:
                 continue
+            _stage(f"leg {wn} x{nb_}")
             try:
                 other[f"{wn} x{nb_}"] = short_leg(wn, nb_, args, dev)
             except Exception as e:                               # a leg never takes the headline down; its failure is visible
                 other[f"{wn} x{nb_}"] = {"error": f"{type(e).__name__}: {e}"[:300]}
         if not args.no_train_step and args.dtype != "fp32":
+            _stage("train-step leg")
             try:
                 train = train_step_leg(args.workload, args, dev)
             except Exception as e:

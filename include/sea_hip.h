@@ -195,6 +195,26 @@ int sea_sparse_attention_ex(const void* q, const void* k, const void* v, int dty
                             const uint8_t* block_path, /* buffer filled by sea_attention_plan, or NULL */
                             int flags, sea_stream_t stream);
 
+/* Steps I + J of the hot path in ONE launch (round 3): the nearest-neighbour interpolation of the kept pixels
+ * (causal_resize_m_to_t.py:493-572,631-762) INSIDE the row-indexed sparse attention (flat_csr_masked_bmm / softmax / elmul /
+ * sdbmm).  Each lane group of the gather kernels expands ITS (row, head)'s kept pixels to key columns -- sea_csr_emit's
+ * arithmetic bit for bit: fp32 scale = w_t / T_m, bounds round_half_away(b * scale), keys descending inside a pixel, the
+ * reference's fp32 stepping for a pixel wider than max_k -- into a group-private list in LDS, writes the list to `col` and
+ * walks it from LDS.  No separate sea_csr_emit launch, no column re-read from memory.
+ *   bits      (N, T_dst, ceil(H*T_m/32)) kept-pixel masks of sea_topk_select / sea_predictor_tail_select (T_m % 32 == 0);
+ *   crow      from sea_csr_row_scan over that launch's row_nnz; head_off from the same launch;
+ *   col       (N, col_stride_n) int32: OUTPUT -- after the launch it holds exactly what sea_csr_emit would have written.
+ * Other arguments as sea_sparse_attention_ex (gather path; probs_out allowed).  Rows of 4 lanes and rows wider than 16
+ * lanes are SEA_EUNSUPPORTED: run sea_csr_emit + sea_sparse_attention_ex there. */
+int sea_sparse_attention_fused(const void* q, const void* k, const void* v, int dtype,
+                               int64_t N, int64_t H, int64_t T_dst, int64_t T_src, int64_t D,
+                               const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                               const int32_t* crow, int32_t* col, int64_t col_stride_n, const int32_t* head_off,
+                               const float* row_scale, const void* avg, const int64_t* avg_strides, const float* mix,
+                               void* out, int out_dtype, const int64_t* out_strides,
+                               float* probs_out, int64_t probs_stride_n,
+                               const uint32_t* bits, int64_t T_m, int is_causal, int max_k, sea_stream_t stream);
+
 /* Backward of the fused operator WITHOUT its epilogue (o = sum_e softmax_e(q.k_e) v_e; the caller applies row scale and mix
  * in its autograd framework): dQ, dK, dV from dO.  Reference shape: masked_mm.py:169-267 + the dense branch's autograd
  * (attention.py:1061-1133).  probs = the forward's probs_out with row_scale = NULL; out / dout / dq fp32 (N,H,T_dst,D)

@@ -187,12 +187,103 @@ __device__ inline int slot_length(const AttnParams& p, int n, int h, int tn) {
   return hon[h + 1] - hon[h];
 }
 
+// ---- steps I + J in one launch: the interpolation of ONE (row, head) by the lane group that walks it -----------------------
+// The lane group expands its row's kept pixels of head h to key columns -- the emit kernel's arithmetic, bit for bit
+// (interp_scale / interp_bound, keys descending inside a pixel, the reference's fp32 stepping for a thinned pixel) -- into
+// a group-private list in LDS, copies the list to `col` (the CSR's column array is an output of the layer) and then walks
+// it from LDS: no separate emit launch, no column re-read from memory, and the expansion's scalar-heavy loops run in the
+// shadow of a kernel that is bound by its gathers.  Lane `sub` owns mask word `sub` of the head (T_m / 32 words; more:
+// rounds of LPR); a group scan orders the runs.  The list is written and read by the same wave, whose LDS operations
+// execute in order: no workgroup barrier after the one that sizes the lists.  Blocks whose lists would not fit the LDS
+// budget expand straight into `col` and read it back past the L1 (rare: a head that takes most of a row).
+// Every thread of the block calls (one workgroup barrier inside).
+template <int LPR, int RPB>
+__device__ inline void fused_expand(const AttnParams& p, int n, int h, int tt, bool rowok, int gi, int sub, int beg, int end,
+                                    int hcol, int* s_keys, int* lbase_out, bool* fits_out) {
+  __shared__ int s_glen[RPB];
+  const int mylen = end - beg;
+  if (sub == 0) s_glen[gi] = mylen;
+  __syncthreads();
+  int bef = 0, tot = 0;
+#pragma unroll
+  for (int r = sub; r < RPB; r += LPR) {
+    const int v_ = s_glen[r];
+    tot += v_;
+    bef += r < gi ? v_ : 0;
+  }
+  const int lbase = lane_group_sum_i<LPR>(bef);
+  const bool fits = lane_group_sum_i<LPR>(tot) <= p.fuse_cap;      // block-uniform
+  int32_t* gcol = p.col_w + n * p.col_stride_n;
+  const int WPH = p.T_m >> 5;                              // mask words per head (launcher: T_m % 32 == 0)
+  const int w_t = row_width(tt, p.T_dst, p.T_src, p.is_causal);
+  const float scale = interp_scale(w_t, p.T_m);
+  const uint32_t* brow = p.bits + ((int64_t)n * p.T_dst + tt) * p.W + h * WPH;
+  int carry = 0;
+  for (int w0 = 0; w0 < WPH; w0 += LPR) {                  // uniform
+    const int wi = w0 + sub;
+    const uint32_t word = (rowok && wi < WPH) ? brow[wi] : 0u;
+    int nent = 0;
+    for (uint32_t mm = word; mm;) {
+      const int b = wi * 32 + __ffs(mm) - 1;
+      mm &= mm - 1;
+      const int wd = (int)interp_bound(b + 1, scale) - (int)interp_bound(b, scale);
+      nent += wd < p.max_k ? wd : p.max_k;
+    }
+    int incl = nent;                                       // inclusive scan over the group's LPR lanes (word order)
+#pragma unroll
+    for (int o = 1; o < LPR; o <<= 1) {
+      const int up = __shfl_up(incl, o, LPR);
+      if (sub >= o) incl += up;
+    }
+    int off = carry + incl - nent;
+    carry += __shfl(incl, LPR - 1, LPR);
+    for (uint32_t mm = word; mm;) {
+      const int b = wi * 32 + __ffs(mm) - 1;
+      mm &= mm - 1;
+      const int lo = (int)interp_bound(b, scale), hi = (int)interp_bound(b + 1, scale);
+      const int wd = hi - lo;
+      if (wd <= p.max_k) {
+        const int c0 = hcol + hi - 1;
+        if (fits) { for (int j = 0; j < wd; ++j) s_keys[lbase + off + j] = c0 - j; }
+        else { for (int j = 0; j < wd; ++j) gcol[beg + off + j] = c0 - j; }
+        off += wd;
+      } else {                                             // thinned pixel: the reference's fp32 stepping (csr_emit_kernel)
+        const float rs = (float)lo + (float)hcol, re = (float)hi + (float)hcol;
+        const float step = __fdiv_rn(re - rs, (float)p.max_k);
+        for (int j = 0; j < p.max_k; ++j) {
+          const int c = (int)((re - (float)(int)__fmul_rn((float)j, step)) - 1.0f);
+          if (fits) s_keys[lbase + off + j] = c; else gcol[beg + off + j] = c;
+        }
+        off += p.max_k;
+      }
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (fits) {                                              // the CSR's columns: the list, copied out by its own lane group
+    for (int i = sub; i < mylen; i += LPR) gcol[beg + i] = s_keys[lbase + i];
+  } else {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_waitcnt(0);                         // this wave's column stores have left before it reads them back
+  }
+  *lbase_out = lbase;
+  *fits_out = fits;
+}
+
+// lane `sub`'s column of entry `ec` of its row: from the group's own list (fused, fits), from `col` past the L1 (fused, the
+// block's lists did not fit: written just above by this wave), or from `col` as the emit launch left it
+template <bool FUSE>
+__device__ inline int entry_column(const AttnParams& p, const int32_t* col, int n, int ec, int beg, const int* s_keys, int lbase, bool fits) {
+  if (FUSE && fits) return s_keys[lbase + ec - beg];
+  if (FUSE) return __hip_atomic_load(p.col_w + n * p.col_stride_n + ec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return col[ec];
+}
+
 // ---- variant B: one LPR-lane GROUP per query row (64/LPR rows per wave) -----------------------------------
 // Each group walks its own row's entries, one key per instruction step, U keys in flight, with its own online
 // softmax; nothing is merged across groups.  A wave therefore has 64/LPR independent
 // (offsets -> col -> K/V) load chains in flight instead of one, which is what the wave-per-row mapping lacks.
 // Workgroup = 4 waves = 256/LPR consecutive query rows of one (n, h).
-template <typename T, typename TO, int LPR, int U, bool WP, int NWB = 4>
+template <typename T, typename TO, int LPR, int U, bool WP, int NWB = 4, bool FUSE = false>
 __global__ __launch_bounds__(NWB * 64) void sparse_attn_rows_kernel(AttnParams p) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr int RPW = 64 / LPR;       // rows per wave
@@ -228,6 +319,12 @@ __global__ __launch_bounds__(NWB * 64) void sparse_attn_rows_kernel(AttnParams p
   const int32_t* col = p.col + n * p.col_stride_n;
   const int hcol = h * p.T_src;
 
+  // ---- FUSE: the interpolation of THIS (row, head) inside the attention launch (fused_expand below the helpers) ----------
+  extern __shared__ int s_keys[];
+  int lbase = 0;
+  bool fits = false;
+  if constexpr (FUSE) fused_expand<LPR, RPB>(p, n, h, tt, rowok, gi, sub, beg, end, hcol, s_keys, &lbase, &fits);
+
   float m = -INFINITY, l = 0.f;
   float acc[VEC];
 #pragma unroll
@@ -247,7 +344,7 @@ __global__ __launch_bounds__(NWB * 64) void sparse_attn_rows_kernel(AttnParams p
     {
       const int e = beg + i0 + sub;
       const int ec = e < end ? e : (last >= beg ? last : 0);
-      cidx = (end > beg) ? (col[ec] - hcol) : 0;           // rows without entries read key 0 (masked below)
+      cidx = (end > beg) ? (entry_column<FUSE>(p, col, n, ec, beg, s_keys, lbase, fits) - hcol) : 0;   // rows without entries read key 0 (masked below)
     }
 #pragma unroll
     for (int u0 = 0; u0 < LPR; u0 += U) {
@@ -339,7 +436,7 @@ template <> __device__ inline void unpack2<__half>(uint32_t r, float* f) {
 template <typename TO> __device__ inline void store2(TO* dst, float a, float b) { *reinterpret_cast<uint32_t*>(dst) = pack2<TO>(a, b); }
 template <> __device__ inline void store2<float>(float* dst, float a, float b) { *reinterpret_cast<float2*>(dst) = make_float2(a, b); }
 
-template <typename T, typename TO, int U, bool WP, int NWB = 4>
+template <typename T, typename TO, int U, bool WP, int NWB = 4, bool FUSE = false>
 __global__ __launch_bounds__(NWB * 64) void sparse_attn_rows80_kernel(AttnParams p) {
   constexpr int LPR = 8, VEC = 8, XT = 2, DM = LPR * VEC;     // DM = 64 elements in the 16-byte fragments
   constexpr int RPW = 64 / LPR, RPB = NWB * RPW;
@@ -369,6 +466,10 @@ __global__ __launch_bounds__(NWB * 64) void sparse_attn_rows80_kernel(AttnParams
   const int end = rowok ? row_beg + ho[h + 1] : beg;
   const int32_t* col = p.col + n * p.col_stride_n;
   const int hcol = h * p.T_src;
+  extern __shared__ int s_keys[];                          // fused interpolation: see fused_expand
+  int lbase = 0;
+  bool fits = false;
+  if constexpr (FUSE) fused_expand<LPR, RPB>(p, n, h, tt, rowok, gi, sub, beg, end, hcol, s_keys, &lbase, &fits);
 
   float m = -INFINITY, l = 0.f;
   float acc[VEC + XT];
@@ -385,7 +486,7 @@ __global__ __launch_bounds__(NWB * 64) void sparse_attn_rows80_kernel(AttnParams
     {
       const int e = beg + i0 + sub;
       const int ec = e < end ? e : (last >= beg ? last : 0);
-      cidx = (end > beg) ? (col[ec] - hcol) : 0;
+      cidx = (end > beg) ? (entry_column<FUSE>(p, col, n, ec, beg, s_keys, lbase, fits) - hcol) : 0;
     }
 #pragma unroll
     for (int u0 = 0; u0 < LPR; u0 += U) {
@@ -594,7 +695,8 @@ static int launch_attn_wp(AttnParams p, hipStream_t s) {
       const int rpb = 8 * 8;                               // 8 waves x 8 rows, sorted by length
       p.TB = (p.T_dst + rpb - 1) / rpb;
       const int64_t blocks = (int64_t)8 * ((NH + 7) / 8) * p.TB;
-      hipLaunchKernelGGL((sparse_attn_rows80_kernel<T, TO, 4, WP, 8>), dim3((unsigned)blocks), dim3(512), 0, s, p);
+      if (p.bits) hipLaunchKernelGGL((sparse_attn_rows80_kernel<T, TO, 4, WP, 8, true>), dim3((unsigned)blocks), dim3(512), p.fuse_cap * (int)sizeof(int), s, p);
+      else hipLaunchKernelGGL((sparse_attn_rows80_kernel<T, TO, 4, WP, 8>), dim3((unsigned)blocks), dim3(512), 0, s, p);
       return SEA_OK;
     }
   }
@@ -606,6 +708,13 @@ static int launch_attn_wp(AttnParams p, hipStream_t s) {
     p.TB = (p.T_dst + rpb - 1) / rpb;
     const int64_t blocks = (int64_t)8 * ((NH + 7) / 8) * p.TB;
     dim3 grid((unsigned)blocks), block(nwb * 64);
+    if (p.bits) {                                          // fused interpolation: group-private key lists in LDS
+      if (lpr == 4) return SEA_EUNSUPPORTED;
+      const int lds = p.fuse_cap * (int)sizeof(int);
+      if (lpr == 8) hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 8, 4, WP, 8, true>), grid, block, lds, s, p);
+      else hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 16, 4, WP, 8, true>), grid, block, lds, s, p);
+      return SEA_OK;
+    }
     switch (lpr) {
       case 4: hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 4, 4, WP, 4>), grid, block, 0, s, p); break;
       case 8: hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 8, 4, WP, 8>), grid, block, 0, s, p); break;
@@ -613,6 +722,7 @@ static int launch_attn_wp(AttnParams p, hipStream_t s) {
     }
     return SEA_OK;
   }
+  if (p.bits) return SEA_EUNSUPPORTED;                      // (the wave-per-row kernel below has no fused form)
   const int64_t blocks = (int64_t)8 * ((NH + 7) / 8) * p.TB;
   dim3 grid((unsigned)blocks), block(256);
   switch (lpr) {
@@ -675,15 +785,15 @@ static int check_dtype(const char* name, int dtype) {
   return SEA_OK;
 }
 
-extern "C" int sea_sparse_attention_ex(const void* q, const void* k, const void* v, int dtype, int64_t N, int64_t H,
-                                       int64_t T_dst, int64_t T_src, int64_t D, const int64_t* q_strides,
-                                       const int64_t* k_strides, const int64_t* v_strides, const int32_t* crow,
-                                       const int32_t* col, int64_t col_stride_n, const int32_t* head_off,
-                                       const float* row_scale, const void* avg, const int64_t* avg_strides,
-                                       const float* mix, void* out, int out_dtype, const int64_t* out_strides,
-                                       float* probs_out, int64_t probs_stride_n, const uint8_t* block_path, int flags,
-                                       sea_stream_t stream) {
-  const char* nm = "sea_sparse_attention";
+// bits != NULL: the fused form (sea_sparse_attention_fused) -- `col` is written by the launch, not read
+static int attention_entry(const char* nm, const void* q, const void* k, const void* v, int dtype, int64_t N, int64_t H,
+                           int64_t T_dst, int64_t T_src, int64_t D, const int64_t* q_strides,
+                           const int64_t* k_strides, const int64_t* v_strides, const int32_t* crow,
+                           const int32_t* col, int64_t col_stride_n, const int32_t* head_off,
+                           const float* row_scale, const void* avg, const int64_t* avg_strides,
+                           const float* mix, void* out, int out_dtype, const int64_t* out_strides,
+                           float* probs_out, int64_t probs_stride_n, const uint8_t* block_path, int flags,
+                           const uint32_t* bits, int64_t T_m, int is_causal, int max_k, sea_stream_t stream) {
   SEA_REQUIRE(q && k && v && crow && col && head_off && out && q_strides && k_strides && v_strides && out_strides,
               SEA_EINVAL, "%s: null pointer", nm);
   if (int e = check_dtype(nm, dtype)) return e;
@@ -718,6 +828,13 @@ extern "C" int sea_sparse_attention_ex(const void* q, const void* k, const void*
   // with the plan's cut at 30 entries per staged tile the structured map gives 0.53 / 0.71 / 0.51 at d = 64 / 80 / 128 and
   // the tile kernel wins by 4 % / 13 % / loses by 13 %; the layer's own and independent rows give <= 0.33 and lose always)
   p.sel_num = D >= 128 ? 13 : 1; p.sel_den = D >= 128 ? 20 : 2;
+  p.bits = bits; p.col_w = const_cast<int32_t*>(col); p.T_m = (int)T_m; p.W = (int)((H * T_m + 31) / 32);
+  p.max_k = max_k; p.is_causal = is_causal;
+  p.fuse_cap = 8192;                                        // entries of a block's key lists held in LDS (32 KB)
+  if (bits) {
+    SEA_REQUIRE(path != SEA_ATTN_TILE && block_path == nullptr, SEA_EUNSUPPORTED, "%s: the fused interpolation runs on the gather kernels", nm);
+    SEA_REQUIRE(T_m > 0 && T_m % 32 == 0 && max_k > 0, SEA_EUNSUPPORTED, "%s: fused interpolation needs T_m %% 32 == 0", nm);
+  }
   p.TB = (int)((T_dst + 3) / 4);
   hipStream_t s = (hipStream_t)stream;
   const bool tile_ok = attn_tile_supported(dtype, (int)D, (int)T_src, p) && probs_out == nullptr;
@@ -746,6 +863,36 @@ extern "C" int sea_sparse_attention_ex(const void* q, const void* k, const void*
   SEA_REQUIRE(rc == SEA_OK, rc, "%s: unsupported head size %lld", nm, (long long)D);
   SEA_CHECK_LAUNCH(nm);
   return SEA_OK;
+}
+
+extern "C" int sea_sparse_attention_ex(const void* q, const void* k, const void* v, int dtype, int64_t N, int64_t H,
+                                       int64_t T_dst, int64_t T_src, int64_t D, const int64_t* q_strides,
+                                       const int64_t* k_strides, const int64_t* v_strides, const int32_t* crow,
+                                       const int32_t* col, int64_t col_stride_n, const int32_t* head_off,
+                                       const float* row_scale, const void* avg, const int64_t* avg_strides,
+                                       const float* mix, void* out, int out_dtype, const int64_t* out_strides,
+                                       float* probs_out, int64_t probs_stride_n, const uint8_t* block_path, int flags,
+                                       sea_stream_t stream) {
+  return attention_entry("sea_sparse_attention", q, k, v, dtype, N, H, T_dst, T_src, D, q_strides, k_strides, v_strides, crow, col,
+                         col_stride_n, head_off, row_scale, avg, avg_strides, mix, out, out_dtype, out_strides, probs_out,
+                         probs_stride_n, block_path, flags, nullptr, 0, 0, 0, stream);
+}
+
+// Steps I + J in ONE launch: the gather kernel expands the selection's kept pixels to key columns itself (the emit's
+// arithmetic), writes them to `col` and walks them from LDS.  crow / head_off as for sea_sparse_attention (from
+// sea_csr_row_scan and the selection launch); `col` (N, col_stride_n) is OUTPUT here.
+extern "C" int sea_sparse_attention_fused(const void* q, const void* k, const void* v, int dtype, int64_t N, int64_t H,
+                                          int64_t T_dst, int64_t T_src, int64_t D, const int64_t* q_strides,
+                                          const int64_t* k_strides, const int64_t* v_strides, const int32_t* crow,
+                                          int32_t* col, int64_t col_stride_n, const int32_t* head_off,
+                                          const float* row_scale, const void* avg, const int64_t* avg_strides,
+                                          const float* mix, void* out, int out_dtype, const int64_t* out_strides,
+                                          float* probs_out, int64_t probs_stride_n, const uint32_t* bits, int64_t T_m,
+                                          int is_causal, int max_k, sea_stream_t stream) {
+  SEA_REQUIRE(bits != nullptr, SEA_EINVAL, "sea_sparse_attention_fused: null pointer");
+  return attention_entry("sea_sparse_attention_fused", q, k, v, dtype, N, H, T_dst, T_src, D, q_strides, k_strides, v_strides, crow,
+                         col, col_stride_n, head_off, row_scale, avg, avg_strides, mix, out, out_dtype, out_strides, probs_out,
+                         probs_stride_n, nullptr, SEA_ATTN_GATHER, bits, T_m, is_causal, max_k, stream);
 }
 
 extern "C" int sea_sparse_attention(const void* q, const void* k, const void* v, int dtype, int64_t N, int64_t H,

@@ -30,6 +30,11 @@ struct AttnParams {
   const int32_t* sel_count;
   int sel_total, sel_num, sel_den;
   int TB;  // row blocks per (n, h): ceil(T_dst / 4)
+  // fused interpolation (sea_sparse_attention_fused): the gather kernel expands the kept pixels itself -- `col` holds no
+  // columns yet, the kernel WRITES them (col_w) while it walks them.  bits (N, T_dst, W) from the selection launch.
+  const uint32_t* bits;
+  int32_t* col_w;
+  int T_m, W, max_k, is_causal, fuse_cap;
 };
 
 template <typename TO, int VEC> __device__ inline void store_frag(TO* dst, const float* f);

@@ -219,6 +219,14 @@ class PerlinAttention(nn.Module):
         return super()._apply(fn, *args, **kwargs)
 
     # ------------------------------------------------------------------------------------------------
+    def _fuses_interpolation(self, q, T_M) -> bool:
+        """Steps I + J in one launch (`sea_sparse_attention_fused`): with `sparse_kernel` "gather" or "auto" and a head shape
+        the fused gather kernels cover, the CSR's column array is left to the attention launch.  "auto" takes it wherever
+        it exists: fused gather beats emit + the better of {gather, tile} on every map measured (OPT-1.3B x 8: layer's own
+        0.99 + 0.03 vs 0.96 + 0.18 ms, structured 0.98 vs tile 0.90 + 0.18; LLaMA-13B: gather wins anyway); the plan-based
+        choice between the two kernels remains for shapes without a fused form (d = 80)."""
+        return self.sparse_kernel in ("gather", "auto") and ops.fused_interp_supported(q.dtype, q.shape[-1], T_M)
+
     def _keep_table(self, H, T_dst, T_src, T_M, device):
         """K_t (int32, device) + analytic CSR capacity, cached per shape (host work only once)."""
         k, os_ = self.pconfig.k, self.pconfig.k_oversample
@@ -750,7 +758,8 @@ class PerlinAttention(nn.Module):
             # ---- H-I: grouped top-k of the new rows (their absolute widths), interpolation to flat CSR -------------
             with timer("interp"):
                 if fused_sel is not None:
-                    csr = ops.csr_from_selection(*fused_sel, H, T_M, T_SRC, int(self.pconfig.k), True, z_cap)
+                    csr = ops.csr_from_selection(*fused_sel, H, T_M, T_SRC, int(self.pconfig.k), True, z_cap,
+                                                 defer_emit=self._fuses_interpolation(q, T_M))
                 else:
                     keep_cpu, z_cap = self._decode_keep(H, T_DST, T_SRC, T_M)
                     csr, _ = ops.topk_to_csr(estimated_attention_probs, keep_cpu.to(q.device), int(self.pconfig.k),
@@ -780,7 +789,7 @@ class PerlinAttention(nn.Module):
                 want_p = self.return_attention_probs
                 plan = None
                 if (self.sparse_kernel == "auto" and not want_p and qs.dtype != torch.float32 and HID in (64, 80, 128)
-                        and T_DST >= 16):                    # same kernel choice as the stateless path
+                        and T_DST >= 16 and not csr.col_is_pending):   # same kernel choice as the stateless path
                     plan = ops.attention_plan(csr, T_M, is_causal=True)
                 res = ops.sparse_attention(qs, ks, vs, csr, row_scale=row_scale, avg=average_context_layer.to(qs.dtype).contiguous(),
                                            mix=average_scale, out=ctx.view(N, T_DST, H, HID).permute(0, 2, 1, 3),
@@ -814,7 +823,11 @@ class PerlinAttention(nn.Module):
             fs = self._fused_selection
             if fs is not None and fs[0] is probs and not_padded and not probing:
                 # the selection already ran inside the predictor-tail launch on this very map: scan + emit only
-                csr, mask_m = ops.csr_from_selection(*fs[1], H, T_M, T_SRC, int(self.pconfig.k), True, z_cap), None
+                # `sparse_kernel = "gather"`: the column array is left to the attention launch, whose gather kernels do the
+                # interpolation of their own (row, head) themselves and write `col` (sea_sparse_attention_fused: steps I + J
+                # in one launch); with any other consumer the handle runs the emit launch on first use of `.col`
+                csr, mask_m = ops.csr_from_selection(*fs[1], H, T_M, T_SRC, int(self.pconfig.k), True, z_cap,
+                                                     defer_emit=self._fuses_interpolation(q, T_M)), None
             else:
                 csr, mask_m = ops.topk_to_csr(probs, keep, int(self.pconfig.k), target_width=T_SRC, is_causal=True,
                                               z_cap=z_cap, want_mask=probing)
@@ -887,7 +900,7 @@ class PerlinAttention(nn.Module):
                     ctx = torch.empty((N, T, H * HID), dtype=out_dtype, device=q.device)
                     plan = None
                     if (self.sparse_kernel == "auto" and not want_probs and qs.dtype != torch.float32
-                            and HID in (64, 80, 128)):
+                            and HID in (64, 80, 128) and not csr.col_is_pending):
                         # kernel choice on the device: a small launch over the selection's pixel masks counts the 16-row
                         # blocks whose rows share most of their keys; the MFMA tile kernel runs the launch when they are
                         # the majority, the gather kernels otherwise (the idle kernel's workgroups exit at once)

@@ -41,12 +41,27 @@ class FlatCSR:
     the wire format; the first such call costs the one host sync the reference pays at causal_resize_m_to_t.py:667)."""
 
     def __init__(self, crow, col, head_off, H, T_src, bits=None, row_nnz=None, vals=None):
-        self.crow, self.col, self.head_off = crow, col, head_off
+        self.crow, self._col, self.head_off = crow, col, head_off
         self.H, self.T_src = H, T_src
         self.bits, self.row_nnz = bits, row_nnz
         self.vals = vals
         self.N, self.T_dst = crow.shape[0], crow.shape[1] - 1
         self._wire = None
+        # (T_m, max_k, is_causal, emit launcher) while the column array has not been written yet: `csr_from_selection(...,
+        # defer_emit=True)` hands such a handle to the fused attention launch, which writes `col` itself; whoever reads
+        # `.col` first otherwise runs the emit launch then (same stream: ordered behind the selection)
+        self._pending = None
+
+    @property
+    def col(self):
+        if self._pending is not None:
+            emit, self._pending = self._pending[3], None
+            emit()
+        return self._col
+
+    @property
+    def col_is_pending(self) -> bool:
+        return self._pending is not None
 
     @property
     def shape(self):
@@ -172,7 +187,7 @@ def topk_to_csr(probs: torch.Tensor, keep: torch.Tensor, k: int, target_width: O
 @_lib.device_guarded
 def csr_from_selection(bits: torch.Tensor, row_nnz: torch.Tensor, head_off: torch.Tensor, H: int, T_m: int, T_src: int,
                        k: int, is_causal: bool = True, z_cap: Optional[int] = None, keep: Optional[torch.Tensor] = None,
-                       t_src_dev: Optional[torch.Tensor] = None):
+                       t_src_dev: Optional[torch.Tensor] = None, defer_emit: bool = False):
     """Row scan + emit: the (bits, row_nnz, head_off) of a selection launch (sea_topk_select or the fused
     sea_predictor_tail_select) -> FlatCSR.  Two launches, no host sync.
     Decode form (`sea_csr_emit_at`): `t_src_dev` (one int32 on the device) is the sequence length the row widths follow,
@@ -192,10 +207,17 @@ def csr_from_selection(bits: torch.Tensor, row_nnz: torch.Tensor, head_off: torc
             _p(bits), _p(crow), N, H, T_dst, T_m, _p(t_src_dev), T_src, int(is_causal), int(k),
             _p(col), 4, col.stride(0), z_cap, st), "sea_csr_emit_at")
         return FlatCSR(crow, col, head_off, H, T_src, bits=bits, row_nnz=row_nnz)
-    _lib.check(lib.sea_csr_emit(
-        _p(bits), _p(crow), _p(head_off), N, H, T_dst, T_m, T_src, int(is_causal), int(k),
-        _p(col), 4, col.stride(0), z_cap, None, st), "sea_csr_emit")
-    return FlatCSR(crow, col, head_off, H, T_src, bits=bits, row_nnz=row_nnz)
+    def emit():
+        with torch.cuda.device(dev):
+            _lib.check(lib.sea_csr_emit(
+                _p(bits), _p(crow), _p(head_off), N, H, T_dst, T_m, T_src, int(is_causal), int(k),
+                _p(col), 4, col.stride(0), z_cap, None, _lib.stream_ptr()), "sea_csr_emit")
+    csr = FlatCSR(crow, col, head_off, H, T_src, bits=bits, row_nnz=row_nnz)
+    if defer_emit:          # the fused attention launch (sparse_attention(..., fuse_emit=True)) will write `col`; any other
+        csr._pending = (int(T_m), int(k), bool(is_causal), emit)    # reader of `.col` triggers this emit launch itself
+    else:
+        emit()
+    return csr
 
 
 @_lib.device_guarded
@@ -221,6 +243,16 @@ def topk_mask(probs: torch.Tensor, keep: torch.Tensor, k: int, target_width=None
 
 
 _PATHS = {"auto": _lib.SEA_ATTN_AUTO, "gather": _lib.SEA_ATTN_GATHER, "tile": _lib.SEA_ATTN_TILE}
+
+
+def fused_interp_supported(dtype, D: int, T_m: int) -> bool:
+    """Shapes `sea_sparse_attention_fused` covers (steps I + J in one launch): rows of 8 or 16 lanes (16-bit d = 64 / 80 / 128,
+    fp32 d = 32 / 64), T_m a multiple of 32."""
+    vec = 4 if dtype == torch.float32 else 8
+    lanes = 1
+    while lanes * vec < D:
+        lanes *= 2
+    return lanes in (8, 16) and D % vec == 0 and T_m % 32 == 0
 
 
 class _SparseAttentionFn(torch.autograd.Function):
@@ -315,7 +347,7 @@ def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = 
                      avg: Optional[torch.Tensor] = None, mix: Optional[torch.Tensor] = None,
                      out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None,
                      path: str = "auto", want_probs: bool = False, row_tiles: int = 0, key_window: int = 0,
-                     plan: Optional[torch.Tensor] = None):
+                     plan: Optional[torch.Tensor] = None, fuse_emit: bool = True):
     """Fused SDDMM + per-(row,head) softmax + row scale + SpMM (+ mix) over the flat CSR (`sea_sparse_attention_ex`).
 
     q (N,H,T_dst,D), k/v (N,H,T_src,D), any [n,h,t] strides, feature stride 1.
@@ -338,6 +370,12 @@ def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = 
         assert out is None and not want_probs, "the differentiable form returns a new fp32 tensor"
         return sparse_attention_autograd(q, k, v, csr, row_scale, avg, mix)
     N, H, T_dst, D = q.shape
+    # a handle whose columns are still pending (csr_from_selection(..., defer_emit=True)): the gather kernels expand the
+    # kept pixels themselves and WRITE `col` (sea_sparse_attention_fused) where their fused form exists; anything else
+    # (the tile kernel, a plan that may choose it, rows of 4 lanes / d = 80 / wider than 16 lanes) reads `.col`, which
+    # runs the emit launch first
+    fused = (csr.col_is_pending and fuse_emit and path != "tile" and not (path == "auto" and plan is not None)
+             and fused_interp_supported(q.dtype, D, csr._pending[0]))
     T_src = k.shape[2]
     assert k.shape == (N, H, T_src, D) and v.shape == (N, H, T_src, D)
     assert q.dtype == k.dtype == v.dtype
@@ -350,10 +388,28 @@ def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = 
     if mix is not None:
         assert avg is not None and avg.shape == (N, H, T_dst, D) and avg.dtype == q.dtype
         assert mix.dtype == torch.float32 and mix.shape == (N, H, T_dst) and mix.is_contiguous()
-    probs = torch.zeros(csr.col.shape, dtype=torch.float32, device=q.device) if want_probs else None
     if plan is not None:
         nb_ = N * H * ((T_dst + 15) // 16)
         assert plan.dtype == torch.uint8 and plan.numel() == ((nb_ + 3) & ~3) + 4 and plan.is_contiguous()
+    if fused:
+        T_m_, max_k_, causal_, _emit = csr._pending
+        raw_col = csr._col
+        probs = torch.zeros(raw_col.shape, dtype=torch.float32, device=q.device) if want_probs else None
+        rc = lib.sea_sparse_attention_fused(
+            _p(q), _p(k), _p(v), _lib.dtype_code(q.dtype), N, H, T_dst, T_src, D,
+            _lib.strides3(q), _lib.strides3(k), _lib.strides3(v),
+            _p(csr.crow), _p(raw_col), raw_col.stride(0), _p(csr.head_off),
+            _p(row_scale), _p(avg), _lib.strides3(avg) if avg is not None else None, _p(mix),
+            _p(out), _lib.dtype_code(out.dtype), _lib.strides3(out),
+            _p(probs), probs.stride(0) if probs is not None else 0,
+            _p(csr.bits), T_m_, int(causal_), max_k_, _lib.stream_ptr())
+        if rc == 0:
+            csr._pending = None                             # the launch has written the columns
+            return (out, probs) if want_probs else out
+        if rc != _lib.SEA_EUNSUPPORTED:
+            _lib.check(rc, "sea_sparse_attention_fused")
+        # a shape the fused form does not cover (nothing was launched): emit, then the plain operator below
+    probs = torch.zeros(csr.col.shape, dtype=torch.float32, device=q.device) if want_probs else None
     flags = _PATHS[path] | ((int(row_tiles) & 0xf) << 8)
     if key_window:
         assert key_window & (key_window - 1) == 0, "key_window is a power of two"
