@@ -328,7 +328,7 @@ class LayerBench:
         alg_bytes = ops.sparse_attention_bytes(Z, NB, H, T, d, esz)
         osz = torch.tensor([], dtype=self.ctx_dtype).element_size()
         compulsory = (4 * NB * H * T * d * esz + NB * H * T * d * osz     # q, k, v, avg in; out
-                      + Z * 4 + NB * T * (H + 2) * 4                      # col, head_off, crow
+                      + Z * 4 + NB * T * (H + 2) * 4                      # col (read, or written by the fused form), head_off, crow
                       + 2 * NB * H * T * 4)                               # row_scale, mix
         if not t_attn_s:
             return None, Z
@@ -348,9 +348,13 @@ class LayerBench:
             except Exception:
                 pass
         gname = "sparse_attn_rows80_kernel" if d == 80 and esz == 2 else "sparse_attn_rows_kernel"
-        kname = {"tile": "sparse_attn_tile_kernel", "gather": gname,
+        fused_ij = path in ("gather", "auto") and ops.fused_interp_supported(self.dtype, d, w["T_M"])
+        if fused_ij:      # steps I + J in one launch: the kernel also expands the kept pixels and writes the CSR's columns
+            gname += " (fused form: interpolation + attention, sea_sparse_attention_fused)"
+        kname = {"tile": "sparse_attn_tile_kernel", "gather": gname, "auto": gname} if fused_ij else {"tile": "sparse_attn_tile_kernel", "gather": gname,
                  "auto": "attn_plan_kernel + " + gname + " + sparse_attn_tile_kernel (kernel choice on the device: the plan, the "
-                         "running kernel and the idle kernel's exit all sit inside the timed events)"}[path]
+                         "running kernel and the idle kernel's exit all sit inside the timed events)"}
+        kname = kname[path]
         # achieved = SURVEY 8d's algorithmic bytes (every gathered K / V row counted once per entry) / launch time.  K + V of
         # one head stay in the XCD's L2, so what binds is the L2 -> L1 request path, not HBM: `bound` says so, `frac` is
         # still against the 8 TB/s HBM line (the contract's roofline), `l2_gather_frac` against the 17.8 TB/s the
