@@ -284,7 +284,7 @@ __device__ inline int entry_column(const AttnParams& p, const int32_t* col, int 
 // (offsets -> col -> K/V) load chains in flight instead of one, which is what the wave-per-row mapping lacks.
 // Workgroup = 4 waves = 256/LPR consecutive query rows of one (n, h).
 template <typename T, typename TO, int LPR, int U, bool WP, int NWB = 4, bool FUSE = false>
-__global__ __launch_bounds__(NWB * 64) void sparse_attn_rows_kernel(AttnParams p) {
+__global__ __launch_bounds__(NWB * 64, (FUSE && LPR == 8 && sizeof(T) == 2 && !WP) ? 8 : 1) void sparse_attn_rows_kernel(AttnParams p) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr int RPW = 64 / LPR;       // rows per wave
   constexpr int RPB = NWB * RPW;      // rows per workgroup
