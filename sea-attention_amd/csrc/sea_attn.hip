@@ -284,7 +284,9 @@ __device__ inline int entry_column(const AttnParams& p, const int32_t* col, int 
 // (offsets -> col -> K/V) load chains in flight instead of one, which is what the wave-per-row mapping lacks.
 // Workgroup = 4 waves = 256/LPR consecutive query rows of one (n, h).
 template <typename T, typename TO, int LPR, int U, bool WP, int NWB = 4, bool FUSE = false>
-__global__ __launch_bounds__(NWB * 64, (FUSE && LPR == 8 && sizeof(T) == 2 && !WP) ? 8 : 1) void sparse_attn_rows_kernel(AttnParams p) {
+// the fused 16-bit inference forms are held to 64 registers (8 waves per SIMD; 4 - 8 spilled registers): measured 0.307 ms
+// against 0.328 ms at 88 registers for the 16-lane form (LLaMA-13B d = 128), and the same direction for the 8-lane form
+__global__ __launch_bounds__(NWB * 64, (FUSE && sizeof(T) == 2 && !WP) ? 8 : 1) void sparse_attn_rows_kernel(AttnParams p) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr int RPW = 64 / LPR;       // rows per wave
   constexpr int RPB = NWB * RPW;      // rows per workgroup
@@ -437,6 +439,8 @@ template <typename TO> __device__ inline void store2(TO* dst, float a, float b) 
 template <> __device__ inline void store2<float>(float* dst, float a, float b) { *reinterpret_cast<float2*>(dst) = make_float2(a, b); }
 
 template <typename T, typename TO, int U, bool WP, int NWB = 4, bool FUSE = false>
+// (no wave floor here: capping this kernel at 80 / 64 registers for 6 / 8 waves per SIMD measured 0.427 / 0.489 ms against
+// 0.418 ms as compiled, OPT-2.7B T = 8192 -- DESIGN.md section 9)
 __global__ __launch_bounds__(NWB * 64) void sparse_attn_rows80_kernel(AttnParams p) {
   constexpr int LPR = 8, VEC = 8, XT = 2, DM = LPR * VEC;     // DM = 64 elements in the 16-byte fragments
   constexpr int RPW = 64 / LPR, RPB = NWB * RPW;

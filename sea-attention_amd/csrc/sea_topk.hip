@@ -94,7 +94,7 @@ __device__ inline int block_excl_scan(int v, int* s_wave /*[TK_WAVES]*/, int* to
   return base + incl - v;
 }
 
-constexpr int TK_CAND_CAP = 1024;  // threshold-bin keys resolved by direct ranking (more -> multi-pass fallback)
+constexpr int TK_CAND_CAP = 512;  // threshold-bin keys resolved by direct ranking (more -> multi-pass fallback)
 
 // Slow path, rarely taken (massive ties / all-equal rows / overfull threshold bin): classic MSB radix passes
 // followed by an ordered tie scan.  It re-reads the row from memory in every pass instead of using the caller's
@@ -399,6 +399,7 @@ __device__ __forceinline__ void select_body(const TopkParams& p, uint32_t (&key)
 }
 
 template <typename T, int EPT, bool FROM_MASK, bool FULL>
+// (no register cap here: 80 registers for a sixth wave spill 12-14 of this kernel's and cost 280 -> 378 us at OPT-1.3B x 8)
 __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(TopkParams p) {
   constexpr int R = EPT / 4;  // chunk rounds
   const int tid = threadIdx.x;
@@ -442,8 +443,12 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(TopkParams p) {
 // c = 256j + tid of the selection kernel.  So the tail's softmax output, rounded to the map's dtype, is stored for the
 // caller (the module returns the map) AND becomes the selection key in registers: the selection never re-reads the
 // (N,H,T,T_m) map from memory.  Results are bit-identical to the two-launch path (same arithmetic, same rounding).
+// Register caps that buy a wave of occupancy per SIMD (4 waves per workgroup, so one more resident workgroup per CU), measured:
+// H = 32 (EPT 32): 87-90 -> 80 registers (1 spill), 5 -> 6 waves, 499 -> 412 us at OPT-1.3B x 8 (with the candidate list cut to
+// 512 so that six workgroups' LDS fits); 72 registers (40 spills) 574 us.  H <= 16: 76 -> 72, 6 -> 7 waves, -5 %.  H = 40: 97-108
+// -> 96 (2-4 spills), 4 -> 5 waves, -7 %.
 template <typename T, int EPT, bool FULL>
-__global__ __launch_bounds__(TK_THREADS) void predictor_tail_select_kernel(TailParams tp, TopkParams p) {
+__global__ __launch_bounds__(TK_THREADS, EPT <= 16 ? 7 : EPT == 32 ? 6 : EPT == 40 ? 5 : 1) void predictor_tail_select_kernel(TailParams tp, TopkParams p) {
   constexpr int R = EPT / 4, E = 4;
   extern __shared__ __attribute__((aligned(16))) float s_z[];     // HP x (W4 + 3)
   const int tid = threadIdx.x;
