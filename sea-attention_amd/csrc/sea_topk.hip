@@ -94,7 +94,7 @@ __device__ inline int block_excl_scan(int v, int* s_wave /*[TK_WAVES]*/, int* to
   return base + incl - v;
 }
 
-constexpr int TK_CAND_CAP = 512;  // threshold-bin keys resolved by direct ranking (more -> multi-pass fallback)
+constexpr int TK_CAND_CAP = 1024;  // threshold-bin keys resolved by direct ranking (more -> multi-pass fallback)
 
 // Slow path, rarely taken (massive ties / all-equal rows / overfull threshold bin): classic MSB radix passes
 // followed by an ordered tie scan.  It re-reads the row from memory in every pass instead of using the caller's
@@ -208,18 +208,27 @@ __device__ inline long long block_excl_scan64(long long v, long long* s_wave /*[
 // Everything after the keys of the row are in registers: threshold search, bit mask, per-head entry counts.
 // Shared by topk_select_kernel (keys loaded from the probability map) and predictor_tail_select_kernel (keys
 // produced in registers by the predictor tail).  `base` = the row's probabilities in memory (slow path only).
-// HMAX: bound on p.H (sizes the per-head counters; the fused kernel's 64 keeps five workgroups per CU with its tables).
-template <typename T, int EPT, bool FROM_MASK, bool FULL, int HMAX = 1024>
+// HMAX: bound on p.H (sizes the per-head counters; the fused kernel's 64 keeps its LDS small).
+// cand: LDS for the candidate list, 2 * TK_CAND_CAP words that nobody else touches from the first barrier in here on; nullptr
+// -> a static array of this function (the fused tail + selection kernel lends the z tile it no longer needs: 8 KB less LDS per
+// workgroup, which is what lets a sixth workgroup onto a CU).
+template <typename T, int EPT, bool FROM_MASK, bool FULL, int HMAX = 1024, bool EXT_CAND = false>
 __device__ __forceinline__ void select_body(const TopkParams& p, uint32_t (&key)[EPT], unsigned long long sel, int n, int t,
-                                            int row, const T* base) {
+                                            int row, const T* base, uint32_t* cand = nullptr) {
   constexpr int R = EPT / 4;  // chunk rounds
   __shared__ int s_hist[TK_MAX_BINS + 1];          // +1: dump bin for unused register slots
   __shared__ int s_head[HMAX];
   __shared__ int s_wave[TK_WAVES];
   __shared__ uint32_t s_red[2 * TK_WAVES];
   __shared__ int s_bcast[4];
-  __shared__ uint32_t s_ckey[TK_CAND_CAP];         // threshold-bin candidates: key ...
-  __shared__ uint32_t s_cidx[TK_CAND_CAP];         // ... and flat pixel index
+  uint32_t* s_ckey;                                // threshold-bin candidates: key ...
+  uint32_t* s_cidx;                                // ... and flat pixel index
+  if constexpr (EXT_CAND) {
+    s_ckey = cand; s_cidx = cand + TK_CAND_CAP;
+  } else {
+    __shared__ uint32_t s_cand[2 * TK_CAND_CAP];
+    s_ckey = s_cand; s_cidx = s_cand + TK_CAND_CAP;
+  }
   __shared__ uint32_t s_selbits[512];              // resolved candidates, one bit per flat pixel (M <= 16384)
   __shared__ int s_ncand;
 
@@ -444,8 +453,8 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(TopkParams p) {
 // caller (the module returns the map) AND becomes the selection key in registers: the selection never re-reads the
 // (N,H,T,T_m) map from memory.  Results are bit-identical to the two-launch path (same arithmetic, same rounding).
 // Register caps that buy a wave of occupancy per SIMD (4 waves per workgroup, so one more resident workgroup per CU), measured:
-// H = 32 (EPT 32): 87-90 -> 80 registers (1 spill), 5 -> 6 waves, 499 -> 412 us at OPT-1.3B x 8 (with the candidate list cut to
-// 512 so that six workgroups' LDS fits); 72 registers (40 spills) 574 us.  H <= 16: 76 -> 72, 6 -> 7 waves, -5 %.  H = 40: 97-108
+// H = 32 (EPT 32): 87-90 -> 80 registers (1 spill), 5 -> 6 waves, 499 -> 412 us at OPT-1.3B x 8 (with the candidate list moved
+// into the dead z tile so that six workgroups' LDS fits); 72 registers (18-40 spills) 449-574 us.  H <= 16: 76 -> 72, 6 -> 7 waves, -5 %.  H = 40: 97-108
 // -> 96 (2-4 spills), 4 -> 5 waves, -7 %.
 template <typename T, int EPT, bool FULL>
 __global__ __launch_bounds__(TK_THREADS, EPT <= 16 ? 7 : EPT == 32 ? 6 : EPT == 40 ? 5 : 1) void predictor_tail_select_kernel(TailParams tp, TopkParams p) {
@@ -492,7 +501,9 @@ __global__ __launch_bounds__(TK_THREADS, EPT <= 16 ? 7 : EPT == 32 ? 6 : EPT == 
   }
   STAMP(9);   // 8 heads per wave: resize + LayerNorm + softmax + store
   const T* base = reinterpret_cast<const T*>(p.src) + n * p.sn + t * p.st;   // = the map just written (slow path re-reads it)
-  select_body<T, EPT, false, FULL, 64>(p, key, 0ull, n, t, row, base);     // H <= 64: sea_predictor_tail_select checks
+  // H <= 64: sea_predictor_tail_select checks.  The z tile and the constants table are dead once every wave has left the head
+  // loop, i.e. from select_body's first barrier on: the candidate list lives there (the launcher sizes the dynamic LDS for both).
+  select_body<T, EPT, false, FULL, 64, true>(p, key, 0ull, n, t, row, base, reinterpret_cast<uint32_t*>(s_z));
 }
 
 // ---- crow = exclusive scan of row_nnz ------------------------------------------------------------
@@ -822,7 +833,8 @@ extern "C" int sea_mask_to_bits(const void* mask, int dtype, int64_t N, int64_t 
 template <typename T>
 static int launch_tail_select(const TailParams& tp, const TopkParams& p, int64_t rows, hipStream_t s) {
   const int ept = ((p.nchunks + TK_THREADS - 1) / TK_THREADS) * 4;
-  const size_t lds = (size_t)(((tp.H + 15) / 16) * 16) * (tp.W4 + 3) * sizeof(float) + (size_t)TAIL_TAB_ROWS * 256 * sizeof(uint32_t);
+  size_t lds = (size_t)(((tp.H + 15) / 16) * 16) * (tp.W4 + 3) * sizeof(float) + (size_t)TAIL_TAB_ROWS * 256 * sizeof(uint32_t);
+  if (lds < 2 * TK_CAND_CAP * sizeof(uint32_t)) lds = 2 * TK_CAND_CAP * sizeof(uint32_t);     // the selection's candidate list re-uses it
   dim3 grid((unsigned)rows), block(TK_THREADS);
 #define SEA_TSEL(EE)                                                                                              \
   do {                                                                                                            \

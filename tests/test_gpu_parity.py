@@ -69,7 +69,7 @@ def test_topk_low_precision_probs_and_ties(ops, dtype):
     assert torch.equal(got2.cpu(), ref2)
 
 
-@pytest.mark.parametrize("levels", [1, 2, 4, 16, 37])
+@pytest.mark.parametrize("levels", [1, 2, 4, 8, 16, 37])
 def test_topk_overfull_threshold_bin(ops, levels):
     """Few distinct values over H*T_m = 8192 pixels: the threshold bin holds thousands of equal keys, which
     forces the multi-pass fallback and the ordered tie scan of the select kernel."""
@@ -78,7 +78,7 @@ def test_topk_overfull_threshold_bin(ops, levels):
     vals = torch.rand(levels, generator=g) + 0.01
     probs = vals[torch.randint(0, levels, (N, H, T, T_M), generator=g)]
     keep = O.keep_counts_module(H, T, T_M, k)
-    keep[40:] = torch.tensor([1, 2, 100, 511, 512, 513, 1025, 5000] * 7)         # also ranks around the list capacity (512; 16 levels: ~512 keys per bin)
+    keep[40:] = torch.tensor([1, 2, 100, 512, 1023, 1024, 1025, 5000] * 7)       # also ranks around the list capacity (1024; 8 / 16 levels: ~1024 / ~512 keys per bin)
     ref = O.grouped_topk_mask(probs, keep)
     got = ops.topk_mask(probs.to(DEV), keep.to(torch.int32).to(DEV), k)
     assert torch.equal(got.cpu(), ref)
