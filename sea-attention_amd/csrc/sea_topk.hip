@@ -212,10 +212,23 @@ __device__ inline long long block_excl_scan64(long long v, long long* s_wave /*[
 // cand: LDS for the candidate list, 2 * TK_CAND_CAP words that nobody else touches from the first barrier in here on; nullptr
 // -> a static array of this function (the fused tail + selection kernel lends the z tile it no longer needs: 8 KB less LDS per
 // workgroup, which is what lets a sixth workgroup onto a CU).
-template <typename T, int EPT, bool FROM_MASK, bool FULL, int HMAX = 1024, bool EXT_CAND = false>
-__device__ __forceinline__ void select_body(const TopkParams& p, uint32_t (&key)[EPT], unsigned long long sel, int n, int t,
-                                            int row, const T* base, uint32_t* cand = nullptr) {
+// K16: the keys are non-negative 16-bit values (a 16-bit map's probabilities: their own bit patterns order like the
+// numbers), TWO per register -- element i is half (i & 1) of key[i >> 1].  Half the key registers, packed 16-bit min / max, and
+// the packed pair is the very word the tail stores to the map.  Same selection, bit for bit: the order of the keys and the
+// tie rule are what the 32-bit keys give.
+template <typename T, int EPT, bool FROM_MASK, bool FULL, int HMAX = 1024, bool EXT_CAND = false, bool K16 = false>
+__device__ __forceinline__ void select_body(const TopkParams& p, uint32_t (&key)[K16 ? EPT / 2 : EPT], unsigned long long sel, int n,
+                                            int t, int row, const T* base, uint32_t* cand = nullptr) {
   constexpr int R = EPT / 4;  // chunk rounds
+  static_assert(!K16 || (sizeof(T) == 2 && !FROM_MASK), "packed keys: 16-bit maps");
+  auto key_at = [&](int i) -> uint32_t {                   // (i is a compile-time constant after unrolling)
+    if constexpr (K16) return (i & 1) ? (key[i >> 1] >> 16) : (key[i >> 1] & 0xffffu);
+    else return key[i];
+  };
+  auto digit_at = [&](int i, int shift, int d) -> int {    // digit of the DESCENDING bin order
+    if constexpr (K16) return (int)__builtin_amdgcn_ubfe(~key[i >> 1], shift + 16 * (i & 1), d);
+    else return (int)__builtin_amdgcn_ubfe(~key[i], shift, d);
+  };
   __shared__ int s_hist[TK_MAX_BINS + 1];          // +1: dump bin for unused register slots
   __shared__ int s_head[HMAX];
   __shared__ int s_wave[TK_WAVES];
@@ -255,12 +268,27 @@ __device__ __forceinline__ void select_body(const TopkParams& p, uint32_t (&key)
     } else {
       // ---- common leading bits of all keys: skipped, so the histogram digit starts where keys differ --------
       uint32_t umin = 0xFFFFFFFFu, umax = 0u;
+      if constexpr (K16) {
+        typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+        us2 mn = us2{0xFFFF, 0xFFFF}, mx = us2{0, 0};
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          if (FULL || j * TK_THREADS + tid < p.nchunks) {
+            const us2 a = __builtin_bit_cast(us2, key[2 * j]), b = __builtin_bit_cast(us2, key[2 * j + 1]);
+            mn = __builtin_elementwise_min(mn, __builtin_elementwise_min(a, b));       // v_pk_min_u16
+            mx = __builtin_elementwise_max(mx, __builtin_elementwise_max(a, b));
+          }
+        }
+        umin = min((uint32_t)mn[0], (uint32_t)mn[1]);
+        umax = max((uint32_t)mx[0], (uint32_t)mx[1]);
+      } else {
 #pragma unroll
       for (int j = 0; j < R; ++j) {
         if (FULL || j * TK_THREADS + tid < p.nchunks) {
           umin = min(umin, min(min(key[4 * j], key[4 * j + 1]), min(key[4 * j + 2], key[4 * j + 3])));
           umax = max(umax, max(max(key[4 * j], key[4 * j + 1]), max(key[4 * j + 2], key[4 * j + 3])));
         }
+      }
       }
       umin = wave_min(umin);
       umax = wave_max(umax);
@@ -279,7 +307,7 @@ __device__ __forceinline__ void select_body(const TopkParams& p, uint32_t (&key)
         const int nb = 1 << d;
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
-          int rb = (int)__builtin_amdgcn_ubfe(~key[i], shift, d);
+          int rb = digit_at(i, shift, d);
           if (!FULL) rb = (((i >> 2) * TK_THREADS + tid) < p.nchunks) ? rb : TK_MAX_BINS;
           atomicAdd(&s_hist[rb], 1);
         }
@@ -313,12 +341,12 @@ __device__ __forceinline__ void select_body(const TopkParams& p, uint32_t (&key)
         // ---- sweep: above the bin -> kept; inside the bin -> candidate list (key, flat index) -----------------
 #pragma unroll
         for (int i = 0; i < EPT; ++i) {
-          const int rb = (int)__builtin_amdgcn_ubfe(~key[i], shift, d);
+          const int rb = digit_at(i, shift, d);
           const bool valid = FULL || (((i >> 2) * TK_THREADS + tid) < p.nchunks);
           if (valid && rb < rb_sel) sel |= 1ull << i;
           if (valid && rb == rb_sel) {
             const int slot = atomicAdd(&s_ncand, 1);
-            s_ckey[slot] = key[i];
+            s_ckey[slot] = key_at(i);
             s_cidx[slot] = (uint32_t)(((i >> 2) * TK_THREADS + tid) * 4 + (i & 3));
           }
         }
@@ -341,6 +369,10 @@ __device__ __forceinline__ void select_body(const TopkParams& p, uint32_t (&key)
           sel |= nibx << (4 * j);
         }
       } else {
+        if constexpr (K16) {           // the fallback builds 32-bit keys from the stored map: hand it the range in that space
+          umin = f2key(Elem<T>::to_f(__builtin_bit_cast(T, (unsigned short)umin)));
+          umax = f2key(Elem<T>::to_f(__builtin_bit_cast(T, (unsigned short)umax)));
+        }
         sel = select_multipass<T>(base, p.sh, p.T_m, p.nchunks, p.M, K, umin, umax, R, s_hist, s_wave, s_bcast);
         for (int i = tid; i < p.H; i += TK_THREADS) s_head[i] = 0;
         __syncthreads();
@@ -452,12 +484,13 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(TopkParams p) {
 // c = 256j + tid of the selection kernel.  So the tail's softmax output, rounded to the map's dtype, is stored for the
 // caller (the module returns the map) AND becomes the selection key in registers: the selection never re-reads the
 // (N,H,T,T_m) map from memory.  Results are bit-identical to the two-launch path (same arithmetic, same rounding).
-// Register caps that buy a wave of occupancy per SIMD (4 waves per workgroup, so one more resident workgroup per CU), measured:
-// H = 32 (EPT 32): 87-90 -> 80 registers (1 spill), 5 -> 6 waves, 499 -> 412 us at OPT-1.3B x 8 (with the candidate list moved
-// into the dead z tile so that six workgroups' LDS fits); 72 registers (18-40 spills) 449-574 us.  H <= 16: 76 -> 72, 6 -> 7 waves, -5 %.  H = 40: 97-108
-// -> 96 (2-4 spills), 4 -> 5 waves, -7 %.
+// Register caps that buy waves of occupancy per SIMD (4 waves per workgroup, so more resident workgroups per CU), measured at
+// OPT-1.3B x 8 (H = 32, EPT 32): as first compiled 87-90 registers, 5 waves, 499 us; capped at 80 (1 spill; the candidate list
+// moved into the dead z tile so that six workgroups' LDS fits) 412 us; with two 16-bit keys per register and the ragged form
+// (78 registers uncapped) capped at 72 (4 spills), 7 waves: 399 us.  64 registers: 40 spills, 574 us.  H <= 16: 76 -> 72,
+// 6 -> 7 waves, -5 %.  H = 40: 97-108 -> 90-96, 4 -> 5 waves, -7 %.
 template <typename T, int EPT, bool FULL>
-__global__ __launch_bounds__(TK_THREADS, EPT <= 16 ? 7 : EPT == 32 ? 6 : EPT == 40 ? 5 : 1) void predictor_tail_select_kernel(TailParams tp, TopkParams p) {
+__global__ __launch_bounds__(TK_THREADS, EPT <= 16 ? 7 : EPT == 32 ? 7 : EPT == 40 ? 5 : 1) void predictor_tail_select_kernel(TailParams tp, TopkParams p) {
   constexpr int R = EPT / 4, E = 4;
   extern __shared__ __attribute__((aligned(16))) float s_z[];     // HP x (W4 + 3)
   const int tid = threadIdx.x;
@@ -476,21 +509,22 @@ __global__ __launch_bounds__(TK_THREADS, EPT <= 16 ? 7 : EPT == 32 ? 6 : EPT == 
   TailRow<T, E> tr;
   tr.load(s_tab, lane);
   STAMP(8);   // z tile (MFMA) + per-pixel constants
-  uint32_t key[EPT];
+  uint32_t key[EPT / 2];                                           // two 16-bit keys per register (select_body, K16)
   const int mine = FULL ? R : max(0, (tp.H - wv + 3) / 4);         // heads wv, wv + 4, ... of this wave (wave-uniform)
   auto batch = [&](auto j0c, auto nbc) {                           // heads 4 (J0 + b) + wv, b < NBC, through one batch
     constexpr int J0 = decltype(j0c)::value, NBC = decltype(nbc)::value;
     float a[NBC][E];
     const int nb = min(NBC, mine - J0);
     if (nb > 0) {
-      tr.heads(tp, lane, nb, [&](int b) { return s_z + (4 * (J0 + b) + wv) * LDZ; },
-               [&](int b) { return (((int64_t)n * tp.H + (4 * (J0 + b) + wv)) * tp.T + t) * tp.T_M; }, a);
+      // T_M == 256 == 64 E here (sea_predictor_tail_select checks): the full-row form, without its ragged twin in the kernel
+      tr.template heads_impl<true>(tp, lane, nb, [&](int b) { return s_z + (4 * (J0 + b) + wv) * LDZ; },
+                                   [&](int b) { return (((int64_t)n * tp.H + (4 * (J0 + b) + wv)) * tp.T + t) * (64 * E); }, a);
     }
 #pragma unroll
-    for (int b = 0; b < NBC; ++b)
-#pragma unroll
-      for (int e = 0; e < E; ++e)   // probabilities are >= +0: the order-preserving key is the bit pattern with the sign bit set
-        key[4 * (J0 + b) + e] = (b < nb) ? (__float_as_uint(Elem<T>::to_f(from_f<T>(a[b][e]))) | 0x80000000u) : 0u;
+    for (int b = 0; b < NBC; ++b) {  // probabilities are >= +0: the 16-bit pattern the map stores orders like the number
+      key[2 * (J0 + b)] = (b < nb) ? pack2<T>(a[b][0], a[b][1]) : 0u;
+      key[2 * (J0 + b) + 1] = (b < nb) ? pack2<T>(a[b][2], a[b][3]) : 0u;
+    }
   };
   static_assert(R <= 16, "two batches of eight heads per wave");
   if constexpr (R <= 8) {
@@ -503,7 +537,7 @@ __global__ __launch_bounds__(TK_THREADS, EPT <= 16 ? 7 : EPT == 32 ? 6 : EPT == 
   const T* base = reinterpret_cast<const T*>(p.src) + n * p.sn + t * p.st;   // = the map just written (slow path re-reads it)
   // H <= 64: sea_predictor_tail_select checks.  The z tile and the constants table are dead once every wave has left the head
   // loop, i.e. from select_body's first barrier on: the candidate list lives there (the launcher sizes the dynamic LDS for both).
-  select_body<T, EPT, false, FULL, 64, true>(p, key, 0ull, n, t, row, base, reinterpret_cast<uint32_t*>(s_z));
+  select_body<T, EPT, false, FULL, 64, true, true>(p, key, 0ull, n, t, row, base, reinterpret_cast<uint32_t*>(s_z));
 }
 
 // ---- crow = exclusive scan of row_nnz ------------------------------------------------------------
@@ -838,9 +872,10 @@ static int launch_tail_select(const TailParams& tp, const TopkParams& p, int64_t
   dim3 grid((unsigned)rows), block(TK_THREADS);
 #define SEA_TSEL(EE)                                                                                              \
   do {                                                                                                            \
-    const bool full = p.nchunks == ((EE) / 4) * TK_THREADS;                                                       \
-    if (full) hipLaunchKernelGGL((predictor_tail_select_kernel<T, EE, true>), grid, block, lds, s, tp, p);        \
-    else hipLaunchKernelGGL((predictor_tail_select_kernel<T, EE, false>), grid, block, lds, s, tp, p);            \
+    /* always the ragged form (FULL = false): with every trip count known the compiler interleaves the eight heads of a wave */ \
+    /* further and needs 88 registers where this form needs 78 (H = 32; spilling them to reach the same occupancy: 453 us   */ \
+    /* against 399 us); what FULL saves is a compare per chunk                                                              */ \
+    hipLaunchKernelGGL((predictor_tail_select_kernel<T, EE, false>), grid, block, lds, s, tp, p);                 \
   } while (0)
   if (ept <= 4) SEA_TSEL(4);
   else if (ept <= 8) SEA_TSEL(8);
