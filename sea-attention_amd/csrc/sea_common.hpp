@@ -87,7 +87,20 @@ __device__ inline float erf_as(float z) {
   const float e = __builtin_amdgcn_exp2f(a * a * -1.4426950408889634f);
   return copysignf(fmaf(-(p * t), e, 1.0f), z);
 }
-__device__ inline float gelu_erf(float x) { return 0.5f * x * (1.0f + erf_as(x * 0.70710678118654752f)); }
+// GELU(x) = 0.5 x (1 + erf(x / sqrt 2)) = h + |h| E,  h = x / 2,  E = erf(|x| / sqrt 2) as in erf_as with the 1 / sqrt 2 folded
+// into its constants: no copysign, no separate 1 + erf, the argument scaling gone -- 16 issue slots instead of 19, in the
+// one-launch MLP that is bound by vector issue (22 k vector instructions per wave, a third of them this function).
+__device__ inline float gelu_erf(float x) {
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f * 0.70710678118654752f, fabsf(x), 1.0f));
+  float p = fmaf(1.061405429f, t, -1.453152027f);
+  p = fmaf(p, t, 1.421413741f);
+  p = fmaf(p, t, -0.284496736f);
+  p = fmaf(p, t, 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(x * x * (-0.5f * 1.4426950408889634f));
+  const float E = fmaf(-(p * t), e, 1.0f);
+  const float h = 0.5f * x;
+  return fmaf(fabsf(h), E, h);
+}
 
 // Two floats -> one dword of packed 16-bit values (low half = a), same rounding as from_f<T>.
 template <typename T> __device__ inline uint32_t pack2(float a, float b) {
