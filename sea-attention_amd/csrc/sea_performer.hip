@@ -554,7 +554,11 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   f4 S[NBT];
 #pragma unroll
   for (int b = 0; b < NBT; ++b) S[b] = f4{0.f, 0.f, 0.f, 0.f};
-  float csum = 0.f;                                        // running column sum of v (cumulative-average output)
+  // running column sums of v (cumulative-average output): in the transposed accumulator layout of (d) a lane owns the four
+  // columns e0 + 4 lg + r of its wave; the 16 lanes of a lane group carry the same four.  Image slot of column r: lane
+  // (lg, li = r) of the wave, i.e. (tid & ~15) + r.
+  float csum[4] = {0.f, 0.f, 0.f, 0.f};
+  const int cslot = (tid & ~15);
   {
     float ks0 = 0.f;
     if (!STATE_ONLY && p.state_in) {                       // increments of pass 1 do not include the incoming state
@@ -564,7 +568,8 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) S[b][r] = cr[(b * 4 + r) * NTH + tid];
       if (tid < FP) ks0 = cr[NBT * 4 * NTH + tid];
-      csum = cr[NBT * 4 * NTH + FP + tid];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) csum[r] = cr[NBT * 4 * NTH + FP + cslot + r];
     }
     if (!STATE_ONLY) {
       for (int s2 = 0; s2 < seg; ++s2) {                   // fixed order: bitwise reproducible
@@ -574,7 +579,8 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) S[b][r] += cr[(b * 4 + r) * NTH + tid];
         if (tid < FP) ks0 += cr[NBT * 4 * NTH + tid];
-        csum += cr[NBT * 4 * NTH + FP + tid];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) csum[r] += cr[NBT * 4 * NTH + FP + cslot + r];
       }
     }
     if (tid < FP) sKsum[tid] = ks0;
@@ -650,7 +656,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) cw[(b * 4 + r) * NTH + tid] = S[b][r];
     if (tid < FP) cw[NBT * 4 * NTH + tid] = sKsum[tid];
-    cw[NBT * 4 * NTH + FP + tid] = csum;
+    cw[NBT * 4 * NTH + FP + tid] = li == 0 ? csum[0] : li == 1 ? csum[1] : li == 2 ? csum[2] : li == 3 ? csum[3] : 0.f;
   };
 
   for (int t0 = t_begin; t0 < t_end; t0 += C) {
@@ -826,8 +832,9 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
         if (want_avg && jb >= EB / 2) {                    // column total of the chunk = the last row's prefix
           f4 cum = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int ks = 0; ks <= (RB - 1) / 2; ++ks) cum = S16<T>::mfma(tril[RB - 1][ks], vf[ks], cum);
-          csum += __shfl(cum[3], 48 + li);
+          for (int ks = 0; ks <= (RB - 1) / 2; ++ks) cum = S16<T>::mfma(vf[ks], tril[RB - 1][ks], cum);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) csum[r] += __shfl(cum[r], (lane & 48) | 15);
         }
       } else {
       f4 o[RB];
@@ -840,8 +847,8 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
         for (int ks = 0; ks <= ib / 2; ++ks) {
           const uint4 ah = *reinterpret_cast<const uint4*>(sAh + (ib * 16 + li) * LDA + ks * 32 + lg * 8);
           const uint4 al = *reinterpret_cast<const uint4*>(sAl + (ib * 16 + li) * LDA + ks * 32 + lg * 8);
-          o[ib] = S16<T>::mfma(ah, vf[ks], o[ib]);
-          o[ib] = S16<T>::mfma(al, vf[ks], o[ib]);
+          o[ib] = S16<T>::mfma(vf[ks], ah, o[ib]);
+          o[ib] = S16<T>::mfma(vf[ks], al, o[ib]);
         }
       }
       // phi(Q) S: the state tiles, split, are the B operand; k-step kk pairs feature blocks 2kk and 2kk+1
@@ -859,19 +866,24 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
         for (int ib = 0; ib < RB; ++ib) {
           const uint4 ah = *reinterpret_cast<const uint4*>(sQh + (ib * 16 + li) * LDQ2 + kk * 32 + lg * 8);
           const uint4 al = *reinterpret_cast<const uint4*>(sQl + (ib * 16 + li) * LDQ2 + kk * 32 + lg * 8);
-          o[ib] = S16<T>::mfma(ah, bh, o[ib]);
-          o[ib] = S16<T>::mfma(ah, bl, o[ib]);
-          o[ib] = S16<T>::mfma(al, bh, o[ib]);
+          o[ib] = S16<T>::mfma(bh, ah, o[ib]);
+          o[ib] = S16<T>::mfma(bl, ah, o[ib]);
+          o[ib] = S16<T>::mfma(bh, al, o[ib]);
         }
       }
-      const int col = e0 + li;
+      // Every product above has its operands SWAPPED (O^T = V^T A^T + S^T phi(Q)^T; the A and B fragment layouts are mirror
+      // images, so the same registers serve): the accumulator of query block ib then holds, per lane, row ib*16 + li and the
+      // FOUR CONSECUTIVE COLUMNS e0 + 4 lg + r -- one 8-byte LDS store and one denominator read per block instead of four
+      // 2-byte stores (two lanes per bank word) and four reads.
+      const int col = e0 + 4 * lg;
 #pragma unroll
       for (int ib = 0; ib < RB; ++ib) {
+        const int row = ib * 16 + li;
+        const float dn = sDen[row];
+        unsigned short ob[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = ib * 16 + lg * 4 + r;
-          sO[row * LDO + col] = S16<T>::bits(o[ib][r] * sDen[row]);
-        }
+        for (int r = 0; r < 4; ++r) ob[r] = S16<T>::bits(o[ib][r] * dn);
+        *reinterpret_cast<uint2*>(sO + row * LDO + col) = pack4(ob);
       }
       if (want_avg && jb >= EB / 2) {                      // wave-uniform: this wave's 16 columns are v features
         f4 cum[RB];
@@ -879,17 +891,22 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
         for (int ib = 0; ib < RB; ++ib) {
           cum[ib] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int ks = 0; ks <= ib / 2; ++ks) cum[ib] = S16<T>::mfma(tril[ib][ks], vf[ks], cum[ib]);
+          for (int ks = 0; ks <= ib / 2; ++ks) cum[ib] = S16<T>::mfma(vf[ks], tril[ib][ks], cum[ib]);
         }
         const int gcol = col - D;
 #pragma unroll
-        for (int ib = 0; ib < RB; ++ib)
+        for (int ib = 0; ib < RB; ++ib) {
+          const int row = ib * 16 + li;
+          const float ri = sRinv[row];
+          unsigned short gb4[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = ib * 16 + lg * 4 + r;
-            sAvg[row * LDG + gcol] = S16<T>::bits((cum[ib][r] + csum) * sRinv[row]);
-          }
-        if (upd) csum += __shfl(cum[RB - 1][3], 48 + li);  // column total of the chunk = its last row's prefix
+          for (int r = 0; r < 4; ++r) gb4[r] = S16<T>::bits((cum[ib][r] + csum[r]) * ri);
+          *reinterpret_cast<uint2*>(sAvg + row * LDG + gcol) = pack4(gb4);
+        }
+        if (upd) {                                         // column totals of the chunk = its last row's prefix (lane li = 15)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) csum[r] += __shfl(cum[RB - 1][r], (lane & 48) | 15);
+        }
       }
       }
       // (e) S[f][e] += sum_s phi(k_s)[f] V[s][e]: A operand = phi(K)^T by transposing reads of the row-major images
@@ -919,7 +936,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) cw[(b * 4 + r) * NTH + tid] = S[b][r];
     if (tid < FP) cw[NBT * 4 * NTH + tid] = sKsum[tid];
-    cw[NBT * 4 * NTH + FP + tid] = csum;
+    cw[NBT * 4 * NTH + FP + tid] = li == 0 ? csum[0] : li == 1 ? csum[1] : li == 2 ? csum[2] : li == 3 ? csum[3] : 0.f;
   } else {
     const int t0l = t_begin + ((t_end - t_begin - 1) / C) * C;
     flush_out(t0l, t_end - t0l);
