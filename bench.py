@@ -302,7 +302,8 @@ class LayerBench:
         cands = ["gather"] + (["auto", "tile"] if self.tile_supported() else [])
         rep = {}
         for rnd in range(2):                                   # two interleaved rounds, the better of each candidate: whoever
-            for c in cands:                                    # is measured first pays the process's one-time costs
+            for c in (cands if rnd == 0 else cands[::-1]):     # is measured first pays the process's one-time costs, and a
+                # candidate measured right after another one's capture inherits its cache state: second round in reverse order
                 if not self.capture(c, with_process_group):
                     return "auto" if self.tile_supported() else "gather", {"requested": "ab", "graph": False}
                 self.timed(2)
@@ -313,7 +314,7 @@ class LayerBench:
         best = min(rep, key=lambda c_: rep[c_]["ms_per_step"])
         self.capture(best, with_process_group)
         return best, {"requested": "ab", "graph": True, "candidates": rep, "chosen": best,
-                      "note": f"2 x {steps} graph-replayed steps per candidate (interleaved, the better round counts) on the "
+                      "note": f"2 x {steps} graph-replayed steps per candidate (two rounds, the second in reverse order; the better round counts) on the "
                               "layer's own selection, before the timed region"}
 
     # -- roofline of the attention launch -----------------------------------------------------------------------------------
