@@ -502,17 +502,15 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   unsigned short* sQ = sW + (D / 8) * NBP * 8;                      // [D/8][C][8]
   unsigned short* sK = sQ + (D / 8) * C * 8;                        // [D/8][C][8]
   unsigned short* sV = sK + (D / 8) * C * 8;                        // [C][E] 256-byte rows, chunk-swizzled
-  unsigned short* sQh = sV + C * E;                                 // [C][LDQ2]
-  unsigned short* sQl = sQh + C * LDQ2;
+  unsigned short* sQh = sV + C * E;                                 // [2][ [C][LDQ2] x 2, [C][LDK2] x 2 ]: the phi images of two
+  unsigned short* sQl = sQh + C * LDQ2;                             //   chunks in flight (set stride PHI below)
   unsigned short* sKh = sQl + C * LDQ2;                             // [C][LDK2]
   unsigned short* sKl = sKh + C * LDK2;
-  unsigned short* sAh = sKl + C * LDK2;                             // [C][LDA]
+  // two sets where they fit (FP = 64: 152 KB in all); with FP = 96 one set, and (b) of the next chunk waits for a fourth barrier
+  constexpr int NSET = (FP == 64) ? 2 : 1;
+  unsigned short* sAh = sKl + C * LDK2 + (NSET - 1) * (2 * C * LDQ2 + 2 * C * LDK2);   // [C][LDA]   (behind the last set)
   unsigned short* sAl = sAh + C * LDA;
-  constexpr int LDO = E + 8;
-  unsigned short* sO = sAl + C * LDA;                               // [C][LDO]  the chunk's result rows, flushed one chunk later
-  constexpr int LDG = D + 8;
-  unsigned short* sAvg = sO + C * LDO;                              // [C][LDG]  cumulative-average rows (optional output)
-  float* sKsum = reinterpret_cast<float*>(sAvg + C * LDG);          // [FP]
+  float* sKsum = reinterpret_cast<float*>(sAl + C * LDA);           // [FP]
   float* sDen = sKsum + FP;                                         // [C]
   float* sDenP = sDen + C;                                          // [C][DSL]
   float* sKsP = sDenP + C * DSL;                                    // [NW][FP]   per-wave k-sum increments
@@ -546,7 +544,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
     sW[i] = f < p.nb ? S16<T>::bits(p.W[f * D + kc * 8 + j]) : (unsigned short)0;
   }
   // phi and A images: padded features / upper-triangular tiles are written once (zero) and never again
-  for (int i = tid; i < 2 * C * LDQ2 + 2 * C * LDK2 + 2 * C * LDA; i += NTH) sQh[i] = 0;
+  for (int i = tid; i < NSET * (2 * C * LDQ2 + 2 * C * LDK2) + 2 * C * LDA; i += NTH) sQh[i] = 0;
   for (int i = tid; i < C * DSL; i += NTH) sDenP[i] = 0.f;   // slots of key blocks above the diagonal stay zero
 
   // carry image of one (n, h, segment): per-thread state registers, the k-sum, the per-thread column sum of v
@@ -602,33 +600,23 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   T* gb = reinterpret_cast<T*>(p.avg) + (want_avg ? (int64_t)nh * p.T * D - (int64_t)lead * D : 0);
   const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(gb, 0, want_avg ? (int)((int64_t)TL * D * 2) : 0, 0x00020000);
   bu4 pq, pk, pv, pp;
-  auto issue_loads = [&](int t0n) {
+  auto issue_qk = [&](int t0n) {
     const int t = t0n + sr;
     const bool ok = t < t_end;
     pq = __builtin_amdgcn_raw_buffer_load_b128(rq, (ok && !STATE_ONLY && t >= lead) ? (int)((t * p.qs[2] + sc * 8) * 2) : (int)OOB, 0, 0);
     pk = __builtin_amdgcn_raw_buffer_load_b128(rk, ok ? (int)((t * p.ks[2] + sc * 8) * 2) : (int)OOB, 0, 0);
+  };
+  auto issue_v = [&](int t0n) {
+    const int t = t0n + sr;
+    const bool ok = t < t_end;
     pv = __builtin_amdgcn_raw_buffer_load_b128(rv, ok ? (int)((t * p.vs[2] + sc * 8) * 2) : (int)OOB, 0, 0);
     pp = __builtin_amdgcn_raw_buffer_load_b128(rp, ok ? (int)((t * p.pos_stride + sc * 8) * 2) : (int)OOB, 0, 0);
   };
 #ifdef SEA_STAMP
   unsigned long long _tprev = __builtin_amdgcn_s_memtime();
 #endif
-  issue_loads(t_begin);
-  // the result tile of a chunk leaves LDS as 16-byte row pieces at the START of the next chunk, i.e. before that
-  // chunk's prefetch loads are issued: a wait for those loads never has younger stores in front of it
-  auto flush_out = [&](int t0p, int rowsp) {
-#pragma unroll
-    for (int i = tid; i < C * (E / 8); i += NTH) {
-      const int row = i / (E / 8), ch = i - row * (E / 8);
-      const bu4 v = *reinterpret_cast<const bu4*>(sO + row * LDO + ch * 8);
-      __builtin_amdgcn_raw_buffer_store_b128(v, ro, (row < rowsp && t0p + row >= lead) ? ((t0p + row) * (3 * D) + ch * 8) * 2 : (int)OOB, 0, 0);
-    }
-    if (want_avg) {                                        // C * D / 8 = 512 pieces: one per thread
-      const int row = tid / (D / 8), ch = tid - row * (D / 8);
-      const bu4 v = *reinterpret_cast<const bu4*>(sAvg + row * LDG + ch * 8);
-      __builtin_amdgcn_raw_buffer_store_b128(v, rg, (row < rowsp && t0p + row >= lead) ? ((t0p + row) * D + ch * 8) * 2 : (int)OOB, 0, 0);
-    }
-  };
+  issue_qk(t_begin);
+  issue_v(t_begin);
   // swizzled chunk position inside a 256-byte row of the V image (conflict-free transposing reads)
   auto vchunk = [](int row, int ch) { return ch ^ (((row & 3) << 2) | ((row >> 2) & 3)); };
 
@@ -659,26 +647,35 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
     cw[NBT * 4 * NTH + FP + tid] = li == 0 ? csum[0] : li == 1 ? csum[1] : li == 2 ? csum[2] : li == 3 ? csum[3] : 0.f;
   };
 
-  for (int t0 = t_begin; t0 < t_end; t0 += C) {
-    const int rows = min(C, t_end - t0);
-    // aligned step, open chunk (always the call's last): its rows produce output but do NOT enter the state -- S, the k-sum
-    // and the column sums stay the state AT THE BOUNDARY, which is the image the next call continues from (it walks this
-    // chunk's rows again).  Block-uniform.
-    const bool upd = !(p.aligned && rows < C);
-    // ---- (a) staging ---------------------------------------------------------------------------------
-    if (!STATE_ONLY) __builtin_amdgcn_raw_buffer_store_b128(pv, ro, (sr < rows && t0 + sr >= lead) ? ((t0 + sr) * (3 * D) + 2 * D + sc * 8) * 2 : (int)OOB, 0, 0);
+  // ---- the chunk walk, software-pipelined over THREE barriers per chunk (the first version ran a chunk's five phases one after
+  // the other behind five barriers; at two waves per SIMD every phase is a dependent chain -- LDS read -> MFMA -> vector ->
+  // LDS write -- that nothing else covers: ablation builds put (b) at 28 %, (c) 12 %, (d) 31 %, (e) 14 %, the flush 8 % of the
+  // kernel, adding up).  Iteration j:
+  //   P1  (d_j)(e_j): output products and the state update of chunk j   +   (b_{j+1}): feature maps of the NEXT chunk, into the
+  //       other phi image;
+  //   P2  (c_{j+1}): A tiles and partials of chunk j+1;  [pos | v] of chunk j+1 and q, k of chunk j+2 go from the prefetch
+  //       registers to LDS (their old images were last read in P1), the loads of chunks j+2 / j+3 are issued;
+  //   P3  denominators, 1 / row index and the k-sum of chunk j+1.
+  // Results leave straight from the accumulators (8-byte pieces: phase (d) holds four consecutive columns of a row per lane).
+  auto rows_of = [&](int t0) { return min(C, t_end - t0); };
+  // aligned step, open chunk (always the call's last): its rows produce output but do NOT enter the state -- S, the k-sum
+  // and the column sums stay the state AT THE BOUNDARY, which is the image the next call continues from (it walks this
+  // chunk's rows again).  Block-uniform.
+  auto upd_of = [&](int t0) { return !(p.aligned && rows_of(t0) < C); };
+  auto stage_qk = [&]() {
     // row slot XOR 2 * chunk: the 16 lanes of a b128 store (2 rows x 8 chunks; chunk images are 1 KB = 0 mod 64 banks apart)
-    // land in 16 different 4-bank groups instead of 2 (8-way conflicts); the reads below permute inside their 16-row runs
+    // land in 16 different 4-bank groups instead of 2 (8-way conflicts); the reads of (b) permute inside their 16-row runs
     *reinterpret_cast<bu4*>(sQ + (sc * C + (sr ^ (2 * sc))) * 8) = pq;
     *reinterpret_cast<bu4*>(sK + (sc * C + (sr ^ (2 * sc))) * 8) = pk;
+  };
+  auto stage_v = [&](int t0) {                               // chunk t0's [pos | v] rows; v also is the third block of the output
+    const int rows = rows_of(t0);
+    if (!STATE_ONLY) __builtin_amdgcn_raw_buffer_store_b128(pv, ro, (sr < rows && t0 + sr >= lead) ? ((t0 + sr) * (3 * D) + 2 * D + sc * 8) * 2 : (int)OOB, 0, 0);
     *reinterpret_cast<bu4*>(sV + sr * E + vchunk(sr, sc) * 8) = pp;
     *reinterpret_cast<bu4*>(sV + sr * E + vchunk(sr, D / 8 + sc) * 8) = pv;
-    if (!STATE_ONLY && t0 > t_begin) flush_out(t0 - C, C);                     // (block-uniform)
-    issue_loads(t0 + C);                                                      // rows beyond T come back as zeros
-    __syncthreads();
-    PSTAMP(0);   // (a) staging
-
-    // ---- (b) feature maps, transposed: X^T[f][t] = sum_d W[f][d] x[t][d]; wave = (Q | K, row block) ----------
+  };
+  // ---- (b) feature maps, transposed: X^T[f][t] = sum_d W[f][d] x[t][d]; wave = (Q | K, row block) ----------
+  auto phase_b = [&](int rows, unsigned short* sQh, unsigned short* sQl, unsigned short* sKh, unsigned short* sKl) {
     if (!STATE_ONLY || wv >= RB) {                           // the state-only pass needs phi(K) alone (wave-uniform)
       const int which = wv / RB, rb = wv - which * RB;
       const unsigned short* src = which ? sK : sQ;
@@ -715,10 +712,9 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
         *reinterpret_cast<uint2*>(dl + row * ldx + pos) = pack4(ll);
       }
     }
-    __syncthreads();
-    PSTAMP(1);   // (b) feature maps
-
-    // ---- (c) A^T tiles (lower triangle), denominator and k-sum partials ------------------------------------
+  };
+  // ---- (c) A^T tiles (lower triangle), denominator and k-sum partials ------------------------------------
+  auto phase_c = [&](const unsigned short* sQh, const unsigned short* sQl, const unsigned short* sKh, const unsigned short* sKl) {
     if constexpr (!STATE_ONLY)
     for (int tile = wv; tile < RB * (RB + 1) / 2; tile += NW) {
       int ib = 0, rem = tile;
@@ -796,7 +792,8 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
       }
       if (lane < FG) *reinterpret_cast<float4*>(sKsP + wv * FP + fc * 4) = make_float4(k4[0], k4[1], k4[2], k4[3]);
     }
-    __syncthreads();
+  };
+  auto phase_c2 = [&](int t0, bool upd) {
     if (tid < C) {
       float s = 0.f;
 #pragma unroll
@@ -810,10 +807,10 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
       for (int i = 0; i < NW; ++i) s += sKsP[i * FP + f];         // fixed order: bitwise reproducible
       if (upd) sKsum[f] = s;
     }
-    __syncthreads();
-    PSTAMP(2);   // (c) A + denominators + k-sum
-
-    // ---- (d) O = A V + phi(Q) S over this wave's 16 columns; (e) S += phi(K)^T V ------------------------------
+  };
+  // ---- (d) O = A V + phi(Q) S over this wave's 16 columns; (e) S += phi(K)^T V ------------------------------
+  auto phase_de = [&](int t0, int rows, bool upd, const unsigned short* sQh, const unsigned short* sQl, const unsigned short* sKh,
+                      const unsigned short* sKl) {
     {
       const int jb = wv, e0 = jb * 16;
       // V fragments (B operand, k = chunk row): rows 32ks + 8lg + {0..3 | 4..7}, columns e0 .. e0+15
@@ -883,7 +880,9 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
         unsigned short ob[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) ob[r] = S16<T>::bits(o[ib][r] * dn);
-        *reinterpret_cast<uint2*>(sO + row * LDO + col) = pack4(ob);
+        const uint2 w2 = pack4(ob);
+        typedef __attribute__((ext_vector_type(2))) unsigned int bu2;
+        __builtin_amdgcn_raw_buffer_store_b64(bu2{w2.x, w2.y}, ro, (row < rows && t0 + row >= lead) ? ((t0 + row) * (3 * D) + col) * 2 : (int)OOB, 0, 0);
       }
       if (want_avg && jb >= EB / 2) {                      // wave-uniform: this wave's 16 columns are v features
         f4 cum[RB];
@@ -901,7 +900,9 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
           unsigned short gb4[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) gb4[r] = S16<T>::bits((cum[ib][r] + csum[r]) * ri);
-          *reinterpret_cast<uint2*>(sAvg + row * LDG + gcol) = pack4(gb4);
+          const uint2 w2 = pack4(gb4);
+          typedef __attribute__((ext_vector_type(2))) unsigned int bu2;
+          __builtin_amdgcn_raw_buffer_store_b64(bu2{w2.x, w2.y}, rg, (row < rows && t0 + row >= lead) ? ((t0 + row) * D + gcol) * 2 : (int)OOB, 0, 0);
         }
         if (upd) {                                         // column totals of the chunk = its last row's prefix (lane li = 15)
 #pragma unroll
@@ -926,8 +927,51 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
         }
       }
     }
+  };
+  constexpr int PHI = 2 * C * LDQ2 + 2 * C * LDK2;          // elements of one phi image set (Qh, Ql, Kh, Kl)
+  auto run_b = [&](int t0, int buf) { phase_b(rows_of(t0), sQh + buf * PHI, sQl + buf * PHI, sKh + buf * PHI, sKl + buf * PHI); };
+  auto run_c = [&](int buf) { phase_c(sQh + buf * PHI, sQl + buf * PHI, sKh + buf * PHI, sKl + buf * PHI); };
+  auto run_de = [&](int t0, int buf) {
+    phase_de(t0, rows_of(t0), upd_of(t0), sQh + buf * PHI, sQl + buf * PHI, sKh + buf * PHI, sKl + buf * PHI);
+  };
+  if (t_begin < t_end) {
+    // prologue: chunk 0 through (b), (c), (c'); chunk 1's q, k staged; loads of chunk 1 ([pos | v]) and chunk 2 (q, k) in flight
+    stage_qk();
+    stage_v(t_begin);
+    issue_qk(t_begin + C);
+    issue_v(t_begin + C);
     __syncthreads();
-    PSTAMP(3);   // (d)+(e)
+    run_b(t_begin, 0);
+    __syncthreads();
+    run_c(0);
+    stage_qk();
+    issue_qk(t_begin + 2 * C);
+    __syncthreads();
+    phase_c2(t_begin, upd_of(t_begin));
+    __syncthreads();
+    int buf = 0;
+    for (int t0 = t_begin; t0 < t_end; t0 += C, buf ^= (NSET - 1)) {
+      const bool has_next = t0 + C < t_end;                  // block-uniform
+      // (measured and not taken: the two waves of a SIMD running P1's two parts in opposite order, 328 vs 306 us; (b) cut in two
+      // and placed between the parts of (d), 320 vs 306 us -- DESIGN.md section 9)
+      run_de(t0, buf);
+      if constexpr (NSET == 1) __syncthreads();              // one image set: chunk j's must have been read
+      if (has_next) run_b(t0 + C, buf ^ (NSET - 1));
+      __syncthreads();
+      PSTAMP(0);
+      if (has_next) {
+        run_c(buf ^ (NSET - 1));
+        stage_v(t0 + C);
+        issue_v(t0 + 2 * C);
+        stage_qk();
+        issue_qk(t0 + 3 * C);
+      }
+      __syncthreads();
+      PSTAMP(1);
+      if (has_next) phase_c2(t0 + C, upd_of(t0 + C));
+      __syncthreads();
+      PSTAMP(2);
+    }
   }
   if constexpr (STATE_ONLY) {
     float* cw = p.carry + ((int64_t)nh * (p.nseg - 1) + seg) * CARRY;
@@ -938,8 +982,6 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
     if (tid < FP) cw[NBT * 4 * NTH + tid] = sKsum[tid];
     cw[NBT * 4 * NTH + FP + tid] = li == 0 ? csum[0] : li == 1 ? csum[1] : li == 2 ? csum[2] : li == 3 ? csum[3] : 0.f;
   } else {
-    const int t0l = t_begin + ((t_end - t_begin - 1) / C) * C;
-    flush_out(t0l, t_end - t0l);
     // the block that walked the last rows holds the final state (aligned step: the state at the last chunk boundary)
     if (p.state_out && seg == p.nseg - 1) write_state();
   }
@@ -1451,7 +1493,8 @@ constexpr int64_t perf_carry_floats() { return (int64_t)(((2 * D / 16) + NW - 1)
 template <typename T, int NBT>
 static int launch_perf_bf16(const PerfParams& p, hipStream_t s) {
   constexpr int D = 64, C = 64, NTH = 512, E = 2 * D, NBP = NBT * 16, FP = ((NBT + 1) / 2) * 32, LDQ2 = FP + 16, LDK2 = (FP == 64) ? 96 : FP + 8, LDA = C + 16;
-  constexpr size_t lds = 2 * ((D / 8) * NBP * 8 + 2 * (D / 8) * C * 8 + C * E + 2 * C * LDQ2 + 2 * C * LDK2 + 2 * C * LDA + C * (E + 8) + C * (D + 8)) +
+  constexpr int NSET = (FP == 64) ? 2 : 1;                   // phi image sets (performer_bf16_kernel)
+  constexpr size_t lds = 2 * ((D / 8) * NBP * 8 + 2 * (D / 8) * C * 8 + C * E + NSET * (2 * C * LDQ2 + 2 * C * LDK2) + 2 * C * LDA) +
                          sizeof(float) * (FP + C + C * (C / 16 + NTH / C) + 8 * FP + C);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool configured = false;
