@@ -205,7 +205,11 @@ int sea_sparse_attention_ex(const void* q, const void* k, const void* v, int dty
  *   crow      from sea_csr_row_scan over that launch's row_nnz; head_off from the same launch;
  *   col       (N, col_stride_n) int32: OUTPUT -- after the launch it holds exactly what sea_csr_emit would have written.
  * Other arguments as sea_sparse_attention_ex (gather path; probs_out allowed).  Rows of 4 lanes and rows wider than 16
- * lanes are SEA_EUNSUPPORTED: run sea_csr_emit + sea_sparse_attention_ex there. */
+ * lanes are SEA_EUNSUPPORTED: run sea_csr_emit + sea_sparse_attention_ex there.
+ * sea_attention_few_rows(): for a launch of at most that many rows (N * H * T_dst: a decoding step) sea_csr_emit +
+ * sea_sparse_attention_ex is the faster pair -- with T_dst <= 8 that kernel's idle lane groups first touch every K / V row
+ * the step will gather, so the rows' dependent walks find them in cache (same arithmetic, bit for bit). */
+int64_t sea_attention_few_rows(void);
 int sea_sparse_attention_fused(const void* q, const void* k, const void* v, int dtype,
                                int64_t N, int64_t H, int64_t T_dst, int64_t T_src, int64_t D,
                                const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,

@@ -21,10 +21,11 @@ ap.add_argument("--batch", type=int, default=8)
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--maps", default="layer,random,structured")
 ap.add_argument("--variants", default="gather,tile:1:0,plan")
+ap.add_argument("--T", type=int, default=0, help="override the workload's sequence length (e.g. 512: only the dense low rows)")
 a = ap.parse_args()
 dev = torch.device("cuda:0")
 w = WORKLOADS[a.workload]
-H, d, T, T_M, k = w["H"], w["d"], w["T"], w["T_M"], w["k"]
+H, d, T, T_M, k = w["H"], w["d"], a.T or w["T"], w["T_M"], w["k"]
 NB = a.batch
 dtype = torch.bfloat16
 torch.manual_seed(42)

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "sea_performer_causal": ([ptr, ptr, ptr, ptr, c_int, ptr, i64, i64, i64, i64, i64, _i64p, _i64p, _i64p, i64, ptr, ptr, ptr], c_int),
     "sea_performer_state_bytes": ([i64, i64, i64, i64, c_int], i64),
     "sea_performer_chunk_rows": ([i64, i64, c_int], i64),
+    "sea_attention_few_rows": ([], i64),
     "sea_performer_causal_step": ([ptr, ptr, ptr, ptr, c_int, ptr, i64, i64, i64, i64, i64, _i64p, _i64p, _i64p, i64, ptr, ptr,
                                    ptr, ptr, i64, i64, i64, ptr, i64, ptr], c_int),
     "sea_performer_causal_step_at": ([ptr, ptr, ptr, ptr, c_int, ptr, i64, i64, i64, i64, i64, _i64p, _i64p, _i64p, i64, ptr, ptr,

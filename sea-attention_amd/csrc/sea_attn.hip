@@ -278,6 +278,8 @@ __device__ inline int entry_column(const AttnParams& p, const int32_t* col, int 
   return col[ec];
 }
 
+constexpr int SEA_ATTN_WARM_ROWS = 8;            // T_dst up to which the idle lane groups pre-touch the rows' K / V lines
+
 // ---- variant B: one LPR-lane GROUP per query row (64/LPR rows per wave) -----------------------------------
 // Each group walks its own row's entries, one key per instruction step, U keys in flight, with its own online
 // softmax; nothing is merged across groups.  A wave therefore has 64/LPR independent
@@ -326,6 +328,32 @@ __global__ __launch_bounds__(NWB * 64, (FUSE && sizeof(T) == 2 && !WP) ? 8 : 1) 
   int lbase = 0;
   bool fits = false;
   if constexpr (FUSE) fused_expand<LPR, RPB>(p, n, h, tt, rowok, gi, sub, beg, end, hcol, s_keys, &lbase, &fits);
+
+  // ---- a decoding step: T_dst of one or a few rows, so all but a few of the block's lane groups have no row -- and the one
+  // that has walks its ~k entries down ONE dependent chain (column indices -> four K / V rows -> the next four ...: three
+  // memory round trips per 8 entries, 40 us for an OPT-1.3B x 8 step whose K / V lines come cold from HBM).  The idle groups
+  // first touch every K / V row the block's rows will gather, all at once: the walk below then finds them in this CU's L1 /
+  // the L2.  Arithmetic untouched: the step stays bitwise the stateless forward.
+  if constexpr (!FUSE) {
+    if (p.T_dst <= SEA_ATTN_WARM_ROWS) {                   // (grid-uniform)
+      constexpr int NG = NWB * RPW;
+      const int g = (int)threadIdx.x / LPR;
+      uint32_t sink = 0;
+      for (int r = 0; r < p.T_dst; ++r) {
+        const int rb2 = p.crow[(int64_t)n * (p.T_dst + 1) + r];
+        const int32_t* ho2 = p.head_off + ((int64_t)n * p.T_dst + r) * (p.H + 1);
+        const int b2 = rb2 + ho2[h], e2 = rb2 + ho2[h + 1];
+        for (int e = b2 + g; e < e2; e += NG) {
+          const uint32_t key_c = (uint32_t)(col[e] - hcol);
+          const uint4 a = *reinterpret_cast<const uint4*>(kbase + (__umul24(key_c, kst) + lane_off));
+          const uint4 b = *reinterpret_cast<const uint4*>(vbase + (__umul24(key_c, vst) + lane_off));
+          sink ^= a.x ^ b.x;
+        }
+      }
+      asm volatile("" ::"v"(sink));                        // the loads must complete; their values are not used
+      __syncthreads();
+    }
+  }
 
   float m = -INFINITY, l = 0.f;
   float acc[VEC];
@@ -686,6 +714,9 @@ static int lanes_per_row(int D, int vec) {
 static bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 static bool strides_ok(const int64_t* s, int vec) { return s[0] % vec == 0 && s[1] % vec == 0 && s[2] % vec == 0; }
 
+// A decoding step (T_dst of a few rows per (n, h)): the fused form has nothing to win there (one row per workgroup), and the
+// plain lane-group kernel warms the row's K / V lines with its idle lane groups first (below).  sea_attention_few_rows().
+constexpr int64_t SEA_ATTN_FEW_ROWS = 2048;
 template <typename T, typename TO, bool WP>
 static int launch_attn_wp(AttnParams p, hipStream_t s) {
   constexpr int VEC = Elem<T>::VEC;
@@ -885,6 +916,8 @@ extern "C" int sea_sparse_attention_ex(const void* q, const void* k, const void*
 // Steps I + J in ONE launch: the gather kernel expands the selection's kept pixels to key columns itself (the emit's
 // arithmetic), writes them to `col` and walks them from LDS.  crow / head_off as for sea_sparse_attention (from
 // sea_csr_row_scan and the selection launch); `col` (N, col_stride_n) is OUTPUT here.
+extern "C" int64_t sea_attention_few_rows(void) { return SEA_ATTN_FEW_ROWS; }
+
 extern "C" int sea_sparse_attention_fused(const void* q, const void* k, const void* v, int dtype, int64_t N, int64_t H,
                                           int64_t T_dst, int64_t T_src, int64_t D, const int64_t* q_strides,
                                           const int64_t* k_strides, const int64_t* v_strides, const int32_t* crow,

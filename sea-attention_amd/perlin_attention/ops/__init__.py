@@ -7,7 +7,7 @@ from .flat_csr import flat_csr_sdbmm
 from .flat_csr import flat_csr_softmax
 from .flat_csr import flat_csr_to_dense
 # fused MI355X entry points (not in the reference)
-from .flat_csr import (FlatCSR, fused_interp_supported, topk_to_csr, topk_mask, sparse_attention, sparse_attention_bytes, attention_plan, plan_blocks, make_plan,
+from .flat_csr import (FlatCSR, fused_interp_supported, attention_few_rows, topk_to_csr, topk_mask, sparse_attention, sparse_attention_bytes, attention_plan, plan_blocks, make_plan,
                        sparse_attention_autograd,
                        keep_table_causal, keep_table_kernel_test, z_capacity, csr_from_selection)
 from .predictor import (split_layernorm, predictor_tail, cumavg, performer_value, performer_supported, performer_avg_supported,

@@ -245,9 +245,23 @@ def topk_mask(probs: torch.Tensor, keep: torch.Tensor, k: int, target_width=None
 _PATHS = {"auto": _lib.SEA_ATTN_AUTO, "gather": _lib.SEA_ATTN_GATHER, "tile": _lib.SEA_ATTN_TILE}
 
 
-def fused_interp_supported(dtype, D: int, T_m: int) -> bool:
+_FEW_ROWS = None
+
+
+def attention_few_rows() -> int:
+    """(n, h, t) rows up to which the attention launch gives every row a whole wave (a decoding step) -- `sea_attention_few_rows`."""
+    global _FEW_ROWS
+    if _FEW_ROWS is None:
+        _FEW_ROWS = int(_lib.load().sea_attention_few_rows())
+    return _FEW_ROWS
+
+
+def fused_interp_supported(dtype, D: int, T_m: int, rows: int = None) -> bool:
     """Shapes `sea_sparse_attention_fused` covers (steps I + J in one launch): rows of 8 or 16 lanes (16-bit d = 64 / 80 / 128,
-    fp32 d = 32 / 64), T_m a multiple of 32."""
+    fp32 d = 32 / 64), T_m a multiple of 32 -- and, when the caller says how many (n, h, t) rows the launch has, more than
+    `attention_few_rows()` of them (a decoding step runs emit + the wave-per-row kernel instead)."""
+    if rows is not None and rows <= attention_few_rows():
+        return False
     vec = 4 if dtype == torch.float32 else 8
     lanes = 1
     while lanes * vec < D:
@@ -375,7 +389,7 @@ def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = 
     # (the tile kernel, a plan that may choose it, rows of 4 lanes / d = 80 / wider than 16 lanes) reads `.col`, which
     # runs the emit launch first
     fused = (csr.col_is_pending and fuse_emit and path != "tile" and not (path == "auto" and plan is not None)
-             and fused_interp_supported(q.dtype, D, csr._pending[0]))
+             and fused_interp_supported(q.dtype, D, csr._pending[0], N * H * T_dst))
     T_src = k.shape[2]
     assert k.shape == (N, H, T_src, D) and v.shape == (N, H, T_src, D)
     assert q.dtype == k.dtype == v.dtype
