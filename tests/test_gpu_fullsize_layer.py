@@ -36,12 +36,14 @@ def _sample_rows(T, seed):
     return torch.tensor(sorted(rows), dtype=torch.long)
 
 
-@pytest.mark.parametrize("sparse_kernel", ["auto", "gather"])
+@pytest.mark.parametrize("sparse_kernel", ["auto", "gather", "auto-fp16"])
 @pytest.mark.parametrize("name,H,d,T", [("opt-1.3b", 32, 64, 4096), ("opt-2.7b", 32, 80, 8192), ("llama-13b", 40, 128, 4096)])
 def test_full_size_layer_against_the_oracle(monkeypatch, name, H, d, T, sparse_kernel):
-    if sparse_kernel == "gather" and name != "opt-1.3b":
-        pytest.skip("the single-kernel twin runs at the headline shape only (time)")
-    N, dtype = 1, torch.bfloat16
+    if sparse_kernel != "auto" and name != "opt-1.3b":
+        pytest.skip("the single-kernel twin and the fp16 twin run at the headline shape only (time)")
+    # fp16: the selection's packed 16-bit keys are the half patterns themselves (select_body K16), another order-preserving map
+    N, dtype = 1, (torch.float16 if sparse_kernel == "auto-fp16" else torch.bfloat16)
+    sparse_kernel = sparse_kernel.split("-")[0]
     S.seed(42)
     pc = PerlinAttentionConfig(k=K, attention_predictor_length=T_M, performer_nb_factor=8, causal=True, k_flatten=True,
                                k_flatten_dim='causal_batch', context_output_method='mix')
