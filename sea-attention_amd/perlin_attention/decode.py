@@ -54,12 +54,15 @@ class DecodeSession:
         assert ops.predictor_tail_select_supported(cs.rows_c8, H, self.T_M), "fused tail + selection shape (T_M = 256, H <= 64)"
         self.image = ps.image.clone()                                        # Performer sums, updated in place
         self.win = cs.rows_c8.clone()                                        # last LB rows of the CNN input
-        self.k_cache = torch.zeros((N, H, capacity, D), dtype=dt, device=dev)
-        self.v_cache = torch.zeros((N, H, capacity, D), dtype=dt, device=dev)
+        # K and V caches are the two halves of ONE tensor and the two position counters two elements of one: a step appends
+        # both new rows with one index_copy_ and advances both counters with one add (a step is a few microseconds per launch)
+        self.kv_cache = torch.zeros((2, N, H, capacity, D), dtype=dt, device=dev)
+        self.k_cache, self.v_cache = self.kv_cache[0], self.kv_cache[1]
         self.k_cache[:, :, :L] = key_prefix
         self.v_cache[:, :, :L] = value_prefix
-        self.seen32 = torch.full((1,), L, dtype=torch.int32, device=dev)      # rows the state has seen
-        self.tsrc32 = torch.full((1,), L + 1, dtype=torch.int32, device=dev)  # keys the new row sees
+        self.ctr32 = torch.tensor([L, L + 1], dtype=torch.int32, device=dev)
+        self.seen32 = self.ctr32[0:1]                                        # rows the state has seen
+        self.tsrc32 = self.ctr32[1:2]                                        # keys the new row sees
         self.idx64 = torch.full((1,), L, dtype=torch.int64, device=dev)       # cache row of the new token
         self.length = L                                                      # host mirror (bounds check only)
         # K_t of every reachable position (attention.py:849-866, the same fp32 expression as the stateless path) and
@@ -71,8 +74,8 @@ class DecodeSession:
         bound = torch.minimum(keep_cpu.to(torch.long) * per_pixel, H * torch.minimum(w, torch.tensor(self.T_M * self.k)))
         self.z_cap = max(int(bound.max().item()), 1)
         self.q_in = torch.zeros((N, H, 1, D), dtype=dt, device=dev)
-        self.k_in = torch.zeros_like(self.q_in)
-        self.v_in = torch.zeros_like(self.q_in)
+        self.kv_in = torch.zeros((2, N, H, 1, D), dtype=dt, device=dev)
+        self.k_in, self.v_in = self.kv_in[0], self.kv_in[1]
         self.ctx = torch.zeros((N, 1, H * D), dtype=at.context_layer_dtype or torch.float32, device=dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.probs = None                                                    # estimated attention probabilities of the last step
@@ -83,8 +86,7 @@ class DecodeSession:
     # the launches of one position; everything position-dependent is read from device memory
     def _launch(self):
         at, H, D, T_M = self.attention, self.H, self.D, self.T_M
-        self.k_cache.index_copy_(2, self.idx64, self.k_in)
-        self.v_cache.index_copy_(2, self.idx64, self.v_in)
+        self.kv_cache.index_copy_(3, self.idx64, self.kv_in)
         # chunk-aligned step: the kernel walks the open Performer chunk again from the caches (which hold the new row already)
         performer_value, avg_rows, _ = ops.performer_step(
             self.q_in, self.k_cache, self.v_cache, at.v_eye_learned_causal[0, 0], at.performer.projection_matrix,
@@ -102,7 +104,7 @@ class DecodeSession:
             conv = body[i].module
             y = ops.causal_conv_c8(y, conv.weight, conv.bias, conv.kernel_size, conv.dilation, conv.padding[1], relu=True)
         conv4 = body[-1].module
-        y_new = y[:, -1:].contiguous()
+        y_new = y[:, -1:]                                                     # (the tail reads the row where it lies)
         self.probs, _, sel = ops.predictor_tail_select(
             y_new, conv4.weight[:, :, 0, 0], conv4.bias, ln2.weight, ln2.bias, up=4, T_m=T_M, keep=self.keep_table,
             k=self.k, T_src=0, is_causal=True, eps=ln2.eps, want_scores=False, t_src_dev=self.tsrc32)
@@ -111,8 +113,7 @@ class DecodeSession:
                              row_scale=row_scale if at.pconfig.partial_attention_scaler else None,
                              avg=avg_rows, mix=avg_scale, out=self.ctx.view(self.N, 1, H, D).permute(0, 2, 1, 3),
                              path="gather")
-        self.seen32 += 1
-        self.tsrc32 += 1
+        self.ctr32 += 1
         self.idx64 += 1
 
     def _capture(self):
@@ -125,7 +126,7 @@ class DecodeSession:
         another layer's `.to()` / `load_state_dict`, or the cache's own size bound -- cannot free memory a replay still
         reads; and it remembers the cache generation: `step()` re-captures when that has moved, because a cleared cache
         means the weights may have been edited and the pinned packs may be stale."""
-        saved = [t.clone() for t in (self.image, self.win, self.k_cache, self.v_cache, self.seen32, self.tsrc32, self.idx64)]
+        saved = [t.clone() for t in (self.image, self.win, self.kv_cache, self.ctr32, self.idx64)]
         with ops.pinned_prep() as pins:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -136,7 +137,7 @@ class DecodeSession:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g), torch.no_grad():
                 self._launch()
-        for dst, src in zip((self.image, self.win, self.k_cache, self.v_cache, self.seen32, self.tsrc32, self.idx64), saved):
+        for dst, src in zip((self.image, self.win, self.kv_cache, self.ctr32, self.idx64), saved):
             dst.copy_(src)
         self.graph = g
         self._pinned = pins
