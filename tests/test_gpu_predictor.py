@@ -358,6 +358,17 @@ def test_predictor_tail_select_bit_identical(ops, dtype, N, H, T, k):
     c2 = ops.csr_from_selection(*sel2, H, T_M, T, k, True, None, keep)
     c3, _ = ops.topk_to_csr(ops.predictor_tail(y0, cw * 0, cb * 0, lw, lb * 0, up=4, T_m=T_M)[0], keep, k, target_width=T)
     assert torch.equal(c2.bits, c3.bits) and torch.equal(c2.crow, c3.crow)
+    # a bump on a flat map: a few distinct levels, the K-th key inside a tie of thousands -- the threshold bin overflows the
+    # candidate list AFTER the histogram pass (keys differ), and the fallback gets its key range from the packed 16-bit keys
+    y1 = torch.zeros_like(y)
+    y1[:, :, :, 5:7, :] = 1.0                                              # (N, T, C/8, W4, 8): two pixel columns lit
+    args1 = (y1, torch.full_like(cw, 0.05), cb * 0, torch.ones_like(lw), lb * 0)   # every head, every flat pixel alike
+    p4, _, sel4 = ops.predictor_tail_select(*args1, up=4, T_m=T_M, keep=keep, k=k, T_src=T)
+    c4 = ops.csr_from_selection(*sel4, H, T_M, T, k, True, None, keep)
+    p5 = ops.predictor_tail(*args1, up=4, T_m=T_M)[0]
+    c5, _ = ops.topk_to_csr(p5, keep, k, target_width=T)
+    assert torch.equal(p4, p5) and p4.float().unique().numel() < 64
+    assert torch.equal(c4.bits, c5.bits) and torch.equal(c4.crow, c5.crow)
 
 
 @pytest.mark.parametrize("D", [64, 80, 128])
