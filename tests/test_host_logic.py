@@ -358,3 +358,20 @@ def test_prep_cache_key_sees_storage_swaps_and_device_tags():
     P.clear_prep_cache()
     P._cached("t", (w,), torch.float32, build)
     assert len(calls) == 4
+
+
+def test_fused_interpolation_is_for_launches_of_many_rows():
+    """`fused_interp_supported`: the head shapes of the fused form, and -- when the caller says how many (n, h, t) rows the
+    launch has -- only above `attention_few_rows()` (a decoding step emits its columns and lets the plain kernel pre-touch its
+    K / V rows; include/sea_hip.h, sea_attention_few_rows).  The library answers without a GPU."""
+    import torch
+    from sea_attention_amd.perlin_attention import ops
+    few = ops.attention_few_rows()
+    assert few >= 256                                                       # at least a batch-8, 32-head decoding step
+    for dt, d in ((torch.bfloat16, 64), (torch.float16, 80), (torch.bfloat16, 128), (torch.float32, 32), (torch.float32, 64)):
+        assert ops.fused_interp_supported(dt, d, 256)
+        assert ops.fused_interp_supported(dt, d, 256, rows=few + 1)
+        assert not ops.fused_interp_supported(dt, d, 256, rows=few)
+    assert not ops.fused_interp_supported(torch.bfloat16, 32, 256)          # rows of 4 lanes
+    assert not ops.fused_interp_supported(torch.float32, 128, 256)          # rows wider than 16 lanes
+    assert not ops.fused_interp_supported(torch.bfloat16, 64, 48)           # T_m not a multiple of 32
