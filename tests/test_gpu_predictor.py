@@ -121,7 +121,8 @@ def test_module_hip_estimator_matches_torch_estimator():
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,H,T,D,nbf", [(1, 2, 256, 64, 8), (2, 3, 200, 64, 8), (1, 2, 130, 80, 8), (1, 2, 96, 128, 8),
                                          (1, 1, 64, 64, 4), (1, 4, 1024, 64, 8), (1, 2, 333, 64, 8), (2, 2, 1000, 128, 8),
-                                         (1, 3, 161, 128, 8), (1, 1, 31, 128, 8), (2, 3, 1000, 80, 8), (1, 2, 95, 80, 6)])
+                                         (1, 3, 161, 128, 8), (1, 1, 31, 128, 8), (2, 3, 1000, 80, 8), (1, 2, 95, 80, 6),
+                                         (1, 2, 300, 64, 4)])      # 66 features at d = 64: one phi image set, several chunks
 def test_performer_value(ops, dtype, N, H, T, D, nbf):
     """Fused Performer kernel vs the torch restatement (perlin_attention/performer.py) evaluated in fp32, and vs
     the naive prefix-sum formula of the published algorithm."""
