@@ -410,7 +410,43 @@ __device__ __forceinline__ void select_body(const TopkParams& p, uint32_t (&key)
   }
   // entries each kept pixel will emit: min(v_end - v_start, max_k), accumulated per head.  Only kept pixels
   // are visited (a row keeps ~K_t << H*T_m of them once t is large).
-  {
+  if constexpr (K16) {
+    // The fused tail + selection (T_m = 256: round j of wave wv IS head 4j + wv, lane l its pixels 4l .. 4l+3): a lane's four
+    // pixel widths are the same for every head, so a head's entries are the widths summed over the kept nibble's bits and
+    // over the wave's lanes -- eight heads per transposing reduction, no loop over kept pixels, no LDS atomics (ablation at
+    // 7 waves per SIMD: the loop below was 50 of the kernel's 406 us).
+    int wpx[4];
+    {
+      float bprev = interp_bound(4 * lane, scale);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float bnext = interp_bound(4 * lane + e + 1, scale);
+        const int w = (int)(bnext - bprev);
+        wpx[e] = w < p.max_k ? w : p.max_k;
+        bprev = bnext;
+      }
+    }
+#pragma unroll
+    for (int j0 = 0; j0 < R; j0 += 8) {
+      float red[8];
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        int sum = 0;
+        if (j0 + b < R) {
+          const uint32_t nib = (uint32_t)(sel >> (4 * (j0 + b))) & 0xFu;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) sum += (nib >> e) & 1u ? wpx[e] : 0;
+        }
+        red[b] = (float)sum;                                 // <= 64 lanes x 4 pixels x max_k: exact
+      }
+      const float x = wave_reduce8(red, [](float u, float v) { return u + v; });
+#pragma unroll
+      for (int b = 0; b < 8; ++b) {
+        const int h = 4 * (j0 + b) + wv;
+        if (j0 + b < R && h < p.H && lane == 0) s_head[h] = (int)reduce8_get(x, b);
+      }
+    }
+  } else {
     unsigned long long m = sel;
     while (m) {
       const int i = __ffsll((long long)m) - 1;
