@@ -293,9 +293,15 @@ int sea_predictor_tail(const void* y, int dtype, int64_t N, int64_t C, int64_t H
 
 /* Predictor tail + grouped top-k selection in one launch: sea_predictor_tail (MFMA variant, 16-bit
  * channels-last / C8 input) followed by sea_topk_select on the probability map it produces, with the map's values
- * handed over in registers -- the (N,H,T,T_m) map is still written (the module returns it) but never re-read.
- * Bit-identical to the two separate calls.  Requires T_m = 256 (W4 = 64, up = 4), H % 4 == 0, H <= 64.
- * Arguments as in sea_predictor_tail (conv_w16 mandatory, no FP32 weight copy) and sea_topk_select
+ * handed over on chip -- the (N,H,T,T_m) map is never re-read, and `probs` MAY BE NULL (round 4): the map is then not
+ * written at all (537 MB per step at OPT-1.3B x 8, stored only because the module returns it, attention.py:1343); a caller
+ * that wants it later runs sea_predictor_tail on the same y (bit-identical values).  The selection's slow path (overfull
+ * threshold bin, all-equal rows) works on the on-chip keys too.
+ * Bit-identical to the two separate calls.  Requires W4 * up == T_m, T_m % 4 == 0, T_m <= 512, H <= 64, H * T_m <= 16384
+ * (round 4: any predictor length -- the reference's own grid runs 64 / 96 / 128 / 256 / 384,
+ * src/main/benchmark_opt_ablation.py:160-186, exp_long_context.py:152; T_m = 256 with H % 4 == 0 keeps the map in
+ * registers, every other shape passes it through a flat LDS image of the row).  SEA_EUNSUPPORTED when the row's LDS plan
+ * does not fit.  Arguments as in sea_predictor_tail (conv_w16 mandatory, no FP32 weight copy) and sea_topk_select
  * (keep / keep_stride_n / T_src / is_causal / max_k -> bits / row_nnz / head_off). */
 int sea_predictor_tail_select(const void* y, int dtype, int64_t N, int64_t C, int64_t H, int64_t T, int64_t W4,
                               int64_t up, int64_t T_m, const int64_t* y_strides, const void* conv_b,
@@ -342,11 +348,15 @@ int sea_causal_conv_c8(const void* x, int dtype, int64_t N, int64_t T, int64_t W
  * w1_packed: W1 (D1,Din) as MFMA A fragments  [ks][tile][lane][j] = W1[16*tile + lane%16][32*ks + 8*(lane/16) + j]
  *            (ks < ceil(Din/32), tile < D1/16, zero beyond Din);
  * w2_packed: [ks][tile][lane][j] = W2'[16*tile + lane%16][f(ks, lane/16, j)],  f(ks,g,j) = 16*(2*ks + j/4) + 4*g + j%4,
- *            ks < D1/32, tile <= D2/16, where W2' = W2 (D2,D1) followed by one extra tile whose rows 0,1 are Wsc (2,D1);
- * vectors (fp32): b1[D1] g1[D1] be1[D1] b2[D2] g2[Wd] be2[Wd] bsc[2].
+ *            ks < D1/32, tile <= 2*HT, HT = ceil(Wd/16), WdP = 16*HT, where W2' = the rows of W2 (D2,D1) with each half
+ *            zero-padded to WdP rows (half s at rows s*WdP .. s*WdP+Wd-1; identical to W2 when Wd % 16 == 0), followed by
+ *            one extra tile whose rows 0,1 are Wsc (2,D1);
+ * vectors (fp32): b1[D1] g1[D1] be1[D1] b2[2*WdP] (padded like W2') g2[WdP] be2[WdP] (zero past Wd) bsc[2].
  * Outputs: x_c8 (N, T, H*2/8, Wd, 8) of `dtype`; optional tpred (N,H,T,D1) of `dtype` (= enc); optional
  * row_scale / avg_scale (N,H,T) FP32 = gate[...,0] / gate[...,1].
- * Supported (D1, D2): (128,128) (128,64) (128,256) (160,128) (the weights must fit 160 KB of LDS); H % 4 == 0; Din % 8 == 0. */
+ * Supported (D1, D2): D1 = 128 with any D2 % 16 == 0 up to 256 (round 4: every predictor length T_M = 2*D2 with
+ * T_M % 32 == 0, the reference's grid of src/main/benchmark_opt_ablation.py:160-186 included), (160,128), (256,128)
+ * (the weights must fit 160 KB of LDS, or stream: D1 = 256); H % 4 == 0; Din % 8 == 0. */
 int sea_predictor_mlp(const void* x, int dtype, int64_t N, int64_t H, int64_t T, int64_t Din, const int64_t* x_strides,
                       int64_t D1, int64_t D2, const void* w1_packed, const void* w2_packed, const float* vectors,
                       float eps1, float eps2, void* x_c8, void* tpred, float* row_scale, float* avg_scale,

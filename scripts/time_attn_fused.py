@@ -15,7 +15,7 @@ pc = PerlinAttentionConfig(k=k, attention_predictor_length=T_M, performer_nb_fac
 layer = PerlinSelfAttention(_Cfg(H * d, H, T), pc).to(dev).to(dt).eval()
 for m in layer.modules():
     if hasattr(m, 'benchmarking'): m.benchmarking = True
-layer.attention.context_layer_dtype = dt
+layer.attention.context_layer_dtype = torch.float32 if os.environ.get('CTX', 'bf16') == 'fp32' else dt
 layer.attention.assume_not_padded = True
 S.seed(7)
 x = torch.randn((NB, H, T, d), device=dev)
@@ -44,4 +44,4 @@ for rep in range(3):
     for _ in range(10): run()
     e1.record(); torch.cuda.synchronize()
     ts.append(round(e0.elapsed_time(e1) / 10, 4))
-print(json.dumps({"lib": os.path.basename(os.environ.get("SEA_HIP_LIB", "libsea_hip.so")), "fused_attention_ms": ts, "nnz": int(csr.crow[:, -1].sum())}))
+print(json.dumps({"ctx": os.environ.get("CTX", "bf16"), "lib": os.path.basename(os.environ.get("SEA_HIP_LIB", "libsea_hip.so")), "fused_attention_ms": ts, "nnz": int(csr.crow[:, -1].sum())}))

@@ -16,8 +16,10 @@ def fused():
     return ops.csr_from_selection(*sel, H, T_M, T, k, True, 10_100_000)
 def tail_only():
     return ops.predictor_tail_select(y, cw, cb, lw, lb, up=4, T_m=T_M, keep=keep, k=k, T_src=T)
+def tail_lazy():
+    return ops.predictor_tail_select(y, cw, cb, lw, lb, up=4, T_m=T_M, keep=keep, k=k, T_src=T, lazy_probs=True)
 res = {}
-for name, fn in (("separate_us", sep), ("fused_us", fused), ("tail_select_launch_us", tail_only)):
+for name, fn in (("separate_us", sep), ("fused_us", fused), ("tail_select_launch_us", tail_only), ("tail_select_no_map_us", tail_lazy)):
     for _ in range(3): fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

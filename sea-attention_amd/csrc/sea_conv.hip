@@ -263,16 +263,19 @@ __global__ __launch_bounds__(256) void split_layernorm_c8_kernel(const T* x, T* 
   const int ldt = CS + 8;
   const int nt = blockIdx.x;
   const int n = nt / Tn, t = nt - n * Tn;
-  const int lpr = W / VEC;                      // lanes per row (W % 8 == 0, W <= 512)
-  const int rows_per_pass = 256 / lpr;
-  const int sub = threadIdx.x % lpr, rloc = threadIdx.x / lpr;
+  const int lpr = W / VEC;                      // lanes that carry data per row (W % 8 == 0, W <= 512)
+  int lprp = 1;                                 // lanes per row: the next power of two (xor butterflies); W = 24, 96: 3 of 4, 12 of 16
+  while (lprp < lpr) lprp <<= 1;
+  const int rows_per_pass = 256 / lprp;
+  const int sub = threadIdx.x % lprp, rloc = threadIdx.x / lprp;
+  const bool lact = sub < lpr;
   float g[VEC], b[VEC];
-  unpack16<T>(*reinterpret_cast<const uint4*>(gamma + sub * VEC), g);
-  unpack16<T>(*reinterpret_cast<const uint4*>(beta + sub * VEC), b);
+  unpack16<T>(lact ? *reinterpret_cast<const uint4*>(gamma + sub * VEC) : make_uint4(0, 0, 0, 0), g);
+  unpack16<T>(lact ? *reinterpret_cast<const uint4*>(beta + sub * VEC) : make_uint4(0, 0, 0, 0), b);
   const float invW = 1.0f / (float)W;
   for (int r0 = 0; r0 < CS; r0 += rows_per_pass) {
     const int r = r0 + rloc;                    // output channel c*S + i
-    const bool ok = r < CS && rloc < rows_per_pass;
+    const bool ok = r < CS && lact;
     float f[VEC];
     {
       uint4 v = make_uint4(0, 0, 0, 0);
@@ -285,12 +288,12 @@ __global__ __launch_bounds__(256) void split_layernorm_c8_kernel(const T* x, T* 
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < VEC; ++j) s += f[j];
-    for (int o = 1; o < lpr; o <<= 1) s += __shfl_xor(s, o);
+    for (int o = 1; o < lprp; o <<= 1) s += __shfl_xor(s, o);
     const float mean = s * invW;
     float q2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { const float d = f[j] - mean; q2 += d * d; }
-    for (int o = 1; o < lpr; o <<= 1) q2 += __shfl_xor(q2, o);
+    for (int j = 0; j < VEC; ++j) { const float d = lact ? f[j] - mean : 0.f; q2 += d * d; }
+    for (int o = 1; o < lprp; o <<= 1) q2 += __shfl_xor(q2, o);
     const float rstd = rsqrtf(q2 * invW + eps);
     if (ok) {
 #pragma unroll
@@ -376,8 +379,8 @@ extern "C" int sea_split_layernorm_c8(const void* x, int dtype, int64_t N, int64
   SEA_REQUIRE(dtype == SEA_F16 || dtype == SEA_BF16, SEA_EUNSUPPORTED, "%s: 16-bit data only (dtype %d)", nm, dtype);
   SEA_REQUIRE(N > 0 && C > 0 && T > 0 && S > 0 && W > 0, SEA_EINVAL, "%s: bad shape", nm);
   const int64_t lpr = W / 8;
-  SEA_REQUIRE(W % 8 == 0 && lpr <= 64 && (lpr & (lpr - 1)) == 0 && (C * S) % 8 == 0, SEA_EUNSUPPORTED,
-              "%s: needs W a power-of-two multiple of 8 (<= 512) and C*S %% 8 == 0", nm);
+  SEA_REQUIRE(W % 8 == 0 && lpr <= 64 && (C * S) % 8 == 0, SEA_EUNSUPPORTED,
+              "%s: needs W a multiple of 8 (<= 512) and C*S %% 8 == 0", nm);
   const size_t lds = (size_t)W * (size_t)(C * S + 8) * 2;
   SEA_REQUIRE(lds <= 64 * 1024, SEA_EUNSUPPORTED, "%s: tile needs %zu B of LDS", nm, lds);
   SEA_REQUIRE((((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, SEA_EUNSUPPORTED,

@@ -50,6 +50,7 @@ struct MlpParams {
   float* avg_scale;         // optional (N, H, T)
   int N, H, T, Din, KS1;
   float eps1, eps2;
+  int Wd;                   // width of one decoder split (= T_M / 4); <= 16 * (NT2 / 2), smaller only in the PADW instantiations
 };
 
 // MLP_WAVES waves per (persistent) workgroup: 16 where the accumulators leave room under 128 VGPRs, else 8.
@@ -59,11 +60,15 @@ struct MlpParams {
 // STREAMED -- the workgroup's waves walk the k-steps of their items in lockstep, one k-step's 16 fragments (16 KB) at a
 // time through a two-slot LDS ring, each thread carrying two 16-byte chunks of the next k-step in registers; one barrier
 // per k-step (a slot is rewritten two steps later, after the barrier every reader has passed).  The 192 KB stay in L2.
-template <typename T, int NT1, int NT2, int MLP_WAVES, bool STAGE, bool W1S = false>
+// PADW: the decoder's split width is not a multiple of 16 (T_M = 96: 24; any T_M % 32 == 0 the reference's grid may ask for,
+// src/main/benchmark_opt_ablation.py:160-186): each split owns HT = ceil(Wd / 16) whole tiles, its rows past Wd are zero
+// weights / zero bias (host packing), they stay out of the LayerNorm statistics and are never stored.
+template <typename T, int NT1, int NT2, int MLP_WAVES, bool STAGE, bool W1S = false, bool PADW = false>
 __global__ __launch_bounds__(MLP_WAVES * 64) __attribute__((amdgpu_waves_per_eu(MLP_WAVES / 4, MLP_WAVES / 4)))
 void predictor_mlp_kernel(MlpParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int D1 = NT1 * 16, D2 = NT2 * 16, Wd = D2 / 2, KS2 = NT1 / 2, HT = NT2 / 2;
+  constexpr int D1 = NT1 * 16, D2 = NT2 * 16, WdP = D2 / 2, KS2 = NT1 / 2, HT = NT2 / 2;
+  const int Wd = PADW ? p.Wd : WdP;
   static_assert(NT1 % 2 == 0 && NT2 % 2 == 0, "tile counts must be even");
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -72,8 +77,8 @@ void predictor_mlp_kernel(MlpParams p) {
   T* sW1 = reinterpret_cast<T*>(smem);                                   // KS1*NT1 fragments of 512 elements (W1S: 2*NT1)
   T* sW2 = sW1 + (size_t)(W1S ? 2 : p.KS1) * NT1 * 512;                  // KS2*(NT2+1) fragments
   float* sV = reinterpret_cast<float*>(sW2 + (size_t)KS2 * (NT2 + 1) * 512);
-  constexpr int NVEC = 3 * D1 + D2 + 2 * Wd + 2;
-  constexpr int QSTR = Wd * 16 + 16;                                     // bytes per 4-head block row of the tile (+16: banks)
+  constexpr int NVEC = 3 * D1 + D2 + 2 * WdP + 2;
+  constexpr int QSTR = WdP * 16 + 16;                                    // bytes per 4-head block row of the tile (+16: banks)
   char* sTile = reinterpret_cast<char*>(sV + ((NVEC + 3) & ~3)) + (size_t)wv * (4 * QSTR);
   {
     const int n1 = p.KS1 * NT1 * 64, n2 = KS2 * (NT2 + 1) * 64;          // 16-byte chunks
@@ -86,7 +91,7 @@ void predictor_mlp_kernel(MlpParams p) {
   }
   __syncthreads();
   const float* sB1 = sV, *sG1 = sV + D1, *sE1 = sV + 2 * D1;
-  const float* sB2 = sV + 3 * D1, *sG2 = sB2 + D2, *sE2 = sG2 + Wd, *sBsc = sE2 + Wd;
+  const float* sB2 = sV + 3 * D1, *sG2 = sB2 + D2, *sE2 = sG2 + WdP, *sBsc = sE2 + WdP;
   const T* w1l = sW1 + lane * 8;                                         // + (ks*NT1 + tile)*512
   const T* w2l = sW2 + lane * 8;                                         // + (ks*(NT2+1) + tile)*512
 
@@ -234,15 +239,19 @@ void predictor_mlp_kernel(MlpParams p) {
         a[0] = round16<T>(a[0] + b.x); a[1] = round16<T>(a[1] + b.y); a[2] = round16<T>(a[2] + b.z); a[3] = round16<T>(a[3] + b.w);
         s += (a[0] + a[1]) + (a[2] + a[3]);
       }
-      s = xor32_sum(xor16_sum(s));
-      const float mean = s * (1.0f / (float)Wd);
+      s = xor32_sum(xor16_sum(s));                                        // (padded features are exact zeros here)
+      const float invWd = 1.0f / (float)Wd;
+      const float mean = s * invWd;
       float q2 = 0.f;
 #pragma unroll
-      for (int i = 0; i < HT; ++i)
+      for (int i = 0; i < HT; ++i) {
+        if (!PADW || i * 16 + lg * 4 < Wd) {                              // a lane's 4 features are real or padding together
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { const float d = acc2[hf * HT + i][r] - mean; q2 += d * d; }
+          for (int r = 0; r < 4; ++r) { const float d = acc2[hf * HT + i][r] - mean; q2 += d * d; }
+        }
+      }
       q2 = xor32_sum(xor16_sum(q2));
-      const float rstd = rsqrtf(q2 * (1.0f / (float)Wd) + p.eps2);
+      const float rstd = rsqrtf(q2 * invWd + p.eps2);
 #pragma unroll
       for (int i = 0; i < HT; ++i) {
         const mf4& a = acc2[hf * HT + i];
@@ -266,18 +275,22 @@ void predictor_mlp_kernel(MlpParams p) {
         for (int r = 0; r < 4; ++r) *reinterpret_cast<uint32_t*>(tl + (i * 16 + lg * 4 + r) * 16) = outp[i][r];
       T* yb = reinterpret_cast<T*>(p.x_c8) + (((int64_t)n * p.T + t) * C8 + ht * 4) * (Wd * 8);
 #pragma unroll
-      for (int c0 = 0; c0 < 4 * Wd; c0 += 64) {
+      for (int c0 = 0; c0 < 4 * WdP; c0 += 64) {
         const int c = c0 + lane, q = c / Wd, w = c - q * Wd;
-        const uint4 v = *reinterpret_cast<const uint4*>(sTile + q * QSTR + w * 16);
-        if (active && ht * 4 + q < C8) *reinterpret_cast<uint4*>(yb + (int64_t)c * 8) = v;
+        const bool cin = !PADW || c < 4 * Wd;
+        const uint4 v = *reinterpret_cast<const uint4*>(sTile + (cin ? q * QSTR + w * 16 : 0));
+        if (active && cin && ht * 4 + q < C8) *reinterpret_cast<uint4*>(yb + (int64_t)c * 8) = v;
       }
     } else if (hok) {   // channel = 2h + split: this lane's pair is bytes [4*(h%4), +4) of block h/4, pixel w
       T* yb = reinterpret_cast<T*>(p.x_c8) + (((int64_t)n * p.T + t) * C8 + (h >> 2)) * (Wd * 8) + (h & 3) * 2;
 #pragma unroll
-      for (int i = 0; i < HT; ++i)
+      for (int i = 0; i < HT; ++i) {
+        if (!PADW || i * 16 + lg * 4 < Wd) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          *reinterpret_cast<uint32_t*>(yb + (i * 16 + lg * 4 + r) * 8) = outp[i][r];
+          for (int r = 0; r < 4; ++r)
+            *reinterpret_cast<uint32_t*>(yb + (i * 16 + lg * 4 + r) * 8) = outp[i][r];
+        }
+      }
     }
   }
 }
@@ -290,7 +303,9 @@ template <typename T>
 static int launch_mlp(const MlpParams& p, int nt1, int nt2, hipStream_t s) {
   const int64_t nitems = (int64_t)p.N * p.T * ((p.H + 15) / 16);
   int rc = SEA_EUNSUPPORTED;
-#define SEA_MLP(A, B)                                                                                               \
+  const bool padw = p.Wd != nt2 * 8;
+#define SEA_MLP(A, B) do { if (padw) SEA_MLP_(A, B, true); else SEA_MLP_(A, B, false); } while (0)
+#define SEA_MLP_(A, B, PW)                                                                                          \
   do {                                                                                                              \
     constexpr int NW = (A + B <= 16) ? 16 : 8;                                                                      \
     const size_t wbytes = ((size_t)p.KS1 * A + (size_t)(A / 2) * (B + 1)) * 1024 + (size_t)((3 * A * 16 + 2 * B * 16 + 2 + 3) & ~3) * sizeof(float); \
@@ -302,15 +317,15 @@ static int launch_mlp(const MlpParams& p, int nt1, int nt2, hipStream_t s) {
     if (blocks > 256) blocks = 256;               /* persistent: one workgroup per CU keeps the weights in LDS */   \
     static bool configured = false;                                                                                 \
     if (!configured) {                                                                                              \
-      (void)hipFuncSetAttribute((const void*)predictor_mlp_kernel<T, A, B, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
-      (void)hipFuncSetAttribute((const void*)predictor_mlp_kernel<T, A, B, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      (void)hipFuncSetAttribute((const void*)predictor_mlp_kernel<T, A, B, NW, true, false, PW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
+      (void)hipFuncSetAttribute((const void*)predictor_mlp_kernel<T, A, B, NW, false, false, PW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
       configured = true;                                                                                            \
     }                                                                                                               \
-    if (stage) hipLaunchKernelGGL((predictor_mlp_kernel<T, A, B, NW, true>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);  \
-    else hipLaunchKernelGGL((predictor_mlp_kernel<T, A, B, NW, false>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);       \
+    if (stage) hipLaunchKernelGGL((predictor_mlp_kernel<T, A, B, NW, true, false, PW>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);  \
+    else hipLaunchKernelGGL((predictor_mlp_kernel<T, A, B, NW, false, false, PW>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);       \
     rc = SEA_OK;                                                                                                    \
   } while (0)
-  if (nt1 == 16 && nt2 == 8) {                               // d = 128: encoder weights streamed through a two-slot LDS ring
+  if (nt1 == 16 && nt2 == 8 && !padw) {                               // d = 128: encoder weights streamed through a two-slot LDS ring
     constexpr int A = 16, B = 8, NW = 8;
     const size_t wbytes = ((size_t)2 * A + (size_t)(A / 2) * (B + 1)) * 1024 + (size_t)((3 * A * 16 + 2 * B * 16 + 2 + 3) & ~3) * sizeof(float);
     const size_t lds = wbytes + (size_t)NW * 4 * (B * 8 * 16 + 16);
@@ -326,9 +341,15 @@ static int launch_mlp(const MlpParams& p, int nt1, int nt2, hipStream_t s) {
       rc = SEA_OK;
     }
   } else if (nt1 == 8 && nt2 == 8) SEA_MLP(8, 8);
-  else if (nt1 == 8 && nt2 == 4) SEA_MLP(8, 4);
+  else if (nt1 == 8 && nt2 == 2) SEA_MLP(8, 2);       // d = 64 at every predictor length T_M % 32 == 0 up to 512 (T_M / 4 = 8 .. 128
+  else if (nt1 == 8 && nt2 == 4) SEA_MLP(8, 4);       //  pixels per split: 1 .. 8 tiles, the last one partly padding)
+  else if (nt1 == 8 && nt2 == 6) SEA_MLP(8, 6);
+  else if (nt1 == 8 && nt2 == 10) SEA_MLP(8, 10);
+  else if (nt1 == 8 && nt2 == 12) SEA_MLP(8, 12);
+  else if (nt1 == 8 && nt2 == 14) SEA_MLP(8, 14);
   else if (nt1 == 8 && nt2 == 16) SEA_MLP(8, 16);
-  else if (nt1 == 10 && nt2 == 8) SEA_MLP(10, 8);
+  else if (nt1 == 10 && nt2 == 8 && !padw) SEA_MLP_(10, 8, false);
+#undef SEA_MLP_
 #undef SEA_MLP
   return rc;
 }
@@ -341,8 +362,8 @@ extern "C" int sea_predictor_mlp(const void* x, int dtype, int64_t N, int64_t H,
   SEA_REQUIRE(x && x_strides && w1_packed && w2_packed && vectors && x_c8, SEA_EINVAL, "%s: null pointer", nm);
   SEA_REQUIRE(dtype == SEA_F16 || dtype == SEA_BF16, SEA_EUNSUPPORTED, "%s: 16-bit data only (dtype %d)", nm, dtype);
   SEA_REQUIRE(N > 0 && H > 0 && T > 0 && Din > 0 && D1 > 0 && D2 > 0, SEA_EINVAL, "%s: bad shape", nm);
-  SEA_REQUIRE(Din % 8 == 0 && Din <= (D1 == 256 ? 384 : 256) && D1 % 32 == 0 && D2 % 32 == 0 && H % 4 == 0, SEA_EUNSUPPORTED,
-              "%s: needs Din %% 8 == 0, Din <= 256 (384 with D1 = 256), D1 %% 32 == 0, D2 %% 32 == 0, H %% 4 == 0", nm);
+  SEA_REQUIRE(Din % 8 == 0 && Din <= (D1 == 256 ? 384 : 256) && D1 % 32 == 0 && D2 % 16 == 0 && H % 4 == 0, SEA_EUNSUPPORTED,
+              "%s: needs Din %% 8 == 0, Din <= 256 (384 with D1 = 256), D1 %% 32 == 0, D2 %% 16 == 0, H %% 4 == 0", nm);
   SEA_REQUIRE(x_strides[0] % 8 == 0 && x_strides[1] % 8 == 0 && x_strides[2] % 8 == 0 &&
                   (((uintptr_t)x | (uintptr_t)w1_packed | (uintptr_t)w2_packed | (uintptr_t)x_c8 | (uintptr_t)tpred) & 15) == 0,
               SEA_EUNSUPPORTED, "%s: 16-byte alignment", nm);
@@ -353,9 +374,11 @@ extern "C" int sea_predictor_mlp(const void* x, int dtype, int64_t N, int64_t H,
   p.x_c8 = x_c8; p.tpred = tpred; p.row_scale = row_scale; p.avg_scale = avg_scale;
   p.N = (int)N; p.H = (int)H; p.T = (int)T; p.Din = (int)Din; p.KS1 = (int)((Din + 31) / 32);
   p.eps1 = eps1; p.eps2 = eps2;
+  p.Wd = (int)(D2 / 2);
+  const int nt2 = 2 * (int)((D2 / 2 + 15) / 16);               // tiles of the padded decoder: each split owns ceil(Wd / 16)
   hipStream_t s = (hipStream_t)stream;
-  const int rc = dtype == SEA_BF16 ? launch_mlp<__hip_bfloat16>(p, (int)(D1 / 16), (int)(D2 / 16), s)
-                                   : launch_mlp<__half>(p, (int)(D1 / 16), (int)(D2 / 16), s);
+  const int rc = dtype == SEA_BF16 ? launch_mlp<__hip_bfloat16>(p, (int)(D1 / 16), nt2, s)
+                                   : launch_mlp<__half>(p, (int)(D1 / 16), nt2, s);
   SEA_REQUIRE(rc == SEA_OK, rc, "%s: unsupported (D1=%lld, D2=%lld) combination", nm, (long long)D1, (long long)D2);
   SEA_CHECK_LAUNCH(nm);
   return SEA_OK;

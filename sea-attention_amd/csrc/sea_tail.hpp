@@ -12,7 +12,7 @@ struct TailParams {
   const void* b4;    // (Hpad) fp32
   const void* gamma; // (T_M)
   const void* beta;  // (T_M)
-  void* probs;       // (N, H, T, T_M)
+  void* probs;       // (N, H, T, T_M); optional in the fused tail + selection kernels (the map stays in registers)
   void* scores;      // optional (N, H, T, T_M)
   float eps;
   int N, C, H, T, W4, UP, T_M;
@@ -268,8 +268,15 @@ struct TailRow {
     for (int b = 0; b < NBC; ++b) {
       const float inv = reduce8_get(x, b);
 #pragma unroll
-      for (int e = 0; e < E; ++e) a[b][e] *= inv;
-      if (b < nb) store_run<T, E>(reinterpret_cast<T*>(p.probs) + obase(b), a[b], lane * E, FULLROW ? 64 * E : p.T_M);
+      for (int e = 0; e < E; ++e) {
+        a[b][e] *= inv;
+        // the fp32 product exists in a register before anything rounds it to 16 bits: without this the compiler folds the
+        // multiply into a mixed-precision convert (v_fma_mixlo_f16: ONE rounding) in some kernels and not in others, and
+        // the same row then differs by an fp16 ulp between the stand-alone tail and the fused tail + selection kernels
+        // (6e-5 of the elements) -- the selection's keys must be the very numbers a later sea_predictor_tail call writes
+        asm volatile("" : "+v"(a[b][e]));
+      }
+      if (p.probs && b < nb) store_run<T, E>(reinterpret_cast<T*>(p.probs) + obase(b), a[b], lane * E, FULLROW ? 64 * E : p.T_M);
     }
   }
   template <int NBC, typename ZF, typename OF>

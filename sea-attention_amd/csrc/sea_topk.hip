@@ -216,7 +216,9 @@ __device__ inline long long block_excl_scan64(long long v, long long* s_wave /*[
 // numbers), TWO per register -- element i is half (i & 1) of key[i >> 1].  Half the key registers, packed 16-bit min / max, and
 // the packed pair is the very word the tail stores to the map.  Same selection, bit for bit: the order of the keys and the
 // tie rule are what the 32-bit keys give.
-template <typename T, int EPT, bool FROM_MASK, bool FULL, int HMAX = 1024, bool EXT_CAND = false, bool K16 = false>
+// HCW: the per-head entry counts by a transposing wave reduction -- the T_m = 256 fused kernel only (round j of wave wv IS
+// head 4j + wv there); any other caller counts over the kept pixels.
+template <typename T, int EPT, bool FROM_MASK, bool FULL, int HMAX = 1024, bool EXT_CAND = false, bool K16 = false, bool HCW = K16>
 __device__ __forceinline__ void select_body(const TopkParams& p, uint32_t (&key)[K16 ? EPT / 2 : EPT], unsigned long long sel, int n,
                                             int t, int row, const T* base, uint32_t* cand = nullptr) {
   constexpr int R = EPT / 4;  // chunk rounds
@@ -368,11 +370,70 @@ __device__ __forceinline__ void select_body(const TopkParams& p, uint32_t (&key)
           const unsigned long long nibx = (s_selbits[(c >> 3) & 511] >> (4 * (c & 7))) & 0xFu;
           sel |= nibx << (4 * j);
         }
-      } else {
-        if constexpr (K16) {           // the fallback builds 32-bit keys from the stored map: hand it the range in that space
-          umin = f2key(Elem<T>::to_f(__builtin_bit_cast(T, (unsigned short)umin)));
-          umax = f2key(Elem<T>::to_f(__builtin_bit_cast(T, (unsigned short)umax)));
+      } else if constexpr (K16) {
+        // Overfull threshold bin or an all-equal row, packed keys: resolved from the REGISTERS (the fused tail + selection
+        // kernels need not write the map at all, so there may be nothing to re-read).  The histogram above fixed the top d of
+        // the differing bits; 16-bit keys leave at most 5 more, one second histogram over the bin's keys; what is left are
+        // exact ties, kept in flat order (round-major, then thread, then element) by block scans.
+        const bool hist = bits_left > 0;                       // block-uniform: the first pass ran and found bin rb_sel
+        int n_eq = hist ? c_in : p.M;
+        uint32_t tau_low = 0u;
+        const uint32_t lowmask = hist ? ((1u << shift) - 1u) : 0u;
+        auto in_bin = [&](int i) -> bool {
+          const bool valid = FULL || (((i >> 2) * TK_THREADS + tid) < p.nchunks);
+          return valid && (!hist || digit_at(i, shift, d) == rb_sel);
+        };
+        if (hist) {
+#pragma unroll
+          for (int i = 0; i < EPT; ++i) {
+            const bool valid = FULL || (((i >> 2) * TK_THREADS + tid) < p.nchunks);
+            if (valid && digit_at(i, shift, d) < rb_sel) sel |= 1ull << i;
+          }
+          if (shift > 0) {                                     // (block-uniform) <= 5 bits: <= 32 bins
+            const int nb2 = 1 << shift;
+            __syncthreads();                                   // every reader of the first histogram has passed
+            if (tid < nb2) s_hist[tid] = 0;
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < EPT; ++i)
+              if (in_bin(i)) atomicAdd(&s_hist[nb2 - 1 - (int)(key_at(i) & lowmask)], 1);
+            __syncthreads();
+            const int mine = tid < nb2 ? s_hist[tid] : 0;
+            int total;
+            const int excl = block_excl_scan(mine, s_wave, &total);
+            if (tid < nb2 && excl < kth && kth <= excl + mine) { s_bcast[0] = tid; s_bcast[1] = excl; s_bcast[2] = mine; }
+            __syncthreads();
+            tau_low = (uint32_t)(nb2 - 1 - s_bcast[0]);
+            kth -= s_bcast[1];
+            n_eq = s_bcast[2];
+#pragma unroll
+            for (int i = 0; i < EPT; ++i)
+              if (in_bin(i) && (key_at(i) & lowmask) > tau_low) sel |= 1ull << i;
+          }
         }
+        int seen = 0;                                          // ties in earlier rounds
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          bool tie[4];
+          int cnt = 0;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            tie[e] = in_bin(4 * j + e) && (key_at(4 * j + e) & lowmask) == tau_low;
+            cnt += tie[e] ? 1 : 0;
+          }
+          int total = 0, rank = 0;
+          if (n_eq != kth) rank = seen + block_excl_scan(cnt, s_wave, &total);   // block-uniform condition
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            if (tie[e]) {
+              if (n_eq == kth || rank < kth) sel |= 1ull << (4 * j + e);
+              ++rank;
+            }
+          }
+          seen += total;
+        }
+        __syncthreads();
+      } else {
         sel = select_multipass<T>(base, p.sh, p.T_m, p.nchunks, p.M, K, umin, umax, R, s_hist, s_wave, s_bcast);
         for (int i = tid; i < p.H; i += TK_THREADS) s_head[i] = 0;
         __syncthreads();
@@ -410,7 +471,7 @@ __device__ __forceinline__ void select_body(const TopkParams& p, uint32_t (&key)
   }
   // entries each kept pixel will emit: min(v_end - v_start, max_k), accumulated per head.  Only kept pixels
   // are visited (a row keeps ~K_t << H*T_m of them once t is large).
-  if constexpr (K16) {
+  if constexpr (K16 && HCW) {
     // The fused tail + selection (T_m = 256: round j of wave wv IS head 4j + wv, lane l its pixels 4l .. 4l+3): a lane's four
     // pixel widths are the same for every head, so a head's entries are the widths summed over the kept nibble's bits and
     // over the wave's lanes -- eight heads per transposing reduction, no loop over kept pixels, no LDS atomics (ablation at
@@ -570,10 +631,64 @@ __global__ __launch_bounds__(TK_THREADS, EPT <= 16 ? 7 : EPT == 32 ? 7 : EPT == 
     batch(std::integral_constant<int, 8>{}, std::integral_constant<int, R - 8>{});
   }
   STAMP(9);   // 8 heads per wave: resize + LayerNorm + softmax + store
-  const T* base = reinterpret_cast<const T*>(p.src) + n * p.sn + t * p.st;   // = the map just written (slow path re-reads it)
   // H <= 64: sea_predictor_tail_select checks.  The z tile and the constants table are dead once every wave has left the head
   // loop, i.e. from select_body's first barrier on: the candidate list lives there (the launcher sizes the dynamic LDS for both).
-  select_body<T, EPT, false, FULL, 64, true, true>(p, key, 0ull, n, t, row, base, reinterpret_cast<uint32_t*>(s_z));
+  // The packed-key selection never re-reads the map (its slow path works on the registers too): tp.probs may be null.
+  select_body<T, EPT, false, FULL, 64, true, true>(p, key, 0ull, n, t, row, (const T*)nullptr, reinterpret_cast<uint32_t*>(s_z));
+}
+
+// ---- the same fusion for ANY predictor length (T_m % 4 == 0, T_m <= 512; the reference's own grid runs 64 / 96 / 128 / 384:
+// src/main/benchmark_opt_ablation.py:160-186, exp_long_context.py:152).  The tail keeps its natural layout (wave <-> heads
+// wv, wv + 4, ..., lane <-> E consecutive pixels); the rounded probabilities go through a flat 16-bit image of the row in
+// LDS ([head][pixel], 2 H T_m bytes) from which every thread takes the selection's layout (chunk c = 256 j + tid <-> flat
+// pixels 4c .. 4c+3) as packed keys.  Same arithmetic as predictor_tail_mfma_kernel + topk_select_kernel: bit-identical.
+template <typename T, int E, int EPT>
+__global__ __launch_bounds__(TK_THREADS) void predictor_tail_select_gen_kernel(TailParams tp, TopkParams p) {
+  constexpr int R = EPT / 4;
+  constexpr int NBC = E >= 6 ? 4 : 8;                             // heads per batch of the tail stage (register budget)
+  extern __shared__ __attribute__((aligned(16))) float s_z[];     // HP x (W4 + 3) | constants [3][64 E] | flat map (H T_m 16-bit)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row = blockIdx.x;
+  const int n = row / tp.T, t = row - n * tp.T;
+  const int LDZ = tp.W4 + 3;
+  uint32_t* s_tab = reinterpret_cast<uint32_t*>(s_z + ((tp.H + 15) / 16) * 16 * LDZ);
+  // the flat image sits behind z + table, or behind the 8 KB the candidate list takes over from them if they are smaller
+  const int zt_words = ((tp.H + 15) / 16) * 16 * LDZ + TAIL_TAB_ROWS * 64 * E;
+  unsigned short* s_flat = reinterpret_cast<unsigned short*>(s_z + max(zt_words, 2 * TK_CAND_CAP));
+  tail_z_tile<T>(tp, s_z, n, t);
+  tail_consts_fill<T>(tp, s_tab, 64 * E);
+  __syncthreads();
+  TailRow<T, E> tr;
+  tr.load(s_tab, lane);
+  const int mine = max(0, (tp.H - wv + 3) / 4);                   // heads wv, wv + 4, ... of this wave
+  for (int k0 = 0; k0 < mine; k0 += NBC) {
+    float a[NBC][E];
+    const int nb = min(NBC, mine - k0);
+    tr.heads(tp, lane, nb, [&](int b) { return s_z + (wv + 4 * (k0 + b)) * LDZ; },
+             [&](int b) { return (((int64_t)n * tp.H + (wv + 4 * (k0 + b))) * tp.T + t) * tp.T_M; }, a);
+#pragma unroll
+    for (int b = 0; b < NBC; ++b) {
+      if (b < nb) {
+        unsigned short* fr = s_flat + (wv + 4 * (k0 + b)) * tp.T_M + lane * E;
+#pragma unroll
+        for (int e = 0; e < E; ++e)
+          if (lane * E + e < tp.T_M) fr[e] = __builtin_bit_cast(unsigned short, from_f<T>(a[b][e]));
+      }
+    }
+  }
+  __syncthreads();
+  uint32_t key[EPT / 2];                                           // two 16-bit keys per register (select_body, K16)
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int c = j * TK_THREADS + tid;
+    uint2 v = make_uint2(0u, 0u);
+    if (c < p.nchunks) v = *reinterpret_cast<const uint2*>(s_flat + 4 * c);
+    key[2 * j] = v.x;
+    key[2 * j + 1] = v.y;
+  }
+  select_body<T, EPT, false, false, 64, true, true, false>(p, key, 0ull, n, t, row, (const T*)nullptr, reinterpret_cast<uint32_t*>(s_z));
 }
 
 // ---- crow = exclusive scan of row_nnz ------------------------------------------------------------
@@ -923,18 +1038,54 @@ static int launch_tail_select(const TailParams& tp, const TopkParams& p, int64_t
   return SEA_OK;
 }
 
+template <typename T>
+static int launch_tail_select_gen(const TailParams& tp, const TopkParams& p, int64_t rows, hipStream_t s) {
+  const int ept = ((p.nchunks + TK_THREADS - 1) / TK_THREADS) * 4;
+  const int E = (tp.T_M + 63) / 64;
+  const int EE = E <= 4 ? E : E <= 6 ? 6 : 8;        // the widths launch_tail_mfma instantiates (same lane <-> pixel map: same bits)
+  // z tile + constants table (the candidate list of the selection re-uses them: at least its 8 KB), then the flat image
+  size_t zt = (size_t)(((tp.H + 15) / 16) * 16) * (tp.W4 + 3) * sizeof(float) + (size_t)TAIL_TAB_ROWS * 64 * EE * sizeof(uint32_t);
+  if (zt < 2 * TK_CAND_CAP * sizeof(uint32_t)) zt = 2 * TK_CAND_CAP * sizeof(uint32_t);
+  const size_t lds = zt + (((size_t)p.M * 2 + 15) & ~(size_t)15);
+  if (lds + 12 * 1024 > 160 * 1024) return SEA_EUNSUPPORTED;
+  dim3 grid((unsigned)rows), block(TK_THREADS);
+#define SEA_TSG(EV, PV)                                                                                            \
+  do {                                                                                                             \
+    static bool configured = false;                                                                                \
+    if (lds > 48 * 1024 && !configured) {                                                                          \
+      (void)hipFuncSetAttribute((const void*)predictor_tail_select_gen_kernel<T, EV, PV>, hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024); \
+      configured = true;                                                                                           \
+    }                                                                                                              \
+    hipLaunchKernelGGL((predictor_tail_select_gen_kernel<T, EV, PV>), grid, block, lds, s, tp, p);                 \
+  } while (0)
+#define SEA_TSG_E(PV)                                                                                              \
+  switch (EE) {                                                                                                    \
+    case 1: SEA_TSG(1, PV); break; case 2: SEA_TSG(2, PV); break; case 3: SEA_TSG(3, PV); break; case 4: SEA_TSG(4, PV); break; \
+    case 6: SEA_TSG(6, PV); break; default: SEA_TSG(8, PV); break;                                                 \
+  }
+  if (ept <= 8) { SEA_TSG_E(8) }
+  else if (ept <= 16) { SEA_TSG_E(16) }
+  else if (ept <= 32) { SEA_TSG_E(32) }
+  else { SEA_TSG_E(64) }
+#undef SEA_TSG_E
+#undef SEA_TSG
+  return SEA_OK;
+}
+
 static int tail_select_common(const char* nm, const void* y, int dtype, int64_t N, int64_t C, int64_t H, int64_t T, int64_t W4,
                               int64_t up, int64_t T_m, const int64_t* y_strides, const void* conv_b,
                               const void* conv_w16, int64_t Cp, const void* gamma, const void* beta, float eps,
                               void* probs, void* scores, const int32_t* keep, int64_t keep_stride_n,
                               int64_t T_src, const int32_t* t_src_dev, int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz,
                               int32_t* head_off, sea_stream_t stream) {
-  SEA_REQUIRE(y && y_strides && conv_b && conv_w16 && gamma && beta && probs && keep && bits && row_nnz && head_off, SEA_EINVAL,
+  SEA_REQUIRE(y && y_strides && conv_b && conv_w16 && gamma && beta && keep && bits && row_nnz && head_off, SEA_EINVAL,
               "%s: null pointer", nm);
   SEA_REQUIRE(dtype == SEA_F16 || dtype == SEA_BF16, SEA_EUNSUPPORTED, "%s: 16-bit data only (dtype %d)", nm, dtype);
   SEA_REQUIRE(N > 0 && C > 0 && H > 0 && T > 0 && T_src >= T && max_k > 0, SEA_EINVAL, "%s: bad shape", nm);
-  SEA_REQUIRE(T_m == 256 && W4 == 64 && up == 4 && H % 4 == 0 && H <= 64, SEA_EUNSUPPORTED,
-              "%s: needs T_m = 256 (W4 = 64, up = 4), H %% 4 == 0, H <= 64", nm);
+  const bool tm256 = T_m == 256 && W4 == 64 && up == 4 && H % 4 == 0;       // the register-resident form
+  SEA_REQUIRE(W4 * up == T_m && T_m % 4 == 0 && T_m <= 512 && H <= 64 && H * T_m <= 16384 && W4 + 1 < 1024 && W4 * up + 2 <= 2 * T_m,
+              SEA_EUNSUPPORTED, "%s: needs W4 * up == T_m, T_m %% 4 == 0, T_m <= 512, H <= 64, H * T_m <= 16384", nm);
+  SEA_REQUIRE(tm256 || t_src_dev == nullptr, SEA_EUNSUPPORTED, "%s: the decode form takes T_m = 256 (W4 = 64, up = 4), H %% 4 == 0", nm);
   SEA_REQUIRE(y_strides[1] == 1 && C % 8 == 0 && y_strides[0] % 8 == 0 && y_strides[2] % 8 == 0 && y_strides[3] % 8 == 0 &&
                   y_strides[4] % 8 == 0 && Cp % 32 == 0 && Cp >= C &&
                   (((uintptr_t)y | (uintptr_t)conv_w16 | (uintptr_t)probs | (uintptr_t)scores) & 15) == 0,
@@ -946,15 +1097,17 @@ static int tail_select_common(const char* nm, const void* y, int dtype, int64_t 
   tp.ys_n = y_strides[0]; tp.ys_c = y_strides[1]; tp.ys_t = y_strides[2]; tp.ys_w = y_strides[3]; tp.ys_c8 = y_strides[4];
   tp.w16 = conv_w16; tp.Cp = (int)Cp;
   TopkParams p;
-  p.src = probs; p.sn = H * T * T_m; p.sh = T * T_m; p.st = T_m;          // the (N,H,T,T_m) map this kernel writes
+  p.src = nullptr; p.sn = H * T * T_m; p.sh = T * T_m; p.st = T_m;        // (the packed-key selection never re-reads the map)
   p.H = (int)H; p.T_dst = (int)T; p.T_m = (int)T_m; p.T_src = (int)T_src;
   p.is_causal = is_causal; p.max_k = max_k;
   p.M = (int)(H * T_m); p.nchunks = p.M / 4; p.W = (p.M + 31) / 32; p.G = group_lanes((int)T_m);
   p.keep = keep; p.keep_stride_n = keep_stride_n;
   p.bits = bits; p.mask_out = nullptr; p.row_nnz = row_nnz; p.head_off = head_off; p.t_src_dev = t_src_dev;
   hipStream_t s = (hipStream_t)stream;
-  if (dtype == SEA_F16) launch_tail_select<__half>(tp, p, N * T, s);
-  else launch_tail_select<__hip_bfloat16>(tp, p, N * T, s);
+  int rc;
+  if (tm256) rc = dtype == SEA_F16 ? launch_tail_select<__half>(tp, p, N * T, s) : launch_tail_select<__hip_bfloat16>(tp, p, N * T, s);
+  else rc = dtype == SEA_F16 ? launch_tail_select_gen<__half>(tp, p, N * T, s) : launch_tail_select_gen<__hip_bfloat16>(tp, p, N * T, s);
+  SEA_REQUIRE(rc == SEA_OK, rc, "%s: this (H, T_m) does not fit the fused kernel's LDS plan (run sea_predictor_tail + sea_topk_select)", nm);
   SEA_CHECK_LAUNCH(nm);
   return SEA_OK;
 }

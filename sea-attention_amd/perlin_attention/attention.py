@@ -123,6 +123,11 @@ class PerlinAttention(nn.Module):
         # returns at :1162-1171); costs one extra 4-byte store + reload per entry, so it is on only when somebody reads it:
         # PerlinSelfAttention.checkout_last_attention_probs sets it, so does probing through get_bench()
         self.return_attention_probs = False
+        # sparse mode: `estimated_attention_probs(_m)` of the output as an `ops.LazyTensor` when the fused tail + selection
+        # launch produced the map: the (N,H,T,T_M) tensor is then NOT written by the step (nothing on the hot path reads it;
+        # 537 MB per step at OPT-1.3B x 8) and is computed from the kept conv output the first time a caller touches its
+        # values (bit-identical).  False = always write it (the reference's eager tensor, attention.py:1343)
+        self.lazy_attention_probs = True
         # sparse mode: kernel of steps J-L: "gather" (row-indexed gathers), "tile" (MFMA tile kernel, 16-bit data,
         # d in {64, 80, 128}; wins when neighbouring query rows keep mostly the same keys -- trained predictors), "auto"
         self.sparse_kernel = "auto"
@@ -283,7 +288,7 @@ class PerlinAttention(nn.Module):
         if x.dtype not in (torch.float16, torch.bfloat16):
             return False
         W = self.pconfig.attention_predictor_length // 4
-        if W % 8 or (W // 8) & (W // 8 - 1) or W > 512 or (len(body) - 2) % 2:
+        if W % 8 or W > 512 or (len(body) - 2) % 2:
             return False
         for i in range(0, len(body) - 2, 2):
             conv = getattr(body[i], 'module', None)
@@ -372,7 +377,7 @@ class PerlinAttention(nn.Module):
                                 estimated_attention_probs, estimated_attention_score, sel = ops.predictor_tail_select(
                                     x, conv4.weight[:, :, 0, 0], conv4.bias, ln2.weight, ln2.bias, up=4, T_m=T_M_,
                                     keep=keep, k=int(self.pconfig.k), T_src=T_SRC, is_causal=True, eps=ln2.eps,
-                                    want_scores=want_scores)
+                                    want_scores=want_scores, lazy_probs=self.lazy_attention_probs)
                                 self._fused_selection = (estimated_attention_probs, sel)
                             else:
                                 estimated_attention_probs, estimated_attention_score = ops.predictor_tail(
@@ -442,7 +447,7 @@ class PerlinAttention(nn.Module):
                                 estimated_attention_probs, estimated_attention_score, sel = ops.predictor_tail_select(
                                     x, conv4.weight[:, :, 0, 0], conv4.bias, ln2.weight, ln2.bias, up=4, T_m=T_M_,
                                     keep=keep, k=int(self.pconfig.k), T_src=T_SRC, is_causal=True, eps=ln2.eps,
-                                    want_scores=want_scores)
+                                    want_scores=want_scores, lazy_probs=self.lazy_attention_probs)
                                 self._fused_selection = (estimated_attention_probs, sel)
                             else:
                                 estimated_attention_probs, estimated_attention_score = ops.predictor_tail(

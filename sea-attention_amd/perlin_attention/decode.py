@@ -51,7 +51,7 @@ class DecodeSession:
         self.k = int(pc.k)
         dev, dt = key_prefix.device, key_prefix.dtype
         assert dt in (torch.float16, torch.bfloat16)
-        assert ops.predictor_tail_select_supported(cs.rows_c8, H, self.T_M), "fused tail + selection shape (T_M = 256, H <= 64)"
+        assert ops.predictor_tail_select_supported(cs.rows_c8, H, self.T_M, decode=True), "fused tail + selection shape (T_M = 256, H <= 64)"
         self.image = ps.image.clone()                                        # Performer sums, updated in place
         self.win = cs.rows_c8.clone()                                        # last LB rows of the CNN input
         # K and V caches are the two halves of ONE tensor and the two position counters two elements of one: a step appends

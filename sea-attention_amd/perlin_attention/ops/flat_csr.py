@@ -162,6 +162,7 @@ def topk_to_csr(probs: torch.Tensor, keep: torch.Tensor, k: int, target_width: O
     Replaces attention.py:774-947 + ops/kernels/causal_resize_m_to_t.py:910-1007.
     """
     lib = _lib.load()
+    probs = getattr(probs, "materialize", lambda: probs)()      # a lazily produced map (ops.LazyTensor) is computed here
     _lib.require_gpu(probs, keep)
     assert probs.ndim == 4 and probs.stride(-1) == 1
     N, H, T_dst, T_m = probs.shape
@@ -224,6 +225,7 @@ def csr_from_selection(bits: torch.Tensor, row_nnz: torch.Tensor, head_off: torc
 def topk_mask(probs: torch.Tensor, keep: torch.Tensor, k: int, target_width=None, is_causal=True) -> torch.Tensor:
     """a6 alone: 0/1 fp32 compressed mask (N,H,T_dst,T_m)."""
     lib = _lib.load()
+    probs = getattr(probs, "materialize", lambda: probs)()
     _lib.require_gpu(probs, keep)
     N, H, T_dst, T_m = probs.shape
     T_src = target_width if target_width is not None else T_dst

@@ -15,6 +15,49 @@ def _p(t):
     return c_void_p(t.data_ptr()) if t is not None else c_void_p(0)
 
 
+class LazyTensor(torch.Tensor):
+    """A tensor whose values are computed the first time anything needs them.  Shape, dtype, device and strides are
+    served from the wrapper; any torch operation on it (indexing, `.float()`, `.cpu()`, comparisons, ...) runs the
+    thunk once and proceeds on the real tensor.  Used for `estimated_attention_probs(_m)` in sparse mode: the module
+    returns the (N,H,T,T_m) map (attention.py:1343) but nothing on the hot path reads it, and writing it is 537 MB per
+    step at OPT-1.3B x 8 -- the fused tail + selection launch keeps it on chip and this handle recomputes it from the
+    kept conv output on demand (same kernel code: bit-identical values)."""
+
+    @staticmethod
+    def __new__(cls, shape, dtype, device, thunk):
+        r = torch.Tensor._make_wrapper_subclass(cls, tuple(shape), dtype=dtype, device=device, requires_grad=False)
+        r._thunk, r._real = thunk, None
+        return r
+
+    def __init__(self, shape, dtype, device, thunk):
+        pass
+
+    def materialize(self) -> torch.Tensor:
+        if self._real is None:
+            self._real = self._thunk()
+            self._thunk = None
+            assert tuple(self._real.shape) == tuple(self.shape) and self._real.dtype == self.dtype
+        return self._real
+
+    @property
+    def is_materialized(self) -> bool:
+        return self._real is not None
+
+    def __repr__(self):
+        return f"LazyTensor(shape={tuple(self.shape)}, dtype={self.dtype}, device={self.device}, materialized={self._real is not None})"
+
+    @classmethod
+    def __torch_dispatch__(cls, func, types, args=(), kwargs=None):
+        from torch.utils._pytree import tree_map
+        un = lambda x: x.materialize() if isinstance(x, LazyTensor) else x
+        return func(*tree_map(un, args), **tree_map(un, kwargs or {}))
+
+
+def realize(t):
+    """The real tensor behind a LazyTensor (any other value is returned as it is): what goes to the C ABI."""
+    return t.materialize() if isinstance(t, LazyTensor) else t
+
+
 _prep_cache = {}
 _prep_generation = 0          # bumped by clear_prep_cache(): holders of raw pointers into cached packs compare it
 _prep_recorders = []          # lists that collect every value `_cached` hands out while a `pinned_prep()` block is open
@@ -133,18 +176,31 @@ def predictor_tail(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.Tensor, 
     return probs, scores
 
 
-def predictor_tail_select_supported(y: torch.Tensor, H: int, T_m: int) -> bool:
-    """Shapes csrc/sea_topk.hip: predictor_tail_select_kernel takes (see sea_predictor_tail_select in sea_hip.h)."""
-    return (y.dtype in (torch.float16, torch.bfloat16) and T_m == 256 and H % 4 == 0 and H <= 64
-            and (y.dim() == 5 or y.stride(1) == 1))
+def predictor_tail_select_supported(y: torch.Tensor, H: int, T_m: int, decode: bool = False) -> bool:
+    """Shapes csrc/sea_topk.hip: predictor_tail_select(_gen)_kernel take (see sea_predictor_tail_select in sea_hip.h):
+    any predictor length T_m % 4 == 0 up to 512 whose row fits the kernel's LDS plan; the decode form (`_at`) and the
+    register-resident kernel take T_m = 256 with H % 4 == 0."""
+    if not (y.dtype in (torch.float16, torch.bfloat16) and (y.dim() == 5 or y.stride(1) == 1)):
+        return False
+    if T_m == 256 and H % 4 == 0 and H <= 64:
+        return True
+    if decode or T_m % 4 or T_m > 512 or H > 64 or H * T_m > 16384:
+        return False
+    W4, E = T_m // 4, (T_m + 63) // 64
+    E = E if E <= 4 else 6 if E <= 6 else 8
+    zt = max((H + 15) // 16 * 16 * (W4 + 3) * 4 + 3 * 64 * E * 4, 8192)
+    return zt + H * T_m * 2 + 12 * 1024 <= 160 * 1024
 
 
 @_lib.device_guarded
 def predictor_tail_select(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor,
                           up: int, T_m: int, keep: torch.Tensor, k: int, T_src: int, is_causal: bool = True,
-                          eps: float = 1e-5, want_scores: bool = False, t_src_dev: Optional[torch.Tensor] = None):
+                          eps: float = 1e-5, want_scores: bool = False, t_src_dev: Optional[torch.Tensor] = None,
+                          lazy_probs: bool = False):
     """predictor_tail + grouped top-k selection in one launch.  Returns (probs, scores, (bits, row_nnz, head_off));
     feed the triple to flat_csr.csr_from_selection.  Bit-identical to predictor_tail followed by topk_to_csr.
+    `lazy_probs`: the launch does NOT write the (N,H,T,T_m) map (nobody on the hot path reads it); `probs` is then a
+    `LazyTensor` that runs `predictor_tail` on the kept `y` the first time anything touches its values.
     Decode form (`sea_predictor_tail_select_at`, a step replayed as a HIP graph): `t_src_dev` is a one-element int32
     device tensor holding the sequence length (T_src is ignored) and `keep` a table over absolute row indices."""
     lib = _lib.load()
@@ -157,7 +213,7 @@ def predictor_tail_select(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.T
     else:
         N, C, T, W4 = y.shape
     H = conv_w.shape[0]
-    assert conv_w.shape == (H, C) and W4 * up == T_m and predictor_tail_select_supported(y, H, T_m)
+    assert conv_w.shape == (H, C) and W4 * up == T_m and predictor_tail_select_supported(y, H, T_m, decode=t_src_dev is not None)
     assert keep.dtype == torch.int32 and keep.is_contiguous() and (t_src_dev is not None or keep.shape in ((T,), (N, T)))
     dt = y.dtype
     Hpad = (H + 7) // 8 * 8
@@ -173,8 +229,12 @@ def predictor_tail_select(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.T
         return cw, cb, ln_w.to(dt).contiguous(), ln_b.to(dt).contiguous(), w16, Cp
     _cw, cb, g, b, w16, Cp = _cached("tail", (conv_w, conv_b, ln_w, ln_b), dt, build)
     dev = y.device
-    probs = torch.empty((N, H, T, T_m), dtype=dt, device=dev)
-    scores = torch.empty_like(probs) if want_scores else None
+    if lazy_probs:
+        assert t_src_dev is None
+        probs = LazyTensor((N, H, T, T_m), dt, dev, lambda: predictor_tail(y, conv_w, conv_b, ln_w, ln_b, up, T_m, eps)[0])
+    else:
+        probs = torch.empty((N, H, T, T_m), dtype=dt, device=dev)
+    scores = torch.empty((N, H, T, T_m), dtype=dt, device=dev) if want_scores else None
     W = (H * T_m + 31) // 32
     bits = torch.empty((N, T, W), dtype=torch.int32, device=dev)
     row_nnz = torch.empty((N, T), dtype=torch.int32, device=dev)
@@ -188,7 +248,7 @@ def predictor_tail_select(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.T
         return probs, scores, (bits, row_nnz, head_off)
     _lib.check(lib.sea_predictor_tail_select(
         _p(y), _lib.dtype_code(dt), N, C, H, T, W4, up, T_m, _lib.strides5_blocked(y), _p(cb), _p(w16), Cp, _p(g), _p(b),
-        float(eps), _p(probs), _p(scores), _p(keep), T if keep.ndim == 2 else 0, T_src, int(is_causal), int(k),
+        float(eps), _p(None if lazy_probs else probs), _p(scores), _p(keep), T if keep.ndim == 2 else 0, T_src, int(is_causal), int(k),
         _p(bits), _p(row_nnz), _p(head_off), _lib.stream_ptr()), "sea_predictor_tail_select")
     return probs, scores, (bits, row_nnz, head_off)
 
@@ -362,7 +422,9 @@ def predictor_mlp_supported(D1: int, D2: int, H: int, Din: int) -> bool:
     """Shapes csrc/sea_mlp.hip is instantiated for (launch_mlp)."""
     if (D1, D2) == (256, 128):                                    # d = 128: encoder weights streamed through LDS
         return H % 4 == 0 and Din % 8 == 0 and Din <= 384
-    return (D1, D2) in ((128, 128), (128, 64), (128, 256), (160, 128)) and H % 4 == 0 and Din % 8 == 0 and Din <= 256
+    if D1 == 128:                                                 # d = 64: every predictor length T_M = 2 * D2, T_M % 32 == 0, <= 512
+        return D2 % 16 == 0 and 16 <= D2 <= 256 and H % 4 == 0 and Din % 8 == 0 and Din <= 256
+    return (D1, D2) == (160, 128) and H % 4 == 0 and Din % 8 == 0 and Din <= 256
 
 
 def _pack_a_fragments(w: torch.Tensor, kperm=None) -> torch.Tensor:
@@ -397,14 +459,22 @@ def predictor_mlp(x: torch.Tensor, enc_lin, enc_ln, dec_lin, ln1, scaler_lin, wa
         KP = (Din + 31) // 32 * 32
         w1 = torch.zeros((D1, KP), dtype=dt, device=x.device)
         w1[:, :Din] = enc_lin.weight.to(dt)
-        w2 = torch.zeros((D2 + 16, D1), dtype=dt, device=x.device)
-        w2[:D2] = dec_lin.weight.to(dt)
-        w2[D2:D2 + 2] = scaler_lin.weight.to(dt)
+        # each half (split) of the decoder owns ceil(Wd / 16) whole 16-row tiles; rows past Wd are zero (T_M = 96: Wd = 24)
+        WdP = (Wd + 15) // 16 * 16
+        w2 = torch.zeros((2 * WdP + 16, D1), dtype=dt, device=x.device)
+        w2[:Wd] = dec_lin.weight[:Wd].to(dt)
+        w2[WdP:WdP + Wd] = dec_lin.weight[Wd:].to(dt)
+        w2[2 * WdP:2 * WdP + 2] = scaler_lin.weight.to(dt)
         w1p = _pack_a_fragments(w1)
         w2p = _pack_a_fragments(w2, kperm=lambda ks, g, j: 16 * (2 * ks + j // 4) + 4 * g + j % 4)
         f = lambda t: t.to(dt).float().reshape(-1)
-        vec = torch.cat([f(enc_lin.bias), f(enc_ln.weight), f(enc_ln.bias), f(dec_lin.bias), f(ln1.weight), f(ln1.bias),
-                         f(scaler_lin.bias)]).contiguous()
+
+        def padded(t, parts):                                     # `parts` runs of Wd values, each zero-padded to WdP
+            o = torch.zeros((parts, WdP), dtype=torch.float32, device=x.device)
+            o[:, :Wd] = f(t).view(parts, Wd)
+            return o.reshape(-1)
+        vec = torch.cat([f(enc_lin.bias), f(enc_ln.weight), f(enc_ln.bias), padded(dec_lin.bias, 2), padded(ln1.weight, 1),
+                         padded(ln1.bias, 1), f(scaler_lin.bias)]).contiguous()
         return w1p, w2p, vec
     w1p, w2p, vec = _cached("mlp", (enc_lin.weight, enc_lin.bias, enc_ln.weight, enc_ln.bias, dec_lin.weight, dec_lin.bias,
                                     ln1.weight, ln1.bias, scaler_lin.weight, scaler_lin.bias), dt, build)

@@ -177,7 +177,7 @@ def _causal_conv_ref(x, weight, bias, k, dil, pad_w, relu):
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("dil", [2, 1, 3])
 @pytest.mark.parametrize("N,Cin,Cout,T,W", [(2, 64, 64, 40, 64), (1, 24, 24, 33, 16), (1, 80, 80, 20, 64), (1, 64, 64, 9, 32),
-                                            (1, 32, 48, 17, 128), (1, 16, 32, 12, 40)])
+                                            (1, 32, 48, 17, 128), (1, 16, 32, 12, 40), (1, 24, 24, 11, 24), (1, 24, 24, 9, 96)])
 def test_causal_conv_c8(ops, dtype, N, Cin, Cout, T, W, dil):
     g = torch.Generator().manual_seed(3)
     x = torch.randn((N, Cin, T, W), generator=g).to(dtype)
@@ -211,7 +211,8 @@ def test_causal_conv_c8(ops, dtype, N, Cin, Cout, T, W, dil):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("N,C,T,S,W", [(2, 12, 40, 2, 16), (1, 32, 70, 2, 64), (1, 40, 9, 2, 64), (1, 4, 5, 2, 128)])
+@pytest.mark.parametrize("N,C,T,S,W", [(2, 12, 40, 2, 16), (1, 32, 70, 2, 64), (1, 40, 9, 2, 64), (1, 4, 5, 2, 128),
+                                       (1, 12, 21, 2, 24), (1, 12, 13, 2, 96), (1, 4, 7, 2, 40)])    # lanes per row not a power of two
 def test_split_layernorm_c8(ops, dtype, N, C, T, S, W):
     g = torch.Generator().manual_seed(0)
     x = (torch.randn((N, C, T, S * W), generator=g) * 2 + 0.3).to(dtype)
@@ -292,6 +293,10 @@ def test_estimator_kernels_are_bitwise_reproducible(ops):
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,H,T,d,T_M", [(2, 32, 40, 64, 256), (1, 12, 33, 64, 256), (1, 4, 70, 64, 128), (1, 8, 20, 64, 512),
+                                         # the reference's own grid (benchmark_opt_ablation.py:160-186, exp_long_context.py:152) and
+                                         # the padded split widths (T_M / 4 not a multiple of 16: 96 -> 24, 160 -> 40, 32 -> 8)
+                                         (1, 12, 50, 64, 64), (1, 12, 37, 64, 96), (2, 12, 40, 64, 384), (1, 8, 19, 64, 160),
+                                         (1, 4, 9, 64, 32), (1, 16, 21, 64, 448), (1, 4, 30, 64, 480),
                                          (1, 20, 17, 80, 256),
                                          (1, 40, 50, 128, 256), (2, 8, 300, 128, 256)])   # d = 128: encoder weights streamed
 def test_predictor_mlp(ops, dtype, N, H, T, d, T_M):
@@ -333,10 +338,16 @@ def test_predictor_mlp(ops, dtype, N, H, T, d, T_M):
 
 
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
-@pytest.mark.parametrize("N,H,T,k", [(2, 32, 300, 64), (1, 12, 257, 16), (1, 4, 64, 8), (1, 40, 100, 64), (1, 64, 40, 32)])
-def test_predictor_tail_select_bit_identical(ops, dtype, N, H, T, k):
+@pytest.mark.parametrize("N,H,T,k,T_M", [(2, 32, 300, 64, 256), (1, 12, 257, 16, 256), (1, 4, 64, 8, 256), (1, 40, 100, 64, 256),
+                                         (1, 64, 40, 32, 256),
+                                         # any predictor length (round 4): the flat-LDS-image form of the fused kernel
+                                         (1, 12, 300, 32, 64), (2, 12, 130, 128, 96), (1, 12, 200, 64, 128), (1, 12, 150, 32, 384),
+                                         (1, 32, 70, 64, 512), (1, 6, 90, 16, 256), (1, 32, 50, 64, 128), (1, 3, 40, 8, 36)])
+def test_predictor_tail_select_bit_identical(ops, dtype, N, H, T, k, T_M):
     """One-launch tail + top-k selection == predictor_tail followed by topk_to_csr, bit for bit (map, CSR, offsets)."""
-    T_M, C, W4 = 256, 2 * H, 64
+    C, W4 = 2 * H, T_M // 4
+    C = (C + 7) // 8 * 8
+    assert ops.predictor_tail_select_supported(torch.empty((1, 1, 1, 1, 8), dtype=dtype), H, T_M)
     g = torch.Generator().manual_seed(9)
     y = ops.to_c8(torch.relu(torch.randn((N, C, T, W4), generator=g)).to(dtype).to(DEV))
     cw = (torch.randn((H, C), generator=g) * C ** -0.5).to(dtype).to(DEV)
@@ -353,6 +364,13 @@ def test_predictor_tail_select_bit_identical(ops, dtype, N, H, T, k):
     for i in range(N):
         Z = int(c0.crow[i, -1])
         assert torch.equal(c0.col[i, :Z], c1.col[i, :Z])
+    # the map left on chip (round 4): same selection, and the lazy handle computes the very same map when somebody asks
+    pl, _, sel_l = ops.predictor_tail_select(y, cw, cb, lw, lb, up=4, T_m=T_M, keep=keep, k=k, T_src=T, lazy_probs=True)
+    assert isinstance(pl, ops.LazyTensor) and not pl.is_materialized and tuple(pl.shape) == tuple(p0.shape) and pl.dtype == dtype
+    cl = ops.csr_from_selection(*sel_l, H, T_M, T, k, True, None, keep)
+    assert torch.equal(c0.bits, cl.bits) and torch.equal(c0.crow, cl.crow) and torch.equal(c0.head_off, cl.head_off)
+    assert not pl.is_materialized
+    assert torch.equal(pl, p0) and pl.is_materialized and torch.equal(pl[:, :, -1].float(), p0[:, :, -1].float())
     # all-equal map (massive ties): the selection's slow path re-reads the map the same launch has just written
     y0 = torch.zeros_like(y)
     p2, _, sel2 = ops.predictor_tail_select(y0, cw * 0, cb * 0, lw, lb * 0, up=4, T_m=T_M, keep=keep, k=k, T_src=T)
@@ -362,10 +380,12 @@ def test_predictor_tail_select_bit_identical(ops, dtype, N, H, T, k):
     # a bump on a flat map: a few distinct levels, the K-th key inside a tie of thousands -- the threshold bin overflows the
     # candidate list AFTER the histogram pass (keys differ), and the fallback gets its key range from the packed 16-bit keys
     y1 = torch.zeros_like(y)
-    y1[:, :, :, 5:7, :] = 1.0                                              # (N, T, C/8, W4, 8): two pixel columns lit
+    y1[:, :, :, 5:7 if W4 > 8 else 5:6, :] = 1.0                           # (N, T, C/8, W4, 8): two pixel columns lit
     args1 = (y1, torch.full_like(cw, 0.05), cb * 0, torch.ones_like(lw), lb * 0)   # every head, every flat pixel alike
     p4, _, sel4 = ops.predictor_tail_select(*args1, up=4, T_m=T_M, keep=keep, k=k, T_src=T)
     c4 = ops.csr_from_selection(*sel4, H, T_M, T, k, True, None, keep)
+    _, _, sel4l = ops.predictor_tail_select(*args1, up=4, T_m=T_M, keep=keep, k=k, T_src=T, lazy_probs=True)   # slow path, no map in memory
+    assert torch.equal(sel4l[0], sel4[0]) and torch.equal(sel4l[1], sel4[1]) and torch.equal(sel4l[2], sel4[2])
     p5 = ops.predictor_tail(*args1, up=4, T_m=T_M)[0]
     c5, _ = ops.topk_to_csr(p5, keep, k, target_width=T)
     assert torch.equal(p4, p5) and p4.float().unique().numel() < 64
