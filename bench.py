@@ -39,6 +39,7 @@ WORKLOADS = {
 OTHER_LEGS = (("opt-125m", 8), ("opt-2.7b", 1), ("llama-13b", 1))
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 L2_GATHER_GBS = 17800.0    # MI355X_MICROARCH.md "Indexed rows": 16.8-18.8 TB/s chip-wide for rows served by the XCD's L2
+L2_PEAK_GBS = 34500.0      # MI355X_MICROARCH.md "L2 (per XCD)": ~34.5 TB/s aggregate streaming rate of the eight L2s
 METRIC = "tokens/sec + achieved HBM GB/s, OPT-1.3B SEA T=4096 k=64, 1/2/4/8 MI355X"
 
 
@@ -64,11 +65,19 @@ def parse_args(argv=None):
                          "selection before the timed region and runs the fastest (reported as attention_path_ab)")
     ap.add_argument("--no-output-check", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the short legs over the other BASELINE shapes")
-    ap.add_argument("--other-steps", type=int, default=5, help="timed steps of each short leg")
+    ap.add_argument("--other-steps", type=int, default=20, help="timed steps of each short leg")
+    ap.add_argument("--context-dtype", default="fp32", choices=["fp32", "same"],
+                    help="dtype of context_layer: fp32 = the module's and the reference's default (flat_csr_sdbmm.py:347); "
+                         "'same' = the data dtype (reported as the context_bf16 leg by the default run)")
+    ap.add_argument("--no-grid", action="store_true",
+                    help="skip the reference's own ablation grid (benchmark_opt_ablation.py:160-186: opt-125m layer, batch 1, T = 2048, "
+                         "k in {32, 64, 128} x predictor length in {64, 128, 256, 384}, + exp_long_context.py:152's T_M = 96 / k = 128)")
+    ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32-DATA leg at BASELINE config 2 (B=8 H=12 T=2048 d=64)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the forward + backward leg of the sparse branch")
-    ap.add_argument("--decode-steps", type=int, default=0,
-                    help="positions of the generation leg after the timed steps (off by default: its one-row launches share kernel "
-                         "names with the layer's and would dilute a profiler's per-kernel averages of the default command)")
+    ap.add_argument("--decode-steps", type=int, default=200,
+                    help="positions of the generation leg (batch 1 and the headline batch) after the timed steps; 0 = off (the "
+                         "profiling scripts pass 0: its one-row launches share kernel names with the layer's and would dilute a "
+                         "profiler's per-kernel averages)")
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on a box without N GPUs: the process group runs on gloo; with one GPU every rank uses cuda:0 and "
                          "walks the multi-rank code path of this script (shards, graph capture beside a process group, pipelined "
@@ -176,17 +185,17 @@ class LayerBench:
     step (everything up to the fused sparse-attention launch captured, that launch eager between HIP events), the
     A/B of the attention kernel paths, and the roofline block of the attention launch."""
 
-    def __init__(self, wname, NB, dtype_name, dev, ctx_dtype_name=None, inspect_padding=False, seed_offset=0):
+    def __init__(self, wname, NB, dtype_name, dev, ctx_dtype_name=None, inspect_padding=False, seed_offset=0, override=None):
         import torch
         import sea_attention_amd as S
         from sea_attention_amd.perlin_attention import PerlinAttentionConfig, PerlinSelfAttention
         self.torch, self.S = torch, S
-        self.wname, self.w, self.NB, self.dev = wname, WORKLOADS[wname], NB, dev
+        self.wname, self.w, self.NB, self.dev = wname, dict(WORKLOADS[wname], **(override or {})), NB, dev
         w = self.w
         H, d, T, T_M, k = w["H"], w["d"], w["T"], w["T_M"], w["k"]
         dts = {"bf16": torch.bfloat16, "fp16": torch.float16, "fp32": torch.float32}
         self.dtype = dts[dtype_name]
-        self.ctx_dtype = dts[ctx_dtype_name or dtype_name]
+        self.ctx_dtype = dts[ctx_dtype_name or "fp32"]            # fp32 = the module's default (context_layer_dtype None)
         S.seed(42)
         pc = PerlinAttentionConfig(k=k, attention_predictor_length=T_M, performer_nb_factor=w["nbf"], causal=True,
                                    k_flatten=True, k_flatten_dim='causal_batch', context_output_method='mix')
@@ -194,7 +203,7 @@ class LayerBench:
         for m in layer.modules():
             if hasattr(m, 'benchmarking'):
                 m.benchmarking = True
-        layer.attention.context_layer_dtype = self.ctx_dtype     # None-equivalent (fp32) is the reference's default
+        layer.attention.context_layer_dtype = None if self.ctx_dtype == torch.float32 else self.ctx_dtype   # None = the default
         # the synthetic batch carries no padding by construction; telling the module removes the per-layer host
         # sync the reference pays to find that out (attention.py:434) and lets the CPU enqueue ahead of the GPU
         layer.attention.assume_not_padded = None if inspect_padding else True
@@ -334,7 +343,9 @@ class LayerBench:
         if not t_attn_s:
             return None, Z
         achieved = alg_bytes / t_attn_s / 1e9
-        traffic, traffic_note = None, "no PMC pass on record (scripts/gpu_pmc.sh writes profiles/traffic_latest.json)"
+        fused_ij = path in ("gather", "auto") and ops.fused_interp_supported(self.dtype, d, w["T_M"])
+        same_launch = lambda a_, b_: a_ == b_ or (fused_ij and {a_, b_} <= {"gather", "auto"})   # both run the fused gather launch
+        traffic, l2_req, traffic_note = None, None, "no PMC pass on record (scripts/gpu_pmc.sh writes profiles/traffic_latest.json)"
         tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tp):
             try:
@@ -343,13 +354,20 @@ class LayerBench:
                     traffic_note = "profiles/traffic_latest.json was taken on other kernel sources: not reported"
                 elif rec.get("nnz") != Z:
                     traffic_note = "profiles/traffic_latest.json was taken on another workload (entry count differs): not reported"
+                elif (rec.get("attention_path") is not None and not same_launch(rec.get("attention_path"), path)) \
+                        or rec.get("context_dtype") not in (None, str(self.ctx_dtype)):
+                    # the counters belong to the launch they were taken on: same kernel path, same output dtype
+                    traffic_note = (f"profiles/traffic_latest.json was taken on path {rec.get('attention_path')} / context "
+                                    f"{rec.get('context_dtype')}, this run is {path} / {self.ctx_dtype}: not reported")
                 else:
                     traffic = rec.get("sea_sparse_attention_hbm_bytes_per_launch")
+                    l2_req = rec.get("sea_sparse_attention_l2_requests_per_launch")
+                    if l2_req is None:                                   # records of round 3: sum over the attention kernels
+                        l2_req = sum(v_.get("l2_requests_per_launch", 0) for k_, v_ in rec.get("kernels", {}).items() if "sparse_attn" in k_) or None
                     traffic_note = rec.get("note", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command")
             except Exception:
                 pass
         gname = "sparse_attn_rows80_kernel" if d == 80 and esz == 2 else "sparse_attn_rows_kernel"
-        fused_ij = path in ("gather", "auto") and ops.fused_interp_supported(self.dtype, d, w["T_M"])
         if fused_ij:      # steps I + J in one launch: the kernel also expands the kept pixels and writes the CSR's columns
             gname += " (fused form: interpolation + attention, sea_sparse_attention_fused)"
         kname = {"tile": "sparse_attn_tile_kernel", "gather": gname, "auto": gname} if fused_ij else {"tile": "sparse_attn_tile_kernel", "gather": gname,
@@ -364,6 +382,9 @@ class LayerBench:
                 "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_note": traffic_note,
                 "compulsory_bytes": compulsory, "frac_compulsory_hbm": round(compulsory / t_attn_s / 1e9 / HBM_PEAK_GBS, 4),
                 "l2_gather_peak": L2_GATHER_GBS, "l2_gather_frac": round(achieved / L2_GATHER_GBS, 4),
+                # what the L2 actually served (PMC TCC_REQ x 128 B per launch, same record as `traffic`) against its streaming peak
+                "l2_request_bytes": (l2_req * 128 if l2_req else None), "l2_peak": L2_PEAK_GBS,
+                "frac_l2_peak": (round(l2_req * 128 / t_attn_s / 1e9 / L2_PEAK_GBS, 4) if l2_req else None),
                 "timing": timing_note, "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": round(t_attn_s * 1e3, 4), "nnz": Z}, Z
 
@@ -375,30 +396,96 @@ class LayerBench:
         self.torch.cuda.empty_cache()
 
 
-def short_leg(wname, NB, args, dev, ctx_dtype_name=None):
-    """A short run of another BASELINE shape (or of the headline with another context dtype): same protocol as the headline
-    (prewarm, A/B of the attention path, HIP-graph replay, HIP events around the attention launch), fewer steps."""
-    lb = LayerBench(wname, NB, args.dtype, dev, ctx_dtype_name=ctx_dtype_name)
+def short_leg(wname, NB, args, dev, ctx_dtype_name=None, dtype_name=None, override=None, sparse_kernel=None, steps=None,
+              want_regions=False):
+    """A short run of another BASELINE shape (or of the headline with another context dtype / data dtype / predictor length):
+    same protocol as the headline (prewarm, A/B of the attention path, HIP-graph replay, HIP events around the attention
+    launch).  `sparse_kernel`: a fixed path instead of the A/B (the grid legs); `want_regions`: per-region times of a few
+    eager steps after the timed ones."""
+    dtype_name = dtype_name or args.dtype
+    steps = steps or args.other_steps
+    ctx_dtype_name = ctx_dtype_name or ("fp32" if args.context_dtype == "fp32" else dtype_name)
+    lb = LayerBench(wname, NB, dtype_name, dev, ctx_dtype_name=ctx_dtype_name, override=override)
     try:
         for _ in range(3):
             lb.forward()
-        path, ab = ("eager", {"graph": False}) if args.eager else lb.choose_path(args.sparse_kernel)
+        path, ab = ("eager", {"graph": False}) if args.eager else lb.choose_path(sparse_kernel or args.sparse_kernel)
         if lb.graph is None:
             lb.layer.attention.sparse_kernel = "auto" if path in ("ab", "eager") else path
             path = lb.layer.attention.sparse_kernel
         lb.timed(max(2, args.warmup // 2))
-        dt, am = lb.timed(args.other_steps)
+        dt, am = lb.timed(steps)
         out, _ = lb.step()
         lb.torch.cuda.synchronize()
         roof, Z = lb.roofline(out, am / 1e3 if am else None, path, "HIP events around every launch inside the timed steps")
         w = lb.w
-        return {"workload": f"{wname} H={w['H']} d={w['d']} T={w['T']} k={w['k']} predictor_length={w['T_M']}, batch {NB}/GPU, "
-                            f"{args.dtype}, context_layer {ctx_dtype_name or args.dtype}",
-                "ms_per_step": round(dt / args.other_steps * 1e3, 4), "tokens_per_s": round(NB * w["T"] / (dt / args.other_steps), 1),
-                "steps": args.other_steps, "graph": lb.graph is not None, "attention_path": path,
-                "attention_path_ab": ab.get("candidates"), "roofline": roof}
+        res = {"workload": f"{wname} H={w['H']} d={w['d']} T={w['T']} k={w['k']} predictor_length={w['T_M']}, batch {NB}/GPU, "
+                           f"{dtype_name}, context_layer {ctx_dtype_name}",
+               "ms_per_step": round(dt / steps * 1e3, 4), "tokens_per_s": round(NB * w["T"] / (dt / steps), 1),
+               "steps": steps, "graph": lb.graph is not None, "attention_path": path,
+               "attention_path_ab": ab.get("candidates"), "roofline": roof}
+        if want_regions:
+            bench = lb.S.get_bench()
+            bench.disabled, bench.synchronize = False, True
+            bench.reset_measures()
+            lb.layer.attention.sparse_kernel = path
+            for _ in range(3):
+                lb.forward()
+            lb.torch.cuda.synchronize()
+            res["regions_ms"] = {k_: round(v_ * 1e3, 4) for k_, v_ in sorted(bench.todict().items())}
+            bench.disabled, bench.synchronize = True, False
+            bench.reset_measures()
+        return res
     finally:
         lb.release()
+
+
+# the reference's own ablation grid: src/main/benchmark_opt_ablation.py:160-186 (one opt-125m layer, bsize 1, seq_len 2048,
+# ks x ws) + the long-context point of src/main/exp_long_context.py:152 (T_M = 96, k = 128; opt-125m, 4096 tokens)
+GRID_POINTS = [(2048, k_, w_) for k_ in (32, 64, 128) for w_ in (64, 128, 256, 384)] + [(4096, 128, 96)]
+
+
+def grid_leg(args, dev):
+    pts = {}
+    for T_, k_, w_ in GRID_POINTS:
+        try:
+            r = short_leg("opt-125m", 1, args, dev, override=dict(T=T_, k=k_, T_M=w_), sparse_kernel="auto", steps=max(10, args.other_steps))
+            pts[f"k:{k_},w:{w_},l:{T_}"] = {"ms_per_step": r["ms_per_step"], "attention_ms": (r["roofline"] or {}).get("avg_launch_ms"),
+                                           "graph": r["graph"], "nnz": (r["roofline"] or {}).get("nnz")}
+        except Exception as e:
+            pts[f"k:{k_},w:{w_},l:{T_}"] = {"error": f"{type(e).__name__}: {e}"[:200]}
+    return {"protocol": "src/main/benchmark_opt_ablation.py:160-186 (perlin, nbf 8, one opt-125m layer H=12 d=64, batch 1, T=2048; k x w) + "
+                        "exp_long_context.py:152 (T_M=96, k=128, T=4096); latency of the SEA attention layer forward in ms, "
+                        f"{args.dtype} data, context_layer fp32 (module defaults), HIP-graph replay + eager attention launch; every "
+                        "point on the fused estimator kernels (tests/test_gpu_grid.py asserts it)",
+            "points": pts}
+
+
+def decode_leg(layer, q, kk, v, mask, NB, T, positions):
+    """Generation (the reference's loop: src/main/opt_generate.py:131): one position per step from a prefix, the
+    step's launches replayed as one HIP graph (DecodeSession); every sequence of the batch advances together."""
+    import copy
+    import torch
+    from sea_attention_amd.perlin_attention.decode import DecodeSession
+    lc_ = copy.deepcopy(layer)
+    lc_.pconfig = copy.copy(layer.pconfig); lc_.pconfig.use_cache = True
+    lc_.attention.pconfig = lc_.pconfig
+    nd = max(1, min(positions, T // 2))
+    T0 = T - nd - 8
+    with torch.no_grad():
+        pre = lc_(None, None, None, query_layer=q[:NB, :, :T0], key_layer=kk[:NB, :, :T0], value_layer=v[:NB, :, :T0],
+                  attention_mask=mask[:NB, :, :T0, :T0].contiguous())
+        sess = DecodeSession(lc_.attention, pre.state, kk[:NB, :, :T0], v[:NB, :, :T0], capacity=T, use_graph=True)
+        for i in range(4):
+            sess.step(q[:NB, :, T0 + i:T0 + i + 1], kk[:NB, :, T0 + i:T0 + i + 1], v[:NB, :, T0 + i:T0 + i + 1])
+        torch.cuda.synchronize(); t0_ = time.perf_counter()
+        for i in range(4, 4 + nd):
+            sess.step(q[:NB, :, T0 + i:T0 + i + 1], kk[:NB, :, T0 + i:T0 + i + 1], v[:NB, :, T0 + i:T0 + i + 1])
+        torch.cuda.synchronize()
+        t_pos = (time.perf_counter() - t0_) / nd
+    del sess, lc_, pre
+    return {"ms_per_position": round(t_pos * 1e3, 4), "tokens_per_s": round(NB / t_pos, 1), "batch": NB, "prefix_tokens": T0,
+            "positions_timed": nd}
 
 
 def train_step_leg(wname, args, dev):
@@ -438,7 +525,8 @@ def train_step_leg(wname, args, dev):
         Z = int(csr.crow[:, -1].sum().item())
         return {"workload": f"{wname} sparse branch forward + backward, 1 sequence x {T} tokens, {args.dtype}, nnz {Z}",
                 "ms_per_step": round(ms, 4), "tokens_per_s": round(T / (ms / 1e3), 1), "grads_finite": fin,
-                "note": "ops.sparse_attention_autograd: sea_sparse_attention_ex (per-entry probabilities saved) + sea_sparse_attention_bwd"}
+                "note": "ops.sparse_attention_autograd: sea_sparse_attention_ex (per-entry probabilities saved) + "
+                        "sea_sparse_attention_bwd_gather (dK / dV gathered over the transposed pattern, no float atomics)"}
     finally:
         lb.release()
 
@@ -552,14 +640,15 @@ def main(argv=None):
     w = WORKLOADS[args.workload]
     H, d, T, T_M, k = w["H"], w["d"], w["T"], w["T_M"], w["k"]
     NB = args.batch
-    lb = LayerBench(args.workload, NB, args.dtype, dev, inspect_padding=args.inspect_padding, seed_offset=rank)
+    lb = LayerBench(args.workload, NB, args.dtype, dev, ctx_dtype_name="fp32" if args.context_dtype == "fp32" else args.dtype,
+                    inspect_padding=args.inspect_padding, seed_offset=rank)
     dtype = lb.dtype
     layer, q, kk, v, mask = lb.layer, lb.q, lb.k, lb.v, lb.mask
     bench = S.get_bench()
 
     # N > 1: the all-gather of step i (RCCL, its own stream) overlaps the compute of step i+1 -- two slots of
     # (local shard, gathered output); every collective is awaited before the timed region ends (gather.finish()).
-    gather = D.ContextGatherer((NB, T, H * d), NB * world, dtype, dev) if world > 1 else None
+    gather = D.ContextGatherer((NB, T, H * d), NB * world, lb.ctx_dtype, dev) if world > 1 else None
 
     def sync_all():
         if world > 1:
@@ -655,7 +744,7 @@ def main(argv=None):
         dist.all_reduce(t_ag, op=dist.ReduceOp.MAX)
         comp_ms = float(t_comp.item()) / args.steps * 1e3
         ag_ms = float(t_ag.item()) / args.steps * 1e3
-        shard_bytes = NB * T * H * d * torch.tensor([], dtype=dtype).element_size()
+        shard_bytes = NB * T * H * d * torch.tensor([], dtype=lb.ctx_dtype).element_size()
         collective = {"backend": dist.get_backend(), "ranks": dist.get_world_size(),
                       "compute_only_ms_per_step": round(comp_ms, 4),
                       "allgather_alone_ms": round(ag_ms, 4),
@@ -796,31 +885,13 @@ def main(argv=None):
     # ---- generation leg: one position per step from a (T - 64)-token prefix, the step replayed as a HIP graph
     decode = None
     if args.decode_steps > 0 and world == 1 and dtype != torch.float32:
-        try:
-            import copy
-            from sea_attention_amd.perlin_attention.decode import DecodeSession
-            lc_ = copy.deepcopy(layer)
-            lc_.pconfig = copy.copy(layer.pconfig); lc_.pconfig.use_cache = True
-            lc_.attention.pconfig = lc_.pconfig
-            T0 = T - 64
-            with torch.no_grad():
-                pre = lc_(None, None, None, query_layer=q[:, :, :T0], key_layer=kk[:, :, :T0], value_layer=v[:, :, :T0],
-                          attention_mask=mask[:, :, :T0, :T0].contiguous())
-                sess = DecodeSession(lc_.attention, pre.state, kk[:, :, :T0], v[:, :, :T0], capacity=T, use_graph=True)
-                nd = min(args.decode_steps, 60)
-                for i in range(4):
-                    sess.step(q[:, :, T0 + i:T0 + i + 1], kk[:, :, T0 + i:T0 + i + 1], v[:, :, T0 + i:T0 + i + 1])
-                torch.cuda.synchronize(); t0_ = time.perf_counter()
-                for i in range(4, 4 + nd):
-                    sess.step(q[:, :, T0 + i:T0 + i + 1], kk[:, :, T0 + i:T0 + i + 1], v[:, :, T0 + i:T0 + i + 1])
-                torch.cuda.synchronize()
-                t_pos = (time.perf_counter() - t0_) / nd
-            decode = {"ms_per_position": round(t_pos * 1e3, 4), "tokens_per_s": round(NB / t_pos, 1), "prefix_tokens": T0,
-                      "positions_timed": nd, "note": "DecodeSession: fixed-capacity caches, position in device memory, "
-                      "the step's launches replayed as one HIP graph; all sequences of the batch advance together"}
-            del sess, lc_, pre
-        except Exception as e:                                   # an extra leg never takes the headline line down
-            decode = {"error": f"{type(e).__name__}: {e}"[:200]}
+        decode = {"note": "DecodeSession: fixed-capacity caches, position in device memory, the step's launches replayed as one HIP "
+                          "graph; all sequences of a batch advance together (reference loop: src/main/opt_generate.py:131)"}
+        for nb_ in sorted({1, NB}):
+            try:
+                decode[f"batch_{nb_}"] = decode_leg(layer, q, kk, v, mask, nb_, T, args.decode_steps)
+            except Exception as e:                                   # an extra leg never takes the headline line down
+                decode[f"batch_{nb_}"] = {"error": f"{type(e).__name__}: {e}"[:200]}
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -853,7 +924,9 @@ def main(argv=None):
     headline_workload = (f"{args.workload} SEA attention layer forward (sparse mode, steps A-L), "
                          f"H={H} d={d} T={T} k={k} predictor_length={T_M} nbf={w['nbf']}, "
                          f"batch {NB} sequences/GPU, random-init weights seed 42, "
-                         f"context_layer {args.dtype} (reference default: fp32 -- see context_fp32), "
+                         + (f"context_layer fp32 (the module's and the reference's default, flat_csr_sdbmm.py:347; the {args.dtype} "
+                            f"twin: context_{args.dtype}), " if args.context_dtype == "fp32" else
+                            f"context_layer {args.dtype} (reference default: fp32), ")
                          + ("unpadded batch declared to the module (assume_not_padded: no mask inspection sync)"
                             if not args.inspect_padding else "module inspects the mask for padding (one host sync)")
                          + f", sparse kernel path {path}"
@@ -861,20 +934,23 @@ def main(argv=None):
                          + (", layer replayed as a HIP graph + eager fused-attention launch" if graph_on else ", eager launches"))
 
     # ---- the other BASELINE shapes + the reference-default (fp32 context) twin of the headline: short legs, rank 0's GPU ----
-    other, ctx32, train = None, None, None
+    other, ctx_twin, train, fp32_leg, grid = None, None, None, None, None
     del out, ctx, q, kk, v, mask, layer
     lb.release()
     if gather is not None:
         del gather
     torch.cuda.empty_cache()
     _stage("short legs")
+    twin_name = f"context_{args.dtype}" if args.context_dtype == "fp32" else "context_fp32"
     if world == 1 and not args.no_other_workloads:
         other = {}
-        try:
-            ctx32 = short_leg(args.workload, NB, args, dev, ctx_dtype_name="fp32")
-            ctx32["tokens_per_s_note"] = "the headline layer writing context_layer in fp32, the reference's default (flat_csr_sdbmm.py:347)"
+        try:   # the headline with the OTHER context dtype: the tuned 16-bit output (default run) or the reference's fp32
+            ctx_twin = short_leg(args.workload, NB, args, dev, ctx_dtype_name=args.dtype if args.context_dtype == "fp32" else "fp32")
+            ctx_twin["tokens_per_s_note"] = ("the headline layer writing context_layer in the data dtype (a tuned configuration: the module "
+                                             "default is fp32)" if args.context_dtype == "fp32" else
+                                             "the headline layer writing context_layer in fp32, the reference's default (flat_csr_sdbmm.py:347)")
         except Exception as e:
-            ctx32 = {"error": f"{type(e).__name__}: {e}"[:300]}
+            ctx_twin = {"error": f"{type(e).__name__}: {e}"[:300]}
         for wn, nb_ in OTHER_LEGS:
             if wn == args.workload and nb_ == NB:
                 continue
@@ -883,6 +959,24 @@ def main(argv=None):
                 other[f"{wn} x{nb_}"] = short_leg(wn, nb_, args, dev)
             except Exception as e:                               # a leg never takes the headline down; its failure is visible
                 other[f"{wn} x{nb_}"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if not args.no_fp32_leg and args.dtype != "fp32":
+            # BASELINE config 2 lists fp32 and the reference's measurement protocol is fp32 (benchmark_bert.py:196-239): the same
+            # layer on fp32 DATA.  Steps H..L run on the HIP kernels; the estimator runs the fp32-MFMA Performer, library GEMMs
+            # for the three Linears, the HIP LayerNorm / tail kernels and the framework's convolutions (no C8 form for fp32)
+            _stage("fp32-data leg (config 2)")
+            try:
+                fp32_leg = short_leg("opt-125m", 8, args, dev, dtype_name="fp32", want_regions=True)
+                ref16 = (other.get("opt-125m x8") or {}).get("ms_per_step")
+                if ref16:
+                    fp32_leg["ratio_to_16bit_data"] = round(fp32_leg["ms_per_step"] / ref16, 3)
+            except Exception as e:
+                fp32_leg = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if not args.no_grid and args.dtype != "fp32":
+            _stage("reference grid leg")
+            try:
+                grid = grid_leg(args, dev)
+            except Exception as e:
+                grid = {"error": f"{type(e).__name__}: {e}"[:300]}
         if not args.no_train_step and args.dtype != "fp32":
             _stage("train-step leg")
             try:
@@ -900,7 +994,8 @@ def main(argv=None):
                        "parallelism": f"dp{world} (batch shards)"},
             "graph": graph_on, "graph_capture_error": capture_error,
             "roofline": roof, "cpu_baseline": cpu, "output_check": output_check, "attention_path_ab": ab,
-            "collective": collective, "context_fp32": ctx32, "other_workloads": other, "train_step": train,
+            "collective": collective, twin_name: ctx_twin, "other_workloads": other, "fp32_data": fp32_leg,
+            "reference_grid": grid, "train_step": train,
             "kernel_path": kernel_path, "decode": decode,
             "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 3),
             "regions_ms": {k_: round(v_ * 1e3, 4) for k_, v_ in sorted(regions.items())},

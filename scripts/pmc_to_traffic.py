@@ -24,9 +24,13 @@ for sub in ("FETCH_SIZE", "WRITE_SIZE", "TCC_HIT_sum_TCC_MISS_sum_TCC_REQ_sum"):
         w = csv.DictWriter(fo, fieldnames=rd.fieldnames); w.writeheader(); w.writerows(keep)
 log = [l for l in open(os.path.join(src, "FETCH_SIZE.log")).read().splitlines() if l.startswith("{")]
 bench_line = json.loads(log[-1]) if log else {}
-out = {"round": 3, "build": note, "kernel_source_sha256": _attn_source_sha(),
-       "command": "rocprofv3 --kernel-trace --pmc <C> -- python3 bench.py --steps 3 --warmup 1 --prewarm 2 --no-cpu-baseline "
-                  "--kernel-iters 0 --no-output-check  (opt-1.3b, batch 8, bf16; one pass per counter set; in-layer launches)",
+cmd_file = os.path.join(src, "command.txt")                 # written by scripts/gpu_pmc.sh: the command the passes really ran
+ab = bench_line.get("attention_path_ab") or {}
+wl = (bench_line.get("config") or {}).get("workload", "")
+out = {"round": 4, "build": note, "kernel_source_sha256": _attn_source_sha(),
+       "command": open(cmd_file).read().strip() if os.path.exists(cmd_file) else "(scripts/gpu_pmc.sh; command file missing)",
+       "attention_path": ab.get("chosen") or ab.get("requested"),
+       "context_dtype": "torch.float32" if "context_layer fp32" in wl else ("torch.bfloat16" if "context_layer bf16" in wl else None),
        "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the bench command itself (in-layer launches), gfx950 correction applied",
        "correction": "gfx950: FETCH_SIZE counts 64 B per 128-B request for 16 B/lane loads -> hbm = (2*FETCH_SIZE + WRITE_SIZE)*1024 (MI355X_MICROARCH.md, HBM)",
        "workload": bench_line.get("config", {}).get("workload"), "nnz": (bench_line.get("roofline") or {}).get("nnz"), "kernels": {}}
@@ -38,6 +42,7 @@ for name, c in acc.items():
                             "l2_requests_per_launch": int(req), "l2_hit_rate": round(hit / (hit + miss), 4) if hit + miss else None}
     if "sparse_attn" in name:          # per-block dispatch launches the gather AND the tile kernel: the step's traffic is their sum
         out["sea_sparse_attention_hbm_bytes_per_launch"] = out.get("sea_sparse_attention_hbm_bytes_per_launch", 0) + int((2 * fs + ws) * 1024)
+        out["sea_sparse_attention_l2_requests_per_launch"] = out.get("sea_sparse_attention_l2_requests_per_launch", 0) + int(req)
 for dst in (f"{tag}_pmc_traffic.json", "traffic_latest.json"):
     json.dump(out, open(os.path.join(ROOT, "profiles", dst), "w"), indent=1)
 print(json.dumps({k: (v["hbm_bytes_per_launch_corrected"], v["l2_requests_per_launch"], v["l2_hit_rate"]) for k, v in out["kernels"].items()}, indent=1))
