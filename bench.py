@@ -72,6 +72,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-grid", action="store_true",
                     help="skip the reference's own ablation grid (benchmark_opt_ablation.py:160-186: opt-125m layer, batch 1, T = 2048, "
                          "k in {32, 64, 128} x predictor length in {64, 128, 256, 384}, + exp_long_context.py:152's T_M = 96 / k = 128)")
+    ap.add_argument("--no-long-context", action="store_true", help="skip the 32768-token leg (opt-125m shape, one sequence)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32-DATA leg at BASELINE config 2 (B=8 H=12 T=2048 d=64)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the forward + backward leg of the sparse branch")
     ap.add_argument("--decode-steps", type=int, default=200,
@@ -934,7 +935,7 @@ def main(argv=None):
                          + (", layer replayed as a HIP graph + eager fused-attention launch" if graph_on else ", eager launches"))
 
     # ---- the other BASELINE shapes + the reference-default (fp32 context) twin of the headline: short legs, rank 0's GPU ----
-    other, ctx_twin, train, fp32_leg, grid = None, None, None, None, None
+    other, ctx_twin, train, fp32_leg, grid, long_ctx = None, None, None, None, None, None
     del out, ctx, q, kk, v, mask, layer
     lb.release()
     if gather is not None:
@@ -971,6 +972,14 @@ def main(argv=None):
                     fp32_leg["ratio_to_16bit_data"] = round(fp32_leg["ms_per_step"] / ref16, 3)
             except Exception as e:
                 fp32_leg = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if not args.no_long_context and args.dtype != "fp32":
+            # context extension (perlin_trainer.py:533-566): one 32768-token sequence, T / T_M = 128 > k -- every pixel of a late
+            # row is thinned to max_k entries by the reference's fp32 stepping (causal_resize_m_to_t.py:565-569,657-659)
+            _stage("long-context leg")
+            try:
+                long_ctx = short_leg("opt-125m", 1, args, dev, override=dict(T=32768))
+            except Exception as e:
+                long_ctx = {"error": f"{type(e).__name__}: {e}"[:300]}
         if not args.no_grid and args.dtype != "fp32":
             _stage("reference grid leg")
             try:
@@ -995,7 +1004,7 @@ def main(argv=None):
             "graph": graph_on, "graph_capture_error": capture_error,
             "roofline": roof, "cpu_baseline": cpu, "output_check": output_check, "attention_path_ab": ab,
             "collective": collective, twin_name: ctx_twin, "other_workloads": other, "fp32_data": fp32_leg,
-            "reference_grid": grid, "train_step": train,
+            "reference_grid": grid, "long_context": long_ctx, "train_step": train,
             "kernel_path": kernel_path, "decode": decode,
             "host_enqueue_ms_per_step": round(t_enqueued / args.steps * 1e3, 3),
             "regions_ms": {k_: round(v_ * 1e3, 4) for k_, v_ in sorted(regions.items())},
