@@ -72,6 +72,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-grid", action="store_true",
                     help="skip the reference's own ablation grid (benchmark_opt_ablation.py:160-186: opt-125m layer, batch 1, T = 2048, "
                          "k in {32, 64, 128} x predictor length in {64, 128, 256, 384}, + exp_long_context.py:152's T_M = 96 / k = 128)")
+    ap.add_argument("--gather-chunks", type=int, default=1,
+                    help="N > 1: cut every step's context shard into this many groups of sequences, each written by its own "
+                         "attention launch and sent by its own in-place all-gather as soon as that launch is enqueued "
+                         "(distributed.ChunkedContextGatherer); 1 = one launch, one collective per step")
     ap.add_argument("--no-long-context", action="store_true", help="skip the 32768-token leg (opt-125m shape, one sequence)")
     ap.add_argument("--no-fp32-leg", action="store_true", help="skip the fp32-DATA leg at BASELINE config 2 (B=8 H=12 T=2048 d=64)")
     ap.add_argument("--no-train-step", action="store_true", help="skip the forward + backward leg of the sparse branch")
@@ -265,7 +269,7 @@ class LayerBench:
         self._pending = rec["a"][3]._pending
         return True
 
-    def step(self, out_view=None):
+    def step(self, out_view=None, chunk_views=None, after_chunk=None):
         """One step.  Graph mode: replay + the eager attention launch (optionally redirected into `out_view`, the rank's
         slot of the gathered buffer); returns (layer output tuple, context tensor written)."""
         torch = self.torch
@@ -278,10 +282,25 @@ class LayerBench:
             self.rec["a"][3]._pending = self._pending
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        self._real_attn(*self.rec["a"], **kw)
+        if chunk_views is None:
+            self._real_attn(*self.rec["a"], **kw)
+        else:
+            # one attention launch per group of sequences (FlatCSR.items: the same arrays, sliced), each writing its chunk of
+            # the gather slot; `after_chunk(c)` enqueues that chunk's collective behind it
+            q_, k_, v_, csr_ = self.rec["a"][:4]
+            n_c = self.NB // len(chunk_views)
+            cut = lambda t_, a_, b_: t_[a_:b_] if t_ is not None else None
+            for c, view in enumerate(chunk_views):
+                a_, b_ = c * n_c, (c + 1) * n_c
+                kw_c = dict(kw, out=view, row_scale=cut(kw.get("row_scale"), a_, b_), avg=cut(kw.get("avg"), a_, b_),
+                            mix=cut(kw.get("mix"), a_, b_))
+                self._real_attn(q_[a_:b_], k_[a_:b_], v_[a_:b_], csr_.items(a_, b_), *self.rec["a"][4:], **kw_c)
+                if after_chunk is not None:
+                    after_chunk(c)
+            csr_._pending = None                              # every part's launch has written its columns
         e1.record()
         self.attn_events.append((e0, e1))
-        return self.g_out, (self.g_out.context_layer if out_view is None else None)
+        return self.g_out, (self.g_out.context_layer if (out_view is None and chunk_views is None) else None)
 
     def attn_ms(self):
         if not self.attn_events:
@@ -542,11 +561,19 @@ def cpu_rehearsal(args, world, rank):
     from sea_attention_amd import distributed as D
     w = WORKLOADS[args.workload]
     NB, T, C = args.batch, 64, 32
-    gather = D.ContextGatherer((NB, T, C), NB * world, torch.float32, "cpu") if world > 1 else None
+    chunks = max(1, args.gather_chunks)
+    assert NB % chunks == 0, "--gather-chunks must divide the per-GPU batch"
+    gather = (D.ChunkedContextGatherer((NB, T, C), NB * world, torch.float32, "cpu", chunks=chunks) if chunks > 1
+              else D.ContextGatherer((NB, T, C), NB * world, torch.float32, "cpu"))
     ok = True
 
     def step(i):
         slot = gather.next_slot()
+        if chunks > 1:
+            for c in range(chunks):
+                gather.local_chunk(slot, c).fill_(float(1000 * rank + i))
+                gather.launch_chunk(slot, c)
+            return slot, None
         gather.local[slot].fill_(float(1000 * rank + i))
         return slot, gather.launch(slot)
     for i in range(args.warmup):
@@ -560,7 +587,7 @@ def cpu_rehearsal(args, world, rank):
     gather.finish()
     dist.barrier()
     elapsed = time.perf_counter() - t0
-    full = last[1]
+    full = last[1] if chunks == 1 else gather.gathered_items(last[0])
     for r in range(world):
         ok &= bool((full[r * NB:(r + 1) * NB] == float(1000 * r + args.steps - 1)).all())
     t = torch.tensor([elapsed], dtype=torch.float64)
@@ -577,7 +604,7 @@ def cpu_rehearsal(args, world, rank):
                          "timing protocol only -- the numbers mean nothing",
             "config": {"workload": f"REHEARSAL of {args.workload} (H={w['H']} d={w['d']} T={w['T']}): stand-in step",
                        "global_batch": NB * world, "seq_len": T, "parallelism": f"dp{world} (batch shards)"},
-            "collective": {"backend": dist.get_backend(), "ranks": dist.get_world_size()},
+            "collective": {"backend": dist.get_backend(), "ranks": dist.get_world_size(), "chunks_per_step": chunks},
             "output_check": {"status": "ok" if flag.item() == 1.0 else "FAILED", "gathered_shards_match_their_ranks": bool(flag.item() == 1.0)},
             "roofline": None, "cpu_baseline": None}))
     dist.barrier()
@@ -616,12 +643,19 @@ def main(argv=None):
     import torch
     import torch.distributed as dist
     have_gpu = torch.cuda.is_available()
+    rccl_log = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if args.rehearse:
             local_rank = 0
         if have_gpu:
             torch.cuda.set_device(local_rank)
+        if not args.rehearse:
+            # RCCL reports the algorithm / protocol / transports it picks into a per-process file; rank 0 parses its own
+            # after the run (`collective.rccl`).  setdefault: a caller's own NCCL_DEBUG settings win
+            rccl_log = os.environ.setdefault("NCCL_DEBUG_FILE", f"/tmp/sea_bench_rccl_{os.getpid()}_%h_%p.log")
+            os.environ.setdefault("NCCL_DEBUG", "INFO")
+            os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,TUNING")
         dist.init_process_group("gloo" if args.rehearse else "nccl", rank=rank, world_size=world)
         assert dist.get_world_size() == args.gpus
     if args.rehearse and not have_gpu:
@@ -649,7 +683,14 @@ def main(argv=None):
 
     # N > 1: the all-gather of step i (RCCL, its own stream) overlaps the compute of step i+1 -- two slots of
     # (local shard, gathered output); every collective is awaited before the timed region ends (gather.finish()).
-    gather = D.ContextGatherer((NB, T, H * d), NB * world, lb.ctx_dtype, dev) if world > 1 else None
+    chunks = max(1, args.gather_chunks) if world > 1 else 1
+    if chunks > 1 and NB % chunks:
+        print(f"[bench] --gather-chunks {chunks} does not divide the per-GPU batch {NB}", file=sys.stderr)
+        return 2
+    gather = None
+    if world > 1:
+        gather = (D.ChunkedContextGatherer((NB, T, H * d), NB * world, lb.ctx_dtype, dev, chunks=chunks) if chunks > 1
+                  else D.ContextGatherer((NB, T, H * d), NB * world, lb.ctx_dtype, dev))
 
     def sync_all():
         if world > 1:
@@ -665,6 +706,19 @@ def main(argv=None):
         if world == 1:
             return lb.step()
         slot = gather.next_slot()
+        if chunks > 1:
+            n_c = NB // chunks
+            views = [gather.local_chunk(slot, c).view(n_c, T, H, d).permute(0, 2, 1, 3) for c in range(chunks)]
+            send = (lambda c: gather.launch_chunk(slot, c)) if do_gather else None
+            if lb.graph is not None:                       # one attention launch + one collective per group of sequences
+                out, _ = lb.step(chunk_views=views, after_chunk=send)
+            else:
+                out, ctx_ = lb.step()
+                for c in range(chunks):
+                    gather.local_chunk(slot, c).copy_(ctx_[c * n_c:(c + 1) * n_c])
+                    if send is not None:
+                        send(c)
+            return out, (lambda: gather.gathered_items(slot))
         if lb.graph is not None:                           # the attention kernel writes straight into this step's gather slot
             out, _ = lb.step(out_view=slot_view(slot))
         else:
@@ -738,11 +792,23 @@ def main(argv=None):
         sync_all()
         t2 = time.perf_counter()
         for _ in range(args.steps):                        # back-to-back all-gathers of one slot, each awaited
-            gather.launch(0)
+            if chunks > 1:
+                for c in range(chunks):
+                    gather.launch_chunk(0, c)
+            else:
+                gather.launch(0)
             gather.finish()
         torch.cuda.synchronize()
         t_ag = torch.tensor([time.perf_counter() - t2], device=dev, dtype=torch.float64)
         dist.all_reduce(t_ag, op=dist.ReduceOp.MAX)
+        rccl_info = None
+        if rank == 0 and rccl_log is not None:             # what RCCL says it chose (algorithm / protocol / transports)
+            try:
+                import glob
+                txt = "".join(open(f_, errors="replace").read() for f_ in sorted(glob.glob(rccl_log.replace("%h", "*").replace("%p", "*"))))
+                rccl_info = D.parse_nccl_debug(txt)
+            except Exception as e_:
+                rccl_info = {"error": f"{type(e_).__name__}: {e_}"[:200]}
         comp_ms = float(t_comp.item()) / args.steps * 1e3
         ag_ms = float(t_ag.item()) / args.steps * 1e3
         shard_bytes = NB * T * H * d * torch.tensor([], dtype=lb.ctx_dtype).element_size()
@@ -750,6 +816,7 @@ def main(argv=None):
                       "compute_only_ms_per_step": round(comp_ms, 4),
                       "allgather_alone_ms": round(ag_ms, 4),
                       "allgather_exposed_ms_per_step": round(max(0.0, ms_per_step - comp_ms), 4),
+                      "chunks_per_step": chunks, "rccl": rccl_info,
                       "shard_bytes": shard_bytes, "received_bytes_per_rank": shard_bytes * (world - 1),
                       "allgather_alone_GBs_per_rank": round(shard_bytes * (world - 1) / (ag_ms / 1e3) / 1e9, 1),
                       "note": "compute_only = the same steps without launching the collective (the N=1-equivalent per-GPU step, "
@@ -776,6 +843,8 @@ def main(argv=None):
     if not args.no_output_check:
         with torch.no_grad():
             # N > 1 in graph mode: the attention launch wrote this rank's shard straight into the gathered buffer
+            if callable(ctx):                              # chunked gather: the rank-major copy of the last step's slot
+                ctx = ctx()
             ctx_b = ctx[rank * NB:(rank + 1) * NB] if world > 1 else out.context_layer
             probs_b = out.estimated_attention_probs_m
             keep_t = ops.keep_table_causal(H, T, T_M, k, device=dev)

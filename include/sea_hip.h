@@ -29,7 +29,13 @@
 extern "C" {
 #endif
 
-#define SEA_ABI_VERSION 1
+/* ABI version, returned by sea_version(); the Python binding refuses a library of another version (a stale .so next to newer
+ * Python, or the other way round, through SEA_HIP_LIB).  History of INCOMPATIBLE changes of existing entry points:
+ *   1  rounds 1-2
+ *   2  round 3: sea_performer_causal_step / _at read k / v / pos FROM THE LAST CHUNK BOUNDARY (T + t_base % C rows) and take the
+ *      state image at that boundary;  round 4: sea_predictor_mlp's w2_packed / vectors pad every decoder half to whole
+ *      16-row tiles (identical for Wd % 16 == 0), sea_predictor_tail_select accepts probs = NULL and any T_m % 4 == 0 <= 512 */
+#define SEA_ABI_VERSION 2
 
 enum sea_dtype { SEA_F32 = 0, SEA_F16 = 1, SEA_BF16 = 2 };
 

@@ -9,6 +9,7 @@ import torch
 from . import _build
 
 SEA_F32, SEA_F16, SEA_BF16 = 0, 1, 2
+ABI_VERSION = 2            # include/sea_hip.h: SEA_ABI_VERSION
 _DTYPES = {torch.float32: SEA_F32, torch.float16: SEA_F16, torch.bfloat16: SEA_BF16}
 
 _lib = None
@@ -106,8 +107,9 @@ def load(build_if_missing=True):
         fn = getattr(lib, name)          # AttributeError if the symbol is not exported
         fn.argtypes = argtypes
         fn.restype = restype
-    if lib.sea_version() != 1:
-        raise RuntimeError(f"{path}: ABI version {lib.sea_version()}, this binding speaks 1")
+    if lib.sea_version() != ABI_VERSION:
+        raise RuntimeError(f"{path}: ABI version {lib.sea_version()}, this binding speaks {ABI_VERSION} (include/sea_hip.h: "
+                           "SEA_ABI_VERSION lists what changed) -- rebuild the library from this tree's csrc/")
     _lib = lib
     return lib
 

@@ -349,8 +349,12 @@ __global__ __launch_bounds__(NWB * 64) void sparse_attn_bwd_cols_kernel(BwdGathe
   const int grp_lane0 = (lane - sub) << 2;
   for (int i0 = 0; i0 < zmax; i0 += LPR) {
     const int e_mine = beg + i0 + sub;
-    uint4 rm = make_uint4(0, 0, 0, 0);                     // t = 0, p = 0, ds = 0: a finite row, zero weights
-    if (e_mine < end) rm = *reinterpret_cast<const uint4*>(recs + e_mine);
+    // padding slots (lists shorter than the wave's longest) carry zero weights and point at the key's OWN last record: the
+    // q / dO rows they gather are rows that contribute to this key anyway -- never an unrelated row 0 whose Inf / NaN
+    // (an fp16 loss-scale overflow step) would reach this key as 0 * Inf; keys without records: zeroed below
+    uint4 rm = make_uint4(0, 0, 0, 0);
+    if (end > beg) rm = *reinterpret_cast<const uint4*>(recs + (e_mine < end ? e_mine : end - 1));
+    if (e_mine >= end) { rm.y = 0u; rm.z = 0u; }
 #pragma unroll
     for (int u0 = 0; u0 < LPR; u0 += U) {
       if (i0 + u0 < zmax) {                                // wave-uniform
@@ -384,6 +388,10 @@ __global__ __launch_bounds__(NWB * 64) void sparse_attn_bwd_cols_kernel(BwdGathe
         }
       }
     }
+  }
+  if (end == beg) {                                        // no query keeps this key: exact zeros, whatever the padding gathered
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { dk[j] = 0.f; dv[j] = 0.f; }
   }
   if (keyok && dact) {
     const int64_t ro = (((int64_t)n * p.H + h) * p.T_src + key) * p.D + d0;

@@ -229,7 +229,8 @@ class PerlinAttention(nn.Module):
         the fused gather kernels cover, the CSR's column array is left to the attention launch.  "auto" takes it wherever
         it exists: fused gather beats emit + the better of {gather, tile} on every map measured (OPT-1.3B x 8: layer's own
         0.99 + 0.03 vs 0.96 + 0.18 ms, structured 0.98 vs tile 0.90 + 0.18; LLaMA-13B: gather wins anyway); the plan-based
-        choice between the two kernels remains for shapes without a fused form (d = 80)."""
+        choice between the two kernels remains for shapes without a fused form (rows narrower than 8 or wider than 16 lanes,
+        T_M % 32 != 0, a decoding step's few rows: `ops.fused_interp_supported`; 16-bit d = 64 / 80 / 128 all have one)."""
         rows = q.shape[0] * q.shape[1] * q.shape[2]              # a decoding step's few rows take the wave-per-row kernel
         return self.sparse_kernel in ("gather", "auto") and ops.fused_interp_supported(q.dtype, q.shape[-1], T_M, rows)
 

@@ -108,18 +108,23 @@ class PerlinSelfAttention(nn.Module):
         # (`want_attention_probs`: the OPT block's output_attentions=True); it is put back afterwards, so switching
         # `checkout_last_attention_probs` off again also stops the extra per-entry store
         att = self.attention
-        flag_before = att.return_attention_probs
-        att.return_attention_probs = bool(flag_before or self.checkout_last_attention_probs or self.want_attention_probs)
-        try:
-            if self._gradient_checkpointing and self.training:
-                def run(*a):
-                    return tuple(self.attention(*a))
-                output = PerlinAttentionOutput(*torch.utils.checkpoint.checkpoint(
-                    run, *args, use_reentrant=True, preserve_rng_state=True))
-            else:
-                output = self.attention(*args)
-        finally:
-            att.return_attention_probs = flag_before
+        want = bool(att.return_attention_probs or self.checkout_last_attention_probs or self.want_attention_probs)
+
+        def run(*a):
+            # the flag is set and restored INSIDE the function that runs the attention: a checkpointed backward calls `run`
+            # again after this forward has returned, and must see the very flag the forward saw (same outputs, same
+            # per-entry stores) whatever the module's attribute says by then
+            before = att.return_attention_probs
+            att.return_attention_probs = want
+            try:
+                return tuple(self.attention(*a))
+            finally:
+                att.return_attention_probs = before
+        if self._gradient_checkpointing and self.training:
+            output = PerlinAttentionOutput(*torch.utils.checkpoint.checkpoint(
+                run, *args, use_reentrant=True, preserve_rng_state=True))
+        else:
+            output = PerlinAttentionOutput(*run(*args))
 
         if self.checkout_last_attention_probs:
             self.last_attention_probs = output.partial_attention_probs

@@ -32,10 +32,19 @@ def test_gpus2_self_launches_two_ranks_and_reports_them():
     assert "launching 2 ranks" in r.stderr
     line = _line(r.stdout)
     assert line["n_gpus"] == 2 and line["steps"] == 3 and line["warmup"] == 1
-    assert line["collective"] == {"backend": "gloo", "ranks": 2}
+    assert line["collective"] == {"backend": "gloo", "ranks": 2, "chunks_per_step": 1}
     assert line["config"]["global_batch"] == 2 * 8 and line["config"]["parallelism"].startswith("dp2")
     assert line["output_check"]["status"] == "ok" and line["output_check"]["gathered_shards_match_their_ranks"] is True
     assert "rehearsal" in line and line["scaling"] == "weak"
+
+
+def test_gpus2_with_the_shard_cut_into_chunks():
+    # round 4: every step's shard in 4 groups of sequences, each with its own in-place all-gather (ChunkedContextGatherer)
+    r = _run(["--gpus", "2", "--rehearse", "--steps", "3", "--warmup", "1", "--gather-chunks", "4"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = _line(r.stdout)
+    assert line["n_gpus"] == 2 and line["collective"] == {"backend": "gloo", "ranks": 2, "chunks_per_step": 4}
+    assert line["output_check"]["status"] == "ok" and line["output_check"]["gathered_shards_match_their_ranks"] is True
 
 
 def test_gpus_must_match_the_world_the_launcher_made():

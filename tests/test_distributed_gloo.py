@@ -192,3 +192,64 @@ def test_estimator_row_cuts_are_whole_chunks():
         assert cuts[0][0] == 0 and max(hi for _, hi in cuts) == T
         assert all(a[1] == b[0] or b[1] == b[0] for a, b in zip(cuts, cuts[1:]))
         assert all(lo % 64 == 0 for lo, hi in cuts if hi > lo)
+
+
+# ---- round 4: the all-gather cut into chunks of sequences -------------------------------------------------
+def _chunked_worker(rank, world, port, chunks, ret):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from sea_attention_amd import distributed as D
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    NB, T, C = 4, 6, 5
+    g = D.ChunkedContextGatherer((NB, T, C), NB * world, torch.float32, "cpu", chunks=chunks)
+    ref = D.ContextGatherer((NB, T, C), NB * world, torch.float32, "cpu")
+    ok = True
+    value = lambda r, step, i: float(1000 * r + 10 * step + i)          # item i of rank r at step `step`
+    for step in range(5):                                               # more steps than slots: the slots are re-used
+        slot = g.next_slot()
+        for c in range(chunks):                                         # producer of chunk c, then its collective
+            loc = g.local_chunk(slot, c)
+            assert loc.is_contiguous() and tuple(loc.shape) == (NB // chunks, T, C)
+            for i in range(g.n_c):
+                loc[i].fill_(value(rank, step, c * g.n_c + i))
+            g.launch_chunk(slot, c)
+        rslot = ref.next_slot()
+        for i in range(NB):
+            ref.local[rslot][i].fill_(value(rank, step, i))
+        full_ref = ref.launch(rslot)
+        g.finish(); ref.finish()
+        view = g.gathered(slot)                                         # (world, chunks, n_c, T, C)
+        assert tuple(view.shape) == (world, chunks, NB // chunks, T, C)
+        for r in range(world):
+            for i in range(NB):
+                ok &= bool((view[r, i // g.n_c, i % g.n_c] == value(r, step, i)).all())
+        ok &= bool(torch.equal(g.gathered_items(slot), full_ref))       # same items, same order as the one-piece gatherer
+    dist.barrier()
+    dist.destroy_process_group()
+    if not ok:
+        raise SystemExit(3)
+
+
+@pytest.mark.parametrize("world,chunks", [(2, 1), (2, 2), (2, 4), (3, 2)])
+def test_chunked_gatherer_equals_the_one_piece_gatherer(world, chunks):
+    port = _free_port()
+    mp.spawn(_chunked_worker, args=(world, port, chunks, None), nprocs=world, join=True)
+
+
+def test_nccl_debug_parser():
+    from sea_attention_amd.distributed import parse_nccl_debug
+    log = """
+host:123:456 [0] NCCL INFO RCCL version 2.22.3+hip7.0 HEAD:abcdef
+host:123:456 [0] NCCL INFO Channel 00/0 : 0[0] -> 1[1] via P2P/IPC/read
+host:123:456 [0] NCCL INFO Channel 01/0 : 0[0] -> 7[7] via P2P/IPC
+host:123:456 [0] NCCL INFO Connected all rings
+host:123:456 [0] NCCL INFO 16 coll channels, 16 collnet channels, 0 nvls channels, 16 p2p channels, 2 p2p channels per peer
+host:123:456 [0] NCCL INFO AllGather: 134217728 Bytes -> Algo 1 proto 2 time 1234.5
+host:123:456 [0] NCCL INFO AllGather: opCount 5 sendbuff 0x1 recvbuff 0x2 count 67108864 datatype 9 op 0 root 0 comm 0x3 [nranks=8] stream 0x4 algorithm Ring protocol Simple
+"""
+    r = parse_nccl_debug(log)
+    assert r["version"].startswith("2.22.3") and r["channels"] == 16
+    assert "P2P/IPC/read" in r["transports"] and "P2P/IPC" in r["transports"]
+    assert {"algorithm": "Ring", "protocol": "Simple"} in r["allgather"] and len(r["allgather"]) == 1
+    assert parse_nccl_debug("nothing useful here") == {"version": None, "channels": None, "transports": [], "allgather": []}

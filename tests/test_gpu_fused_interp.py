@@ -162,3 +162,36 @@ def test_layer_gather_path_fuses_and_returns_the_reference_csr():
         assert torch.equal(b.partial_attention_mask.col[n, :z].cpu().long(), col[n, :z])
     rel = ((a.context_layer.float() - b.context_layer.float()).norm() / b.context_layer.float().norm()).item()
     assert rel < 2e-3, rel                                   # auto may pick the tile kernel; gather vs gather would be bitwise
+
+
+@pytest.mark.parametrize("dtype,d,fused", [(torch.bfloat16, 64, True), (torch.float16, 128, True), (torch.bfloat16, 64, False)])
+def test_launches_over_groups_of_sequences_equal_the_whole_launch(ops, dtype, d, fused):
+    """`FlatCSR.items(n0, n1)` (round 4: one attention launch per chunk of a chunked all-gather pipeline): launches over the
+    parts write the same columns and the same context rows as ONE launch over the batch, bit for bit, whether the columns
+    are still pending (fused interpolation: every part expands its own) or already there."""
+    N, H, T, T_M, k = 4, 8, 700, 64, 16
+    g = torch.Generator().manual_seed(3)
+    probs = torch.softmax(torch.randn((N, H, T, T_M), generator=g), -1).to(DEV)
+    keep = O.keep_counts_module(H, T, T_M, k).clamp_max(H * T_M).to(torch.int32).contiguous().to(DEV)
+    q, kk, v, rs, mx, avg = _inputs(N, H, T, T, d, dtype, 9)
+    _, whole = _selection(ops, probs, keep, k, T, defer=fused)
+    _, parts = _selection(ops, probs, keep, k, T, defer=fused)
+    ctx_w = torch.empty((N, T, H * d), dtype=torch.float32, device=DEV)
+    ctx_p = torch.full((N, T, H * d), float("nan"), dtype=torch.float32, device=DEV)
+    ops.sparse_attention(q, kk, v, whole, row_scale=rs, avg=avg, mix=mx, out=ctx_w.view(N, T, H, d).permute(0, 2, 1, 3), path="gather")
+    if fused:
+        parts._col.fill_(-7)
+    for n0, n1 in ((0, 1), (1, 3), (3, 4)):                                 # ragged groups
+        sub = parts.items(n0, n1)
+        assert sub.col_is_pending == fused and (sub.N, sub.T_dst) == (n1 - n0, T)
+        ops.sparse_attention(q[n0:n1], kk[n0:n1], v[n0:n1], sub, row_scale=rs[n0:n1], avg=avg[n0:n1], mix=mx[n0:n1],
+                             out=ctx_p[n0:n1].view(n1 - n0, T, H, d).permute(0, 2, 1, 3), path="gather")
+        assert not sub.col_is_pending
+    torch.cuda.synchronize()
+    assert torch.equal(ctx_w, ctx_p)
+    for n in range(N):
+        z = int(whole.crow[n, -1])
+        assert torch.equal(whole._col[n, :z], parts._col[n, :z])
+    if fused:                     # the parent still believes its columns pending: reading them runs the emit launch -- same values
+        assert parts.col_is_pending
+        assert torch.equal(parts.col[0, :int(whole.crow[0, -1])], whole._col[0, :int(whole.crow[0, -1])])

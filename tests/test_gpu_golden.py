@@ -26,7 +26,7 @@ def _keep(ops, g, dev):
 def ops():
     from sea_attention_amd.perlin_attention import ops
     from sea_attention_amd import _lib
-    assert _lib.load().sea_version() == 1
+    assert _lib.load().sea_version() == _lib.ABI_VERSION
     return ops
 
 
