@@ -66,9 +66,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-output-check", action="store_true")
     ap.add_argument("--no-other-workloads", action="store_true", help="skip the short legs over the other BASELINE shapes")
     ap.add_argument("--other-steps", type=int, default=20, help="timed steps of each short leg")
-    ap.add_argument("--context-dtype", default="fp32", choices=["fp32", "same"],
+    ap.add_argument("--context-dtype", default="auto", choices=["auto", "fp32", "same"],
                     help="dtype of context_layer: fp32 = the module's and the reference's default (flat_csr_sdbmm.py:347); "
-                         "'same' = the data dtype (reported as the context_bf16 leg by the default run)")
+                         "'same' = the data dtype (reported as the context_bf16 leg by the default run); auto = fp32 on one GPU, "
+                         "the data dtype for N > 1 (the context shard is what the all-gather carries over xGMI: 134 MB instead "
+                         "of 268 MB per rank and step at the headline shape)")
     ap.add_argument("--no-grid", action="store_true",
                     help="skip the reference's own ablation grid (benchmark_opt_ablation.py:160-186: opt-125m layer, batch 1, T = 2048, "
                          "k in {32, 64, 128} x predictor length in {64, 128, 256, 384}, + exp_long_context.py:152's T_M = 96 / k = 128)")
@@ -633,6 +635,8 @@ def main(argv=None):
     if env_world is None and args.gpus > 1:
         return self_launch(args, argv)                          # before anything here touches the GPU
     world = int(env_world or "1")
+    if args.context_dtype == "auto":
+        args.context_dtype = "fp32" if world == 1 else "same"
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:                                      # never print a line that claims GPUs that did not run
@@ -996,7 +1000,8 @@ def main(argv=None):
                          f"batch {NB} sequences/GPU, random-init weights seed 42, "
                          + (f"context_layer fp32 (the module's and the reference's default, flat_csr_sdbmm.py:347; the {args.dtype} "
                             f"twin: context_{args.dtype}), " if args.context_dtype == "fp32" else
-                            f"context_layer {args.dtype} (reference default: fp32), ")
+                            f"context_layer {args.dtype} (reference default: fp32"
+                            + ("; N > 1: the shard every rank all-gathers is 16-bit, half the bytes over xGMI" if world > 1 else "") + "), ")
                          + ("unpadded batch declared to the module (assume_not_padded: no mask inspection sync)"
                             if not args.inspect_padding else "module inspects the mask for padding (one host sync)")
                          + f", sparse kernel path {path}"
