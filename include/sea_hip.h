@@ -358,14 +358,15 @@ int sea_causal_conv_c8(const void* x, int dtype, int64_t N, int64_t T, int64_t W
  *            zero-padded to WdP rows (half s at rows s*WdP .. s*WdP+Wd-1; identical to W2 when Wd % 16 == 0), followed by
  *            one extra tile whose rows 0,1 are Wsc (2,D1);
  * vectors (fp32): b1[D1] g1[D1] be1[D1] b2[2*WdP] (padded like W2') g2[WdP] be2[WdP] (zero past Wd) bsc[2].
- * Outputs: x_c8 (N, T, H*2/8, Wd, 8) of `dtype`; optional tpred (N,H,T,D1) of `dtype` (= enc); optional
+ * Outputs: x_c8 (N, T, H*2/8, Wd, 8) of `dtype`, batch items x_c8_stride_n elements apart (0 = dense; a decode session
+ *   lets the one new row of every item land behind that item's CNN window); optional tpred (N,H,T,D1) of `dtype` (= enc); optional
  * row_scale / avg_scale (N,H,T) FP32 = gate[...,0] / gate[...,1].
  * Supported (D1, D2): D1 = 128 with any D2 % 16 == 0 up to 256 (round 4: every predictor length T_M = 2*D2 with
  * T_M % 32 == 0, the reference's grid of src/main/benchmark_opt_ablation.py:160-186 included), (160,128), (256,128)
  * (the weights must fit 160 KB of LDS, or stream: D1 = 256); H % 4 == 0; Din % 8 == 0. */
 int sea_predictor_mlp(const void* x, int dtype, int64_t N, int64_t H, int64_t T, int64_t Din, const int64_t* x_strides,
                       int64_t D1, int64_t D2, const void* w1_packed, const void* w2_packed, const float* vectors,
-                      float eps1, float eps2, void* x_c8, void* tpred, float* row_scale, float* avg_scale,
+                      float eps1, float eps2, void* x_c8, int64_t x_c8_stride_n, void* tpred, float* row_scale, float* avg_scale,
                       sea_stream_t stream);
 
 /* Causal Performer of SEA's estimator in one launch, fp32 MFMA:
@@ -442,6 +443,8 @@ int sea_performer_causal_step(const void* q, const void* k, const void* v, const
  *   may be one image (updated in place; it changes only when a chunk completes).
  * sea_predictor_tail_select_at: sea_predictor_tail_select for the LAST T rows of sequences of *t_src_dev tokens;
  *   keep_table[i] = K of the row that sees i+1 keys, for every position the session can reach (attention.py:849-866).
+ *   crow_out (optional; T == 1 only): (N, 2) int32 = [0, row total] per batch item, i.e. the one-row CSR's crow -- the step then
+ *   needs no sea_csr_row_scan launch.
  * sea_csr_emit_at: sea_csr_emit with the row widths following *t_src_dev and column ids = head * T_cap + key for a FIXED
  *   capacity T_cap >= *t_src_dev (the K / V caches' row count), so sea_sparse_attention is called with T_src = T_cap. */
 int sea_performer_causal_step_at(const void* q, const void* k_cache, const void* v_cache, const void* pos_table, int dtype,
@@ -454,6 +457,7 @@ int sea_predictor_tail_select_at(const void* y, int dtype, int64_t N, int64_t C,
                                  const void* conv_w16, int64_t Cp, const void* gamma, const void* beta, float eps,
                                  void* probs, void* scores, const int32_t* keep_table, const int32_t* t_src_dev,
                                  int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz, int32_t* head_off,
+                                 int32_t* crow_out,
                                  sea_stream_t stream);
 int sea_csr_emit_at(const uint32_t* bits, const void* crow, int64_t N, int64_t H, int64_t T_dst, int64_t T_m,
                     const int32_t* t_src_dev, int64_t T_cap, int is_causal, int max_k, void* col, int idx_bytes,
@@ -462,6 +466,19 @@ int sea_csr_emit_at(const uint32_t* bits, const void* crow, int64_t N, int64_t H
 /* Algorithmic bytes of one sea_sparse_attention launch:
  * Z*(2*D*s + 4) + N*H*T_dst*(2*D*s + 4).  Host-side helper, no device work. */
 int64_t sea_sparse_attention_bytes(int64_t Z, int64_t N, int64_t H, int64_t T_dst, int64_t D, int elem_bytes);
+
+/* Glue of a graph-replayed decoding step (round 4; perlin_attention/decode.py, reference loop src/main/opt_generate.py:131).
+ * sea_decode_stage: the ONE launch of a step whose arguments change (the caller's new q / k / v rows, (N,H,1,D) with element
+ *   strides {n, h}, feature stride 1, 16-byte aligned rows): q is copied into q_in (N,H,D), k / v are written into
+ *   kv_cache (2,N,H,capacity,D) at row counters[0] (device int32: the rows the session's state has seen).  Replaces three
+ *   input copies and an index_copy_ of the framework (four launches of ~4.5 us).
+ * sea_c8_window_shift: xs (N, rows, row_bytes) moved up by one row in place (xs[n, r] = xs[n, r + 1]): the predictor CNN's
+ *   window after a step whose MLP wrote the new row behind it (sea_predictor_mlp with x_c8_stride_n).  `counters` (optional):
+ *   two device int32 advanced by one by the same launch -- the LAST of a step, so every reader of the step is done. */
+int sea_decode_stage(const void* q, const void* k, const void* v, int dtype, int64_t N, int64_t H, int64_t D,
+                     const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                     void* q_in, void* kv_cache, int64_t capacity, const int32_t* counters, sea_stream_t stream);
+int sea_c8_window_shift(void* xs, int64_t N, int64_t rows, int64_t row_bytes, int32_t* counters, sea_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -51,6 +51,8 @@ struct MlpParams {
   int N, H, T, Din, KS1;
   float eps1, eps2;
   int Wd;                   // width of one decoder split (= T_M / 4); <= 16 * (NT2 / 2), smaller only in the PADW instantiations
+  int64_t xc8_n;            // element stride between batch items of x_c8 (dense: T * (H*2/8) * Wd * 8; a decode session writes the
+                            // one new row of every item straight behind its CNN window: (rows + 1) * row)
 };
 
 // MLP_WAVES waves per (persistent) workgroup: 16 where the accumulators leave room under 128 VGPRs, else 8.
@@ -273,7 +275,7 @@ void predictor_mlp_kernel(MlpParams p) {
       for (int i = 0; i < HT; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) *reinterpret_cast<uint32_t*>(tl + (i * 16 + lg * 4 + r) * 16) = outp[i][r];
-      T* yb = reinterpret_cast<T*>(p.x_c8) + (((int64_t)n * p.T + t) * C8 + ht * 4) * (Wd * 8);
+      T* yb = reinterpret_cast<T*>(p.x_c8) + n * p.xc8_n + ((int64_t)t * C8 + ht * 4) * (Wd * 8);
 #pragma unroll
       for (int c0 = 0; c0 < 4 * WdP; c0 += 64) {
         const int c = c0 + lane, q = c / Wd, w = c - q * Wd;
@@ -282,7 +284,7 @@ void predictor_mlp_kernel(MlpParams p) {
         if (active && cin && ht * 4 + q < C8) *reinterpret_cast<uint4*>(yb + (int64_t)c * 8) = v;
       }
     } else if (hok) {   // channel = 2h + split: this lane's pair is bytes [4*(h%4), +4) of block h/4, pixel w
-      T* yb = reinterpret_cast<T*>(p.x_c8) + (((int64_t)n * p.T + t) * C8 + (h >> 2)) * (Wd * 8) + (h & 3) * 2;
+      T* yb = reinterpret_cast<T*>(p.x_c8) + n * p.xc8_n + ((int64_t)t * C8 + (h >> 2)) * (Wd * 8) + (h & 3) * 2;
 #pragma unroll
       for (int i = 0; i < HT; ++i) {
         if (!PADW || i * 16 + lg * 4 < Wd) {
@@ -356,8 +358,8 @@ static int launch_mlp(const MlpParams& p, int nt1, int nt2, hipStream_t s) {
 
 extern "C" int sea_predictor_mlp(const void* x, int dtype, int64_t N, int64_t H, int64_t T, int64_t Din, const int64_t* x_strides,
                                  int64_t D1, int64_t D2, const void* w1_packed, const void* w2_packed, const float* vectors,
-                                 float eps1, float eps2, void* x_c8, void* tpred, float* row_scale, float* avg_scale,
-                                 sea_stream_t stream) {
+                                 float eps1, float eps2, void* x_c8, int64_t x_c8_stride_n, void* tpred, float* row_scale,
+                                 float* avg_scale, sea_stream_t stream) {
   const char* nm = "sea_predictor_mlp";
   SEA_REQUIRE(x && x_strides && w1_packed && w2_packed && vectors && x_c8, SEA_EINVAL, "%s: null pointer", nm);
   SEA_REQUIRE(dtype == SEA_F16 || dtype == SEA_BF16, SEA_EUNSUPPORTED, "%s: 16-bit data only (dtype %d)", nm, dtype);
@@ -375,6 +377,10 @@ extern "C" int sea_predictor_mlp(const void* x, int dtype, int64_t N, int64_t H,
   p.N = (int)N; p.H = (int)H; p.T = (int)T; p.Din = (int)Din; p.KS1 = (int)((Din + 31) / 32);
   p.eps1 = eps1; p.eps2 = eps2;
   p.Wd = (int)(D2 / 2);
+  const int64_t dense_n = T * (H * 2 / 8) * (D2 / 2) * 8;
+  SEA_REQUIRE(x_c8_stride_n == 0 || (x_c8_stride_n >= dense_n && x_c8_stride_n % 8 == 0), SEA_EINVAL,
+              "%s: x_c8_stride_n must be 0 (dense) or >= %lld elements in whole 16-byte blocks", nm, (long long)dense_n);
+  p.xc8_n = x_c8_stride_n ? x_c8_stride_n : dense_n;
   const int nt2 = 2 * (int)((D2 / 2 + 15) / 16);               // tiles of the padded decoder: each split owns ceil(Wd / 16)
   hipStream_t s = (hipStream_t)stream;
   const int rc = dtype == SEA_BF16 ? launch_mlp<__hip_bfloat16>(p, (int)(D1 / 16), nt2, s)

@@ -57,6 +57,9 @@ struct TopkParams {
   // decode step replayed as a HIP graph: T_src (the rows' absolute widths) read from device memory; `keep` is then a
   // table over ABSOLUTE row indices (entry i = K of the row with i+1 visible keys), not over the T_dst rows of the call
   const int32_t* t_src_dev;
+  // decode step, ONE row per batch item: the row scan is trivial -- crow = [0, row total] -- and is written here (N, 2),
+  // which saves the step a launch; nullptr everywhere else
+  int32_t* crow1;
 };
 
 template <typename T> __device__ inline void load4(const T* p, float* f);
@@ -532,7 +535,10 @@ __device__ __forceinline__ void select_body(const TopkParams& p, uint32_t (&key)
       if (h < p.H) ho[h] = carry + incl - v;
       carry += __shfl(incl, 63);
     }
-    if (lane == 0) { ho[p.H] = carry; p.row_nnz[row] = carry; }
+    if (lane == 0) {
+      ho[p.H] = carry; p.row_nnz[row] = carry;
+      if (p.crow1 != nullptr) { p.crow1[2 * row] = 0; p.crow1[2 * row + 1] = carry; }
+    }
   }
 }
 
@@ -977,7 +983,7 @@ static int select_common(const char* name, const void* src, int dtype, int64_t N
   p.is_causal = is_causal; p.max_k = max_k;
   p.M = (int)(H * T_m); p.nchunks = p.M / 4; p.W = (p.M + 31) / 32; p.G = group_lanes((int)T_m);
   p.keep = keep; p.keep_stride_n = keep_stride_n;
-  p.bits = bits; p.mask_out = mask_out; p.row_nnz = row_nnz; p.head_off = head_off; p.t_src_dev = nullptr;
+  p.bits = bits; p.mask_out = mask_out; p.row_nnz = row_nnz; p.head_off = head_off; p.t_src_dev = nullptr; p.crow1 = nullptr;
   const int64_t rows = N * T_dst;
   if (dtype == SEA_F32) launch_select<float, FROM_MASK>(p, rows, s);
   else if (dtype == SEA_F16) launch_select<__half, FROM_MASK>(p, rows, s);
@@ -1077,7 +1083,8 @@ static int tail_select_common(const char* nm, const void* y, int dtype, int64_t 
                               const void* conv_w16, int64_t Cp, const void* gamma, const void* beta, float eps,
                               void* probs, void* scores, const int32_t* keep, int64_t keep_stride_n,
                               int64_t T_src, const int32_t* t_src_dev, int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz,
-                              int32_t* head_off, sea_stream_t stream) {
+                              int32_t* head_off, int32_t* crow1, sea_stream_t stream) {
+  SEA_REQUIRE(crow1 == nullptr || T == 1, SEA_EINVAL, "%s: crow_out goes with one row per batch item (T = %lld)", nm, (long long)T);
   SEA_REQUIRE(y && y_strides && conv_b && conv_w16 && gamma && beta && keep && bits && row_nnz && head_off, SEA_EINVAL,
               "%s: null pointer", nm);
   SEA_REQUIRE(dtype == SEA_F16 || dtype == SEA_BF16, SEA_EUNSUPPORTED, "%s: 16-bit data only (dtype %d)", nm, dtype);
@@ -1102,7 +1109,7 @@ static int tail_select_common(const char* nm, const void* y, int dtype, int64_t 
   p.is_causal = is_causal; p.max_k = max_k;
   p.M = (int)(H * T_m); p.nchunks = p.M / 4; p.W = (p.M + 31) / 32; p.G = group_lanes((int)T_m);
   p.keep = keep; p.keep_stride_n = keep_stride_n;
-  p.bits = bits; p.mask_out = nullptr; p.row_nnz = row_nnz; p.head_off = head_off; p.t_src_dev = t_src_dev;
+  p.bits = bits; p.mask_out = nullptr; p.row_nnz = row_nnz; p.head_off = head_off; p.t_src_dev = t_src_dev; p.crow1 = crow1;
   hipStream_t s = (hipStream_t)stream;
   int rc;
   if (tm256) rc = dtype == SEA_F16 ? launch_tail_select<__half>(tp, p, N * T, s) : launch_tail_select<__hip_bfloat16>(tp, p, N * T, s);
@@ -1120,7 +1127,7 @@ extern "C" int sea_predictor_tail_select(const void* y, int dtype, int64_t N, in
                                          int32_t* head_off, sea_stream_t stream) {
   return tail_select_common("sea_predictor_tail_select", y, dtype, N, C, H, T, W4, up, T_m, y_strides, conv_b, conv_w16, Cp, gamma,
                             beta, eps, probs, scores, keep, keep_stride_n, T_src, nullptr, is_causal, max_k, bits, row_nnz,
-                            head_off, stream);
+                            head_off, nullptr, stream);
 }
 
 // Decode form (a step captured as a HIP graph): the T new rows are the LAST rows of sequences of *t_src_dev tokens (device
@@ -1130,11 +1137,11 @@ extern "C" int sea_predictor_tail_select_at(const void* y, int dtype, int64_t N,
                                             const void* conv_w16, int64_t Cp, const void* gamma, const void* beta, float eps,
                                             void* probs, void* scores, const int32_t* keep_table, const int32_t* t_src_dev,
                                             int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz, int32_t* head_off,
-                                            sea_stream_t stream) {
+                                            int32_t* crow_out, sea_stream_t stream) {
   SEA_REQUIRE(t_src_dev, SEA_EINVAL, "sea_predictor_tail_select_at: null pointer");
   return tail_select_common("sea_predictor_tail_select_at", y, dtype, N, C, H, T, W4, up, T_m, y_strides, conv_b, conv_w16, Cp,
                             gamma, beta, eps, probs, scores, keep_table, 0, T, t_src_dev, is_causal, max_k, bits, row_nnz,
-                            head_off, stream);
+                            head_off, crow_out, stream);
 }
 
 extern "C" int sea_csr_row_scan(const int32_t* row_nnz, int64_t N, int64_t T_dst, void* crow, int idx_bytes,

@@ -11,12 +11,15 @@ tensor shapes that grow), so the step is bound by the host enqueueing them.
   * the Performer state image and the predictor CNN's window are updated in place,
   * the three kernels that need the position read it from a device int32
     (`sea_performer_causal_step_at`, `sea_predictor_tail_select_at`, `sea_csr_emit_at`, include/sea_hip.h),
-  * column ids are encoded against the cache capacity, so the fused attention launch has static arguments,
-  * the step ends by incrementing the counters.
+  * column ids are encoded against the cache capacity, so the fused attention launch has static arguments.
 
-The whole step is then captured ONCE with `torch.cuda.graph` and replayed per token; per position the host copies the
-new q / k / v rows into the static input buffers and launches one graph.  Results are bitwise those of
-`_forward_cached` called position by position (tests/test_decode_session.py).
+The whole step is then captured ONCE with `torch.cuda.graph` and replayed per token.  Round 4: the framework glue around
+the kernels (three input copies, index_copy_, cat + copy of the CNN window, row scan, two counter adds: eleven ~4.5 us
+launches, 50 of a position's 130 us) is two launches now -- `sea_decode_stage` in front of the replay (the only launch whose
+arguments change: it takes the caller's q row and appends k / v to the caches) and `sea_c8_window_shift` at its end (it
+also advances the two device counters); the MLP writes the new CNN row straight behind the window and the tail + selection
+launch writes the one-row `crow` itself.  Results are bitwise those of `_forward_cached` called position by position
+(tests/test_decode_session.py).
 """
 from typing import Optional
 
@@ -53,17 +56,22 @@ class DecodeSession:
         assert dt in (torch.float16, torch.bfloat16)
         assert ops.predictor_tail_select_supported(cs.rows_c8, H, self.T_M, decode=True), "fused tail + selection shape (T_M = 256, H <= 64)"
         self.image = ps.image.clone()                                        # Performer sums, updated in place
-        self.win = cs.rows_c8.clone()                                        # last LB rows of the CNN input
-        # K and V caches are the two halves of ONE tensor and the two position counters two elements of one: a step appends
-        # both new rows with one index_copy_ and advances both counters with one add (a step is a few microseconds per launch)
+        # CNN input rows: the window (last LB rows) and, behind it, the row of the current position -- ONE buffer, so that the
+        # MLP writes the new row in place (no cat) and the window moves by an in-place shift at the end of the step
+        self.xs = torch.zeros((N, LB + 1) + tuple(cs.rows_c8.shape[2:]), dtype=dt, device=dev)
+        self.xs[:, :LB] = cs.rows_c8
+        self.win = self.xs[:, :LB]
+        # K and V caches are the two halves of ONE tensor and the two position counters two elements of one
         self.kv_cache = torch.zeros((2, N, H, capacity, D), dtype=dt, device=dev)
         self.k_cache, self.v_cache = self.kv_cache[0], self.kv_cache[1]
         self.k_cache[:, :, :L] = key_prefix
         self.v_cache[:, :, :L] = value_prefix
+        # device counters: seen = rows the state has seen = cache row of the new token, tsrc = keys the new row sees; the
+        # LAST launch of a step (the window shift) advances both
         self.ctr32 = torch.tensor([L, L + 1], dtype=torch.int32, device=dev)
-        self.seen32 = self.ctr32[0:1]                                        # rows the state has seen
-        self.tsrc32 = self.ctr32[1:2]                                        # keys the new row sees
-        self.idx64 = torch.full((1,), L, dtype=torch.int64, device=dev)       # cache row of the new token
+        self.seen32 = self.ctr32[0:1]
+        self.tsrc32 = self.ctr32[1:2]
+        self.crow = torch.zeros((N, 2), dtype=torch.int32, device=dev)        # one-row CSR: [0, row total], written by the selection
         self.length = L                                                      # host mirror (bounds check only)
         # K_t of every reachable position (attention.py:849-866, the same fp32 expression as the stateless path) and
         # the largest CSR row any of them can emit
@@ -74,8 +82,6 @@ class DecodeSession:
         bound = torch.minimum(keep_cpu.to(torch.long) * per_pixel, H * torch.minimum(w, torch.tensor(self.T_M * self.k)))
         self.z_cap = max(int(bound.max().item()), 1)
         self.q_in = torch.zeros((N, H, 1, D), dtype=dt, device=dev)
-        self.kv_in = torch.zeros((2, N, H, 1, D), dtype=dt, device=dev)
-        self.k_in, self.v_in = self.kv_in[0], self.kv_in[1]
         self.ctx = torch.zeros((N, 1, H * D), dtype=at.context_layer_dtype or torch.float32, device=dev)
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.probs = None                                                    # estimated attention probabilities of the last step
@@ -83,23 +89,24 @@ class DecodeSession:
         if use_graph:
             self._capture()
 
-    # the launches of one position; everything position-dependent is read from device memory
+    # the one launch of a position whose arguments change: q -> q_in, k / v -> the caches' new row
+    def _stage(self, q, k, v):
+        ops.decode_stage(q, k, v, self.q_in, self.kv_cache, self.ctr32)
+
+    # the (captured) launches of one position; everything position-dependent is read from device memory
     def _launch(self):
         at, H, D, T_M = self.attention, self.H, self.D, self.T_M
-        self.kv_cache.index_copy_(3, self.idx64, self.kv_in)
         # chunk-aligned step: the kernel walks the open Performer chunk again from the caches (which hold the new row already)
         performer_value, avg_rows, _ = ops.performer_step(
             self.q_in, self.k_cache, self.v_cache, at.v_eye_learned_causal[0, 0], at.performer.projection_matrix,
             state_in=self.image, t_base_dev=self.seen32)
-        x, _t, row_scale, avg_scale = ops.predictor_mlp(
+        _x, _t, row_scale, avg_scale = ops.predictor_mlp(
             performer_value, at.attention_predictor_enc[0], at.attention_predictor_enc[1],
             at.attention_predictor_dec_row[0], at.attention_predictor_cnn[0].module,
-            at.attention_predictor_dec_scaler[0], want_tpred=False)
-        xs = torch.cat([self.win, x], dim=1)                                  # (N, LB + 1, C/8, W, 8)
-        self.win.copy_(xs[:, 1:])
+            at.attention_predictor_dec_scaler[0], want_tpred=False, x_c8_out=self.xs[:, -1:])   # the new row, behind the window
         keepres, ln2 = at.attention_predictor_cnn[1].module, at.attention_predictor_cnn[2].module
         body = list(keepres.net.children())
-        y = xs
+        y = self.xs                                                           # (N, LB + 1, C/8, W, 8)
         for i in range(0, len(body) - 2, 2):
             conv = body[i].module
             y = ops.causal_conv_c8(y, conv.weight, conv.bias, conv.kernel_size, conv.dilation, conv.padding[1], relu=True)
@@ -107,14 +114,13 @@ class DecodeSession:
         y_new = y[:, -1:]                                                     # (the tail reads the row where it lies)
         self.probs, _, sel = ops.predictor_tail_select(
             y_new, conv4.weight[:, :, 0, 0], conv4.bias, ln2.weight, ln2.bias, up=4, T_m=T_M, keep=self.keep_table,
-            k=self.k, T_src=0, is_causal=True, eps=ln2.eps, want_scores=False, t_src_dev=self.tsrc32)
-        csr = ops.csr_from_selection(*sel, H, T_M, self.capacity, self.k, True, self.z_cap, t_src_dev=self.tsrc32)
+            k=self.k, T_src=0, is_causal=True, eps=ln2.eps, want_scores=False, t_src_dev=self.tsrc32, crow_out=self.crow)
+        csr = ops.csr_from_selection(*sel, H, T_M, self.capacity, self.k, True, self.z_cap, t_src_dev=self.tsrc32, crow=self.crow)
         ops.sparse_attention(self.q_in, self.k_cache, self.v_cache, csr,
                              row_scale=row_scale if at.pconfig.partial_attention_scaler else None,
                              avg=avg_rows, mix=avg_scale, out=self.ctx.view(self.N, 1, H, D).permute(0, 2, 1, 3),
                              path="gather")
-        self.ctr32 += 1
-        self.idx64 += 1
+        ops.c8_window_shift(self.xs, counters=self.ctr32)                     # the window of the next position; counters += 1
 
     def _capture(self):
         """One eager step on a side stream would advance the state, so the capture runs against SAVED copies of the
@@ -126,18 +132,20 @@ class DecodeSession:
         another layer's `.to()` / `load_state_dict`, or the cache's own size bound -- cannot free memory a replay still
         reads; and it remembers the cache generation: `step()` re-captures when that has moved, because a cleared cache
         means the weights may have been edited and the pinned packs may be stale."""
-        saved = [t.clone() for t in (self.image, self.win, self.kv_cache, self.ctr32, self.idx64)]
+        saved = [t.clone() for t in (self.image, self.xs, self.kv_cache, self.ctr32)]
         with ops.pinned_prep() as pins:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side), torch.no_grad():                    # warm-up: lazy library work happens outside the capture
+                zero = torch.zeros_like(self.q_in)
+                self._stage(zero, zero, zero)
                 self._launch()
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g), torch.no_grad():
                 self._launch()
-        for dst, src in zip((self.image, self.win, self.kv_cache, self.ctr32, self.idx64), saved):
+        for dst, src in zip((self.image, self.xs, self.kv_cache, self.ctr32), saved):
             dst.copy_(src)
         self.graph = g
         self._pinned = pins
@@ -160,13 +168,11 @@ class DecodeSession:
     @torch.no_grad()
     def step(self, q: torch.Tensor, k: torch.Tensor, v: torch.Tensor) -> torch.Tensor:
         assert self.length < self.capacity, "cache capacity reached"
-        self.q_in.copy_(q)
-        self.k_in.copy_(k)
-        self.v_in.copy_(v)
+        if self.graph is not None and ops.prep_generation() != self._prep_generation:
+            self.graph = None                                      # (re-captured below, BEFORE this step's stage launch: the capture
+            self._capture()                                        #  runs a warm-up step on saved copies of the state)
+        self._stage(q, k, v)
         if self.graph is not None:
-            if ops.prep_generation() != self._prep_generation:     # the weight packs were dropped (weights may have changed):
-                self.graph = None                                  # capture again against freshly prepared ones
-                self._capture()
             self.graph.replay()
         else:
             self._launch()

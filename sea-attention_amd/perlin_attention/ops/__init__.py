@@ -14,4 +14,5 @@ from .predictor import (split_layernorm, predictor_tail, cumavg, performer_value
                         performer_step, performer_plan, performer_chunk_rows,
                         split_layernorm_c8, causal_conv_c8, pack_conv_weight, to_c8, from_c8,
                         predictor_mlp, predictor_mlp_supported, predictor_tail_select,
-                        predictor_tail_select_supported, clear_prep_cache, prep_generation, pinned_prep, LazyTensor, realize)
+                        predictor_tail_select_supported, clear_prep_cache, prep_generation, pinned_prep, LazyTensor, realize,
+                        decode_stage, c8_window_shift)

@@ -202,7 +202,7 @@ def topk_to_csr(probs: torch.Tensor, keep: torch.Tensor, k: int, target_width: O
 @_lib.device_guarded
 def csr_from_selection(bits: torch.Tensor, row_nnz: torch.Tensor, head_off: torch.Tensor, H: int, T_m: int, T_src: int,
                        k: int, is_causal: bool = True, z_cap: Optional[int] = None, keep: Optional[torch.Tensor] = None,
-                       t_src_dev: Optional[torch.Tensor] = None, defer_emit: bool = False):
+                       t_src_dev: Optional[torch.Tensor] = None, defer_emit: bool = False, crow: Optional[torch.Tensor] = None):
     """Row scan + emit: the (bits, row_nnz, head_off) of a selection launch (sea_topk_select or the fused
     sea_predictor_tail_select) -> FlatCSR.  Two launches, no host sync.
     Decode form (`sea_csr_emit_at`): `t_src_dev` (one int32 on the device) is the sequence length the row widths follow,
@@ -211,8 +211,11 @@ def csr_from_selection(bits: torch.Tensor, row_nnz: torch.Tensor, head_off: torc
     N, T_dst = row_nnz.shape
     dev = bits.device
     st = _lib.stream_ptr()
-    crow = torch.empty((N, T_dst + 1), dtype=torch.int32, device=dev)
-    _lib.check(lib.sea_csr_row_scan(_p(row_nnz), N, T_dst, _p(crow), 4, st), "sea_csr_row_scan")
+    if crow is None:
+        crow = torch.empty((N, T_dst + 1), dtype=torch.int32, device=dev)
+        _lib.check(lib.sea_csr_row_scan(_p(row_nnz), N, T_dst, _p(crow), 4, st), "sea_csr_row_scan")
+    else:                     # the selection launch already wrote it (one row per item: sea_predictor_tail_select_at's crow_out)
+        assert crow.dtype == torch.int32 and tuple(crow.shape) == (N, T_dst + 1) and crow.is_contiguous()
     if z_cap is None:
         z_cap = z_capacity(keep.cpu(), H, T_dst, T_src, T_m, int(k), is_causal)
     col = torch.empty((N, z_cap), dtype=torch.int32, device=dev)

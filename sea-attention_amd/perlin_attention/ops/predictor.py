@@ -1,7 +1,7 @@
 """HIP kernels for the bandwidth-bound pieces of SEA's estimator and epilogue (csrc/sea_predictor.hip).
 Not part of the reference's operator package: there these steps are chains of framework kernels inside
 `PerlinAttention.forward` (attention.py:123-131,266-281,670-673,1220-1222)."""
-from ctypes import c_void_p
+from ctypes import c_void_p, c_int64 as ctypes_i64
 from typing import Optional
 
 import weakref
@@ -196,7 +196,7 @@ def predictor_tail_select_supported(y: torch.Tensor, H: int, T_m: int, decode: b
 def predictor_tail_select(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor,
                           up: int, T_m: int, keep: torch.Tensor, k: int, T_src: int, is_causal: bool = True,
                           eps: float = 1e-5, want_scores: bool = False, t_src_dev: Optional[torch.Tensor] = None,
-                          lazy_probs: bool = False):
+                          lazy_probs: bool = False, crow_out: Optional[torch.Tensor] = None):
     """predictor_tail + grouped top-k selection in one launch.  Returns (probs, scores, (bits, row_nnz, head_off));
     feed the triple to flat_csr.csr_from_selection.  Bit-identical to predictor_tail followed by topk_to_csr.
     `lazy_probs`: the launch does NOT write the (N,H,T,T_m) map (nobody on the hot path reads it); `probs` is then a
@@ -239,12 +239,14 @@ def predictor_tail_select(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.T
     bits = torch.empty((N, T, W), dtype=torch.int32, device=dev)
     row_nnz = torch.empty((N, T), dtype=torch.int32, device=dev)
     head_off = torch.empty((N, T, H + 1), dtype=torch.int32, device=dev)
+    assert crow_out is None or (t_src_dev is not None and T == 1 and crow_out.dtype == torch.int32 and tuple(crow_out.shape) == (N, 2)
+                                and crow_out.is_contiguous()), "crow_out: the decode form with one row per batch item"
     if t_src_dev is not None:
         assert t_src_dev.dtype == torch.int32 and t_src_dev.numel() == 1 and t_src_dev.is_cuda and keep.ndim == 1
         _lib.check(lib.sea_predictor_tail_select_at(
             _p(y), _lib.dtype_code(dt), N, C, H, T, W4, up, T_m, _lib.strides5_blocked(y), _p(cb), _p(w16), Cp, _p(g), _p(b),
             float(eps), _p(probs), _p(scores), _p(keep), _p(t_src_dev), int(is_causal), int(k),
-            _p(bits), _p(row_nnz), _p(head_off), _lib.stream_ptr()), "sea_predictor_tail_select_at")
+            _p(bits), _p(row_nnz), _p(head_off), _p(crow_out), _lib.stream_ptr()), "sea_predictor_tail_select_at")
         return probs, scores, (bits, row_nnz, head_off)
     _lib.check(lib.sea_predictor_tail_select(
         _p(y), _lib.dtype_code(dt), N, C, H, T, W4, up, T_m, _lib.strides5_blocked(y), _p(cb), _p(w16), Cp, _p(g), _p(b),
@@ -441,9 +443,12 @@ def _pack_a_fragments(w: torch.Tensor, kperm=None) -> torch.Tensor:
 
 
 @_lib.device_guarded
-def predictor_mlp(x: torch.Tensor, enc_lin, enc_ln, dec_lin, ln1, scaler_lin, want_tpred: bool = False):
+def predictor_mlp(x: torch.Tensor, enc_lin, enc_ln, dec_lin, ln1, scaler_lin, want_tpred: bool = False,
+                  x_c8_out: Optional[torch.Tensor] = None):
     """Fused predictor MLP (csrc/sea_mlp.hip): x (N,H,T,Din) -> (x_c8 (N,T,H*2/8,Wd,8), t_pred or None,
-    row_scale (N,H,T) fp32, avg_scale (N,H,T) fp32).  enc_lin/dec_lin/scaler_lin: nn.Linear; enc_ln/ln1: nn.LayerNorm."""
+    row_scale (N,H,T) fp32, avg_scale (N,H,T) fp32).  enc_lin/dec_lin/scaler_lin: nn.Linear; enc_ln/ln1: nn.LayerNorm.
+    `x_c8_out`: a preallocated (N,T,H*2/8,Wd,8) VIEW whose batch items may lie apart (rows of an item dense): a decode
+    session lets the new row land behind each item's CNN window."""
     lib = _lib.load()
     _lib.require_gpu(x)
     N, H, T, Din = x.shape
@@ -478,12 +483,16 @@ def predictor_mlp(x: torch.Tensor, enc_lin, enc_ln, dec_lin, ln1, scaler_lin, wa
         return w1p, w2p, vec
     w1p, w2p, vec = _cached("mlp", (enc_lin.weight, enc_lin.bias, enc_ln.weight, enc_ln.bias, dec_lin.weight, dec_lin.bias,
                                     ln1.weight, ln1.bias, scaler_lin.weight, scaler_lin.bias), dt, build)
-    x_c8 = torch.empty((N, T, H * 2 // 8, Wd, 8), dtype=dt, device=x.device)
+    if x_c8_out is None:
+        x_c8, xs_n = torch.empty((N, T, H * 2 // 8, Wd, 8), dtype=dt, device=x.device), 0
+    else:
+        x_c8, xs_n = x_c8_out, x_c8_out.stride(0)
+        assert tuple(x_c8.shape) == (N, T, H * 2 // 8, Wd, 8) and x_c8.dtype == dt and x_c8.stride()[1:] == (H * 2 // 8 * Wd * 8, Wd * 8, 8, 1)
     tpred = torch.empty((N, H, T, D1), dtype=dt, device=x.device) if want_tpred else None
     row_scale = torch.empty((N, H, T), dtype=torch.float32, device=x.device)
     avg_scale = torch.empty((N, H, T), dtype=torch.float32, device=x.device)
     _lib.check(lib.sea_predictor_mlp(_p(x), _lib.dtype_code(dt), N, H, T, Din, _lib.strides3(x), D1, D2, _p(w1p), _p(w2p),
-                                     _p(vec), float(enc_ln.eps), float(ln1.eps), _p(x_c8), _p(tpred), _p(row_scale),
+                                     _p(vec), float(enc_ln.eps), float(ln1.eps), _p(x_c8), int(xs_n), _p(tpred), _p(row_scale),
                                      _p(avg_scale), _lib.stream_ptr()), "sea_predictor_mlp")
     return x_c8, tpred, row_scale, avg_scale
 
@@ -545,3 +554,34 @@ def causal_conv_c8(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, ks
                                       int(ksize), int(dilation), int(pad_w), int(relu), _p(y), _lib.stream_ptr()),
                "sea_causal_conv_c8")
     return y
+
+
+@_lib.device_guarded
+def decode_stage(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_in: torch.Tensor, kv_cache: torch.Tensor,
+                 counters: torch.Tensor) -> None:
+    """`sea_decode_stage`: the new rows of a decoding step, (N,H,1,D) each (any [n,h] strides), into the session's static
+    buffers -- q into q_in (N,H,1,D), k / v into kv_cache (2,N,H,capacity,D) at the row the device counters name
+    (int32 [seen, tsrc]: row = counters[0])."""
+    lib = _lib.load()
+    _lib.require_gpu(q, k, v, q_in, kv_cache, counters)
+    N, H, one, D = q.shape
+    assert one == 1 and k.shape == q.shape and v.shape == q.shape and q.dtype == k.dtype == v.dtype == q_in.dtype == kv_cache.dtype
+    assert q_in.is_contiguous() and tuple(q_in.shape) == (N, H, 1, D) and kv_cache.is_contiguous() and kv_cache.shape[:3] == (2, N, H)
+    assert counters.dtype == torch.int32 and counters.numel() == 2 and counters.is_contiguous()
+    q, k, v = (t if t.stride(-1) == 1 else t.contiguous() for t in (q, k, v))
+    st = lambda t: (ctypes_i64 * 2)(t.stride(0), t.stride(1))
+    _lib.check(lib.sea_decode_stage(_p(q), _p(k), _p(v), _lib.dtype_code(q.dtype), N, H, D, st(q), st(k), st(v), _p(q_in),
+                                    _p(kv_cache), kv_cache.shape[3], _p(counters), _lib.stream_ptr()), "sea_decode_stage")
+
+
+@_lib.device_guarded
+def c8_window_shift(xs: torch.Tensor, counters: Optional[torch.Tensor] = None) -> None:
+    """`sea_c8_window_shift`: xs (N, rows, ...) dense -> xs[:, r] = xs[:, r + 1] in place (the last row keeps its values);
+    `counters`: two device int32 the same launch advances by one (the last launch of a decoding step)."""
+    lib = _lib.load()
+    _lib.require_gpu(xs)
+    assert xs.is_contiguous() and xs.dim() >= 3
+    N, rows = xs.shape[:2]
+    row_bytes = xs[0, 0].numel() * xs.element_size()
+    assert counters is None or (counters.dtype == torch.int32 and counters.numel() == 2 and counters.is_contiguous())
+    _lib.check(lib.sea_c8_window_shift(_p(xs), N, rows, row_bytes, _p(counters), _lib.stream_ptr()), "sea_c8_window_shift")

@@ -375,3 +375,62 @@ def test_fused_interpolation_is_for_launches_of_many_rows():
     assert not ops.fused_interp_supported(torch.bfloat16, 32, 256)          # rows of 4 lanes
     assert not ops.fused_interp_supported(torch.float32, 128, 256)          # rows wider than 16 lanes
     assert not ops.fused_interp_supported(torch.bfloat16, 64, 48)           # T_m not a multiple of 32
+
+
+# ---- round 4 host logic ----------------------------------------------------------------------------------------------
+def test_lazy_tensor_computes_once_and_only_when_touched():
+    calls = []
+
+    def thunk():
+        calls.append(1)
+        return torch.arange(24.0).view(2, 3, 4)
+    t = ops.LazyTensor((2, 3, 4), torch.float32, torch.device("cpu"), thunk)
+    # metadata is served by the wrapper: nothing is computed
+    assert isinstance(t, torch.Tensor) and tuple(t.shape) == (2, 3, 4) and t.dtype == torch.float32 and t.stride() == (12, 4, 1)
+    assert t.device.type == "cpu" and t.is_contiguous() and not t.is_materialized and calls == []
+    assert "materialized=False" in repr(t)
+    # any operation on the values computes them, once
+    assert float(t[1, 2, 3]) == 23.0 and calls == [1] and t.is_materialized
+    assert torch.equal(t, torch.arange(24.0).view(2, 3, 4)) and torch.equal(t.transpose(1, 2), torch.arange(24.0).view(2, 3, 4).transpose(1, 2))
+    assert float((t * 2).sum()) == 552.0 and t.float().cpu().shape == (2, 3, 4) and calls == [1]
+    assert ops.realize(t) is t.materialize() and ops.realize(None) is None
+    x = torch.ones(3)
+    assert ops.realize(x) is x
+
+
+def test_fused_estimator_predicates_cover_the_reference_grid():
+    y16 = torch.empty((1, 1, 1, 1, 8), dtype=torch.bfloat16)
+    # src/main/benchmark_opt_ablation.py:160-186 (w in 64 / 128 / 256 / 384 at H = 12) and exp_long_context.py:152 (T_M = 96)
+    for T_M in (64, 96, 128, 256, 384):
+        assert ops.predictor_tail_select_supported(y16, 12, T_M)
+        assert ops.predictor_mlp_supported(128, T_M // 2, 12, 192)
+    assert ops.predictor_tail_select_supported(y16, 32, 512) and ops.predictor_tail_select_supported(y16, 40, 256)
+    assert not ops.predictor_tail_select_supported(y16, 64, 512)                       # H * T_M > 16384
+    assert not ops.predictor_tail_select_supported(y16.float(), 12, 256)               # 16-bit data only
+    assert not ops.predictor_tail_select_supported(y16, 12, 128, decode=True)          # the graph-replayed decode form: T_M = 256
+    assert ops.predictor_tail_select_supported(y16, 32, 256, decode=True)
+    assert not ops.predictor_mlp_supported(128, 24, 12, 192)                            # T_M / 4 must be a multiple of 8
+    assert ops.predictor_mlp_supported(256, 128, 40, 384) and not ops.predictor_mlp_supported(256, 96, 40, 384)
+    layer = make_layer(H=12, d=64, T_M=96, k=16, max_pos=64)
+    body = list(layer.attention.attention_predictor_cnn[1].module.net.children())
+    assert layer.attention._c8_cnn_ok(torch.empty(1, dtype=torch.bfloat16), body)       # W = 24: no power-of-two requirement
+    assert not layer.attention._c8_cnn_ok(torch.empty(1, dtype=torch.float32), body)
+
+
+def test_flat_csr_items_share_storage_and_pending_state():
+    N, T, H, z = 3, 4, 2, 10
+    crow = torch.arange(N * (T + 1), dtype=torch.int32).view(N, T + 1)
+    col = torch.zeros((N, z), dtype=torch.int32)
+    ho = torch.zeros((N, T, H + 1), dtype=torch.int32)
+    bits = torch.zeros((N, T, 1), dtype=torch.int32)
+    csr = ops.FlatCSR(crow, col, ho, H, 8, bits=bits, row_nnz=torch.zeros((N, T), dtype=torch.int32))
+    fired = []
+    csr._pending = (32, 4, True, lambda: fired.append(1))
+    sub = csr.items(1, 3)
+    assert (sub.N, sub.T_dst, sub.H, sub.T_src) == (2, T, H, 8) and sub.col_is_pending
+    assert sub.crow.data_ptr() == crow[1:].data_ptr() and sub._col.data_ptr() == col[1:].data_ptr() and sub.bits.data_ptr() == bits[1:].data_ptr()
+    sub._col[0, 0] = 7                                       # a launch over the part writes the shared array
+    assert int(col[1, 0]) == 7
+    _ = sub.col                                              # a non-fused reader of the part runs the PARENT's emit launch
+    assert fired == [1] and not csr.col_is_pending and not sub.col_is_pending
+    assert not csr.items(0, 1).col_is_pending
