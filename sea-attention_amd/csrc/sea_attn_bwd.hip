@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void sparse_attn_bwd_kernel(AttnBwdParams p) {
 // The scatter of the row pass above (every (row, key) entry adds D floats to dK_key and dV_key with memory-side atomics,
 // ~1.3 TB/s chip-wide) becomes a gather over the TRANSPOSED pattern:
 //   1. csc_count_kernel    entries per (n, head * T_src + key): one int32 atomic per entry (L2 integer atomics);
-//   2. csc_scan_kernel     exclusive scan -> start of every key's list (`cptr`) + a working copy (`cursor`);
+//   2. csc_scan_local / _finish_kernel  exclusive scan -> start of every key's list (`cptr`) + a working copy (`cursor`);
 //   3. bwd_rows_kernel     one lane group per query row (the forward's geometry): dp_j = dO . v_j, ds_j = p_j (dp_j - delta),
 //                          dQ = sum_j ds_j k_j (plain store), and a 16-byte record {t, p_j, ds_j} dropped into the key's
 //                          list at a slot taken from `cursor` (one returning int32 atomic per entry);
@@ -168,19 +168,24 @@ __global__ __launch_bounds__(256) void csc_count_kernel(const int32_t* __restric
   atomicAdd(cnt + (int64_t)n * (C + 1) + col[n * col_stride_n + e], 1);
 }
 
-// one 1024-thread workgroup per batch item: cnt[n][0..C) -> exclusive scan in place (cnt[n][C] = total), copied to cursor
-__global__ __launch_bounds__(1024) void csc_scan_kernel(int32_t* __restrict__ cptr, int32_t* __restrict__ cursor, int64_t C) {
+// cnt[n][0..C) -> exclusive scan in place (cnt[n][C] = total), copied to cursor: two launches over (chunk, batch item)
+// workgroups.  Launch 1 scans its chunk locally and leaves the chunk total in `tot`; launch 2 adds the totals of the chunks
+// before it and writes both copies.  (The first version walked all C = H * T_src = 131072 counters of an item in ONE
+// workgroup, 128 passes of three barriers: 170 us alone on the critical path of the backward at one sequence per GPU --
+// ADVICE r3; a thread-owns-16-consecutive-counters form of that single workgroup measured the same 170 us: uncoalesced.)
+constexpr int CSC_CHUNKS = 32;
+__global__ __launch_bounds__(1024) void csc_scan_local_kernel(int32_t* __restrict__ cptr, int64_t C, int64_t L, int32_t* __restrict__ tot) {
   __shared__ int s_wave[16];
   __shared__ int s_carry;
-  const int n = blockIdx.x;
+  const int ch = blockIdx.x, n = blockIdx.y;
   int32_t* c = cptr + (int64_t)n * (C + 1);
-  int32_t* u = cursor + (int64_t)n * (C + 1);
+  const int64_t lo = (int64_t)ch * L, hi = min(C, lo + L);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (threadIdx.x == 0) s_carry = 0;
   __syncthreads();
-  for (int64_t i0 = 0; i0 < C; i0 += 1024) {
+  for (int64_t i0 = lo; i0 < hi; i0 += 1024) {
     const int64_t i = i0 + threadIdx.x;
-    const int x = i < C ? c[i] : 0;
+    const int x = i < hi ? c[i] : 0;
     const int inc = wave_incl_scan(x);
     if (lane == 63) s_wave[wv] = inc;
     __syncthreads();
@@ -188,13 +193,30 @@ __global__ __launch_bounds__(1024) void csc_scan_kernel(int32_t* __restrict__ cp
 #pragma unroll
     for (int w = 0; w < 16; ++w) woff += (w < wv) ? s_wave[w] : 0;
     const int carry = s_carry;
-    const int ex = carry + woff + inc - x;
-    if (i < C) { c[i] = ex; u[i] = ex; }
+    if (i < hi) c[i] = carry + woff + inc - x;
     __syncthreads();
     if (threadIdx.x == 1023) s_carry = carry + woff + inc;
     __syncthreads();
   }
-  if (threadIdx.x == 0) { c[C] = s_carry; u[C] = s_carry; }
+  if (threadIdx.x == 0) tot[n * CSC_CHUNKS + ch] = s_carry;
+}
+
+__global__ __launch_bounds__(1024) void csc_scan_finish_kernel(int32_t* __restrict__ cptr, int32_t* __restrict__ cursor, int64_t C, int64_t L,
+                                                              const int32_t* __restrict__ tot) {
+  const int ch = blockIdx.x, n = blockIdx.y;
+  int32_t* c = cptr + (int64_t)n * (C + 1);
+  int32_t* u = cursor + (int64_t)n * (C + 1);
+  int base = 0;
+  for (int j = 0; j < ch; ++j) base += tot[n * CSC_CHUNKS + j];
+  const int64_t lo = (int64_t)ch * L, hi = min(C, lo + L);
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 1024) {
+    const int v = c[i] + base;
+    c[i] = v; u[i] = v;
+  }
+  if (ch == CSC_CHUNKS - 1 && threadIdx.x == 0) {
+    const int all = base + tot[n * CSC_CHUNKS + ch];
+    c[C] = all; u[C] = all;
+  }
 }
 
 template <typename T, int LPR, int U, int NWB>
@@ -442,7 +464,13 @@ static int launch_bwd_gather(BwdGatherParams g, hipStream_t s) {
   if (zb >= (1ll << 31) || p.N > 65535) return SEA_EUNSUPPORTED;
   hipLaunchKernelGGL(csc_count_kernel, dim3((unsigned)zb, (unsigned)p.N), dim3(256), 0, s, p.crow, p.col, p.col_stride_n, p.T_dst,
                      g.C, g.cptr);
-  hipLaunchKernelGGL(csc_scan_kernel, dim3((unsigned)p.N), dim3(1024), 0, s, g.cptr, g.cursor, g.C);
+  {
+    // chunk totals live at the start of the record area, which the row pass fills only after the scan
+    int32_t* tot = reinterpret_cast<int32_t*>(g.recs);
+    const int64_t L = (((g.C + CSC_CHUNKS - 1) / CSC_CHUNKS) + 1023) / 1024 * 1024;
+    hipLaunchKernelGGL(csc_scan_local_kernel, dim3(CSC_CHUNKS, (unsigned)p.N), dim3(1024), 0, s, g.cptr, g.C, L, tot);
+    hipLaunchKernelGGL(csc_scan_finish_kernel, dim3(CSC_CHUNKS, (unsigned)p.N), dim3(1024), 0, s, g.cptr, g.cursor, g.C, L, tot);
+  }
   p.TB = (p.T_dst + rpb - 1) / rpb;
   int64_t blocks = (int64_t)NH8 * p.TB;
   if (blocks >= (1ll << 31)) return SEA_EUNSUPPORTED;
@@ -504,7 +532,9 @@ static int64_t bwd_ws_ints(int64_t N, int64_t H, int64_t T_src) { return ((N * (
 
 extern "C" int64_t sea_sparse_attention_bwd_workspace_bytes(int64_t N, int64_t H, int64_t T_src, int64_t col_stride_n) {
   if (N <= 0 || H <= 0 || T_src <= 0 || col_stride_n <= 0) return 0;
-  return 2 * bwd_ws_ints(N, H, T_src) * 4 + N * col_stride_n * (int64_t)sizeof(BwdRec);
+  const int64_t recs = N * col_stride_n * (int64_t)sizeof(BwdRec);
+  const int64_t tot = N * 32 * 4;                              // the scan's chunk totals share the record area
+  return 2 * bwd_ws_ints(N, H, T_src) * 4 + (recs > tot ? recs : tot);
 }
 
 extern "C" int sea_sparse_attention_bwd_gather(const void* q, const void* k, const void* v, int dtype, int64_t N, int64_t H,
