@@ -299,7 +299,6 @@ class LayerBench:
                 self._real_attn(q_[a_:b_], k_[a_:b_], v_[a_:b_], csr_.items(a_, b_), *self.rec["a"][4:], **kw_c)
                 if after_chunk is not None:
                     after_chunk(c)
-            csr_._pending = None                              # every part's launch has written its columns
         e1.record()
         self.attn_events.append((e0, e1))
         return self.g_out, (self.g_out.context_layer if (out_view is None and chunk_views is None) else None)
@@ -359,8 +358,10 @@ class LayerBench:
         esz = torch.tensor([], dtype=self.dtype).element_size()
         alg_bytes = ops.sparse_attention_bytes(Z, NB, H, T, d, esz)
         osz = torch.tensor([], dtype=self.ctx_dtype).element_size()
+        fused_ij_c = path in ("gather", "auto") and ops.fused_interp_supported(self.dtype, d, w["T_M"])
         compulsory = (4 * NB * H * T * d * esz + NB * H * T * d * osz     # q, k, v, avg in; out
-                      + Z * 4 + NB * T * (H + 2) * 4                      # col (read, or written by the fused form), head_off, crow
+                      + (0 if getattr(self.layer.attention, "lazy_csr_columns", False) and fused_ij_c else Z * 4)   # col: read, or written by
+                      + NB * T * (H + 2) * 4                              # the fused form unless left pending; head_off, crow
                       + 2 * NB * H * T * 4)                               # row_scale, mix
         if not t_attn_s:
             return None, Z

@@ -210,6 +210,10 @@ int sea_sparse_attention_ex(const void* q, const void* k, const void* v, int dty
  *   bits      (N, T_dst, ceil(H*T_m/32)) kept-pixel masks of sea_topk_select / sea_predictor_tail_select (T_m % 32 == 0);
  *   crow      from sea_csr_row_scan over that launch's row_nnz; head_off from the same launch;
  *   col       (N, col_stride_n) int32: OUTPUT -- after the launch it holds exactly what sea_csr_emit would have written.
+ *   write_columns  0 (round 4): the expanded columns stay in LDS and `col` is NOT written (blocks whose key lists exceed the
+ *             kernel's LDS list still pass through their part of it): the column array is an output nobody on the hot path
+ *             reads -- 266 MB and ~50 us of the headline launch.  A caller that wants it later runs sea_csr_emit on the same
+ *             bits / crow (bit-identical); the Python handle keeps its columns pending and does that on first access.
  * Other arguments as sea_sparse_attention_ex (gather path; probs_out allowed).  Rows of 4 lanes and rows wider than 16
  * lanes are SEA_EUNSUPPORTED: run sea_csr_emit + sea_sparse_attention_ex there.
  * sea_attention_few_rows(): for a launch of at most that many rows (N * H * T_dst: a decoding step) sea_csr_emit +
@@ -223,7 +227,8 @@ int sea_sparse_attention_fused(const void* q, const void* k, const void* v, int 
                                const float* row_scale, const void* avg, const int64_t* avg_strides, const float* mix,
                                void* out, int out_dtype, const int64_t* out_strides,
                                float* probs_out, int64_t probs_stride_n,
-                               const uint32_t* bits, int64_t T_m, int is_causal, int max_k, sea_stream_t stream);
+                               const uint32_t* bits, int64_t T_m, int is_causal, int max_k, int write_columns,
+                               sea_stream_t stream);
 
 /* Backward of the fused operator WITHOUT its epilogue (o = sum_e softmax_e(q.k_e) v_e; the caller applies row scale and mix
  * in its autograd framework): dQ, dK, dV from dO.  Reference shape: masked_mm.py:169-267 + the dense branch's autograd

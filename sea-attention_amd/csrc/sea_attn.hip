@@ -260,7 +260,8 @@ __device__ inline void fused_expand(const AttnParams& p, int n, int h, int tt, b
   }
   __builtin_amdgcn_wave_barrier();
   if (fits) {                                              // the CSR's columns: the list, copied out by its own lane group
-    for (int i = sub; i < mylen; i += LPR) gcol[beg + i] = s_keys[lbase + i];
+    if (p.write_cols)                                      // (grid-uniform; 0: nobody reads them, the handle stays pending)
+      for (int i = sub; i < mylen; i += LPR) gcol[beg + i] = s_keys[lbase + i];
   } else {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_waitcnt(0);                         // this wave's column stores have left before it reads them back
@@ -828,7 +829,7 @@ static int attention_entry(const char* nm, const void* q, const void* k, const v
                            const float* row_scale, const void* avg, const int64_t* avg_strides,
                            const float* mix, void* out, int out_dtype, const int64_t* out_strides,
                            float* probs_out, int64_t probs_stride_n, const uint8_t* block_path, int flags,
-                           const uint32_t* bits, int64_t T_m, int is_causal, int max_k, sea_stream_t stream) {
+                           const uint32_t* bits, int64_t T_m, int is_causal, int max_k, int write_cols, sea_stream_t stream) {
   SEA_REQUIRE(q && k && v && crow && col && head_off && out && q_strides && k_strides && v_strides && out_strides,
               SEA_EINVAL, "%s: null pointer", nm);
   if (int e = check_dtype(nm, dtype)) return e;
@@ -866,6 +867,7 @@ static int attention_entry(const char* nm, const void* q, const void* k, const v
   p.bits = bits; p.col_w = const_cast<int32_t*>(col); p.T_m = (int)T_m; p.W = (int)((H * T_m + 31) / 32);
   p.max_k = max_k; p.is_causal = is_causal;
   p.fuse_cap = 8192;                                        // entries of a block's key lists held in LDS (32 KB)
+  p.write_cols = write_cols;
   if (bits) {
     SEA_REQUIRE(path != SEA_ATTN_TILE && block_path == nullptr, SEA_EUNSUPPORTED, "%s: the fused interpolation runs on the gather kernels", nm);
     SEA_REQUIRE(T_m > 0 && T_m % 32 == 0 && max_k > 0, SEA_EUNSUPPORTED, "%s: fused interpolation needs T_m %% 32 == 0", nm);
@@ -910,7 +912,7 @@ extern "C" int sea_sparse_attention_ex(const void* q, const void* k, const void*
                                        sea_stream_t stream) {
   return attention_entry("sea_sparse_attention", q, k, v, dtype, N, H, T_dst, T_src, D, q_strides, k_strides, v_strides, crow, col,
                          col_stride_n, head_off, row_scale, avg, avg_strides, mix, out, out_dtype, out_strides, probs_out,
-                         probs_stride_n, block_path, flags, nullptr, 0, 0, 0, stream);
+                         probs_stride_n, block_path, flags, nullptr, 0, 0, 0, 1, stream);
 }
 
 // Steps I + J in ONE launch: the gather kernel expands the selection's kept pixels to key columns itself (the emit's
@@ -925,11 +927,11 @@ extern "C" int sea_sparse_attention_fused(const void* q, const void* k, const vo
                                           const float* row_scale, const void* avg, const int64_t* avg_strides,
                                           const float* mix, void* out, int out_dtype, const int64_t* out_strides,
                                           float* probs_out, int64_t probs_stride_n, const uint32_t* bits, int64_t T_m,
-                                          int is_causal, int max_k, sea_stream_t stream) {
+                                          int is_causal, int max_k, int write_columns, sea_stream_t stream) {
   SEA_REQUIRE(bits != nullptr, SEA_EINVAL, "sea_sparse_attention_fused: null pointer");
   return attention_entry("sea_sparse_attention_fused", q, k, v, dtype, N, H, T_dst, T_src, D, q_strides, k_strides, v_strides, crow,
                          col, col_stride_n, head_off, row_scale, avg, avg_strides, mix, out, out_dtype, out_strides, probs_out,
-                         probs_stride_n, nullptr, SEA_ATTN_GATHER, bits, T_m, is_causal, max_k, stream);
+                         probs_stride_n, nullptr, SEA_ATTN_GATHER, bits, T_m, is_causal, max_k, write_columns != 0, stream);
 }
 
 extern "C" int sea_sparse_attention(const void* q, const void* k, const void* v, int dtype, int64_t N, int64_t H,

@@ -35,6 +35,10 @@ struct AttnParams {
   const uint32_t* bits;
   int32_t* col_w;
   int T_m, W, max_k, is_causal, fuse_cap;
+  // fused interpolation: 0 = the expanded columns stay in LDS (blocks whose lists do not fit still go through `col`): the CSR's
+  // column array is NOT an output of this launch -- the caller's handle keeps its columns pending and sea_csr_emit writes
+  // them if anybody ever reads them (round 4: the copy-out was 266 MB and ~50 us of the headline launch for no reader)
+  int write_cols;
 };
 
 template <typename TO, int VEC> __device__ inline void store_frag(TO* dst, const float* f);

@@ -128,6 +128,11 @@ class PerlinAttention(nn.Module):
         # 537 MB per step at OPT-1.3B x 8) and is computed from the kept conv output the first time a caller touches its
         # values (bit-identical).  False = always write it (the reference's eager tensor, attention.py:1343)
         self.lazy_attention_probs = True
+        # sparse mode: the flat CSR's COLUMN array is an output nobody on the hot path reads (the fused attention launch expands
+        # the kept pixels itself and walks them from LDS); True = that launch does not write it (266 MB per step at OPT-1.3B x
+        # 8) and `partial_attention_mask` keeps its columns pending -- any reader of `.col` / `.col_indices()` / the wire
+        # format runs the emit launch then (bit-identical).  False = written by the step
+        self.lazy_csr_columns = True
         # sparse mode: kernel of steps J-L: "gather" (row-indexed gathers), "tile" (MFMA tile kernel, 16-bit data,
         # d in {64, 80, 128}; wins when neighbouring query rows keep mostly the same keys -- trained predictors), "auto"
         self.sparse_kernel = "auto"
@@ -915,7 +920,7 @@ class PerlinAttention(nn.Module):
                     res = ops.sparse_attention(qs, ks, vs, csr, row_scale=row_scale, avg=average_context_layer,
                                                mix=average_scale, out=ctx.view(N, T, H, HID).permute(0, 2, 1, 3),
                                                want_probs=want_probs, path="gather" if want_probs else self.sparse_kernel,
-                                               plan=plan)
+                                               plan=plan, keep_columns_pending=self.lazy_csr_columns and not want_probs)
                     if want_probs:
                         probs_csr = csr.with_values(res[1])
         if probs_csr is not None:

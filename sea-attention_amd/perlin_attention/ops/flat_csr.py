@@ -394,7 +394,7 @@ def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = 
                      avg: Optional[torch.Tensor] = None, mix: Optional[torch.Tensor] = None,
                      out: Optional[torch.Tensor] = None, out_dtype: Optional[torch.dtype] = None,
                      path: str = "auto", want_probs: bool = False, row_tiles: int = 0, key_window: int = 0,
-                     plan: Optional[torch.Tensor] = None, fuse_emit: bool = True):
+                     plan: Optional[torch.Tensor] = None, fuse_emit: bool = True, keep_columns_pending: bool = False):
     """Fused SDDMM + per-(row,head) softmax + row scale + SpMM (+ mix) over the flat CSR (`sea_sparse_attention_ex`).
 
     q (N,H,T_dst,D), k/v (N,H,T_src,D), any [n,h,t] strides, feature stride 1.
@@ -410,7 +410,10 @@ def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = 
     tile-favouring blocks decides on the device which one runs; the other exits at once); without it "auto" means the
     gather kernels.
     want_probs: also return the per-entry values rs * softmax (fp32, laid out like csr.col) -- what the reference
-    hands out as `partial_attention_probs` (attention.py:1162-1171); returns (out, probs)."""
+    hands out as `partial_attention_probs` (attention.py:1162-1171); returns (out, probs).
+    keep_columns_pending: with a handle whose columns are pending and the fused launch serving it, do NOT write the column
+    array (the launch keeps the expanded columns in LDS): the handle stays pending and whoever reads `.col` later runs the
+    emit launch -- for callers that return the CSR without anybody reading it (the layer's hot path)."""
     lib = _lib.load()
     _lib.require_gpu(q, k, v, csr.crow)
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in (q, k, v, row_scale, avg, mix)):
@@ -449,9 +452,10 @@ def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = 
             _p(row_scale), _p(avg), _lib.strides3(avg) if avg is not None else None, _p(mix),
             _p(out), _lib.dtype_code(out.dtype), _lib.strides3(out),
             _p(probs), probs.stride(0) if probs is not None else 0,
-            _p(csr.bits), T_m_, int(causal_), max_k_, _lib.stream_ptr())
+            _p(csr.bits), T_m_, int(causal_), max_k_, 0 if keep_columns_pending else 1, _lib.stream_ptr())
         if rc == 0:
-            csr._pending = None                             # the launch has written the columns
+            if not keep_columns_pending:
+                csr._pending = None                         # the launch has written the columns
             return (out, probs) if want_probs else out
         if rc != _lib.SEA_EUNSUPPORTED:
             _lib.check(rc, "sea_sparse_attention_fused")

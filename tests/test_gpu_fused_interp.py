@@ -149,7 +149,16 @@ def test_layer_gather_path_fuses_and_returns_the_reference_csr():
         with torch.no_grad():
             outs[mode] = layer(None, None, None, query_layer=x * d ** -0.5, key_layer=x, value_layer=x, attention_mask=mask)
     a, b = outs["gather"], outs["auto"]
-    assert not a.partial_attention_mask.col_is_pending
+    # round 4: the layer leaves the column array unwritten (lazy_csr_columns) -- the handle it returns is still pending and
+    # the first reader below runs the emit launch; with the switch off the step writes it
+    assert a.partial_attention_mask.col_is_pending and b.partial_attention_mask.col_is_pending
+    layer.attention.lazy_csr_columns = False
+    with torch.no_grad():
+        c = layer(None, None, None, query_layer=x * d ** -0.5, key_layer=x, value_layer=x, attention_mask=mask)
+    assert not c.partial_attention_mask.col_is_pending and torch.equal(c.context_layer, b.context_layer)
+    for n in range(N):
+        zc = int(c.partial_attention_mask.crow[n, -1])
+        assert torch.equal(c.partial_attention_mask.col[n, :zc], b.partial_attention_mask.col[n, :zc])
     assert torch.equal(a.estimated_attention_probs_m, b.estimated_attention_probs_m)
     assert torch.equal(a.partial_attention_mask.crow, b.partial_attention_mask.crow)
     probs = a.estimated_attention_probs_m.float().cpu()
@@ -195,3 +204,31 @@ def test_launches_over_groups_of_sequences_equal_the_whole_launch(ops, dtype, d,
     if fused:                     # the parent still believes its columns pending: reading them runs the emit launch -- same values
         assert parts.col_is_pending
         assert torch.equal(parts.col[0, :int(whole.crow[0, -1])], whole._col[0, :int(whole.crow[0, -1])])
+
+
+@pytest.mark.parametrize("dtype,d", [(torch.bfloat16, 64), (torch.float16, 80), (torch.float32, 64), (torch.bfloat16, 128)])
+def test_columns_can_stay_pending_through_the_fused_launch(ops, dtype, d):
+    """`keep_columns_pending` (round 4: the layer's hot path returns the CSR, nobody reads its columns): the fused launch
+    keeps the expanded columns in LDS and does not write the column array -- same output bit for bit, the handle stays
+    pending, and the first reader gets exactly the emit launch's columns.  A block whose lists overflow the LDS list still
+    works (it passes through its part of the array)."""
+    N, H, T, T_M, k = 2, 6, 600, 64, 16
+    g = torch.Generator().manual_seed(21)
+    probs = torch.softmax(torch.randn((N, H, T, T_M), generator=g), -1)
+    probs[1, 2] += 5.0                                                       # item 1: head 2 takes (almost) every kept pixel
+    probs = probs.to(DEV)
+    keep = O.keep_counts_module(H, T, T_M, k).clamp_max(H * T_M).to(torch.int32).contiguous().to(DEV)
+    q, kk, v, rs, mx, avg = _inputs(N, H, T, T, d, dtype, 13)
+    ref_csr, csr = _selection(ops, probs, keep, k, T, defer=True)
+    ref = ops.sparse_attention(q, kk, v, ref_csr, row_scale=rs, avg=avg, mix=mx, path="gather")
+    csr._col.fill_(-7)
+    out = ops.sparse_attention(q, kk, v, csr, row_scale=rs, avg=avg, mix=mx, path="gather", keep_columns_pending=True)
+    torch.cuda.synchronize()
+    assert torch.equal(out, ref)
+    assert csr.col_is_pending, "the handle keeps its columns pending"
+    z0 = int(ref_csr.crow[0, -1])
+    assert bool((csr._col[0, :z0] == -7).all()), "item 0's lists fit the LDS list: nothing of its column array was written"
+    for n in range(N):                                                       # first reader: the emit launch, bit-identical
+        z = int(ref_csr.crow[n, -1])
+        assert torch.equal(csr.col[n, :z], ref_csr.col[n, :z])
+    assert not csr.col_is_pending
