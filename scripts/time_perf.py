@@ -19,6 +19,6 @@ print(json.dumps({"performer_us": round(e0.elapsed_time(e1) / 10 * 1e3, 1), "che
 if os.environ.get("STAMPS"):
     import ctypes
     from sea_attention_amd import _lib
-    lib = _lib.load(); buf = (ctypes.c_ulonglong * 8)()
+    lib = _lib.load(); buf = (ctypes.c_ulonglong * 16)()
     lib.sea_debug_perf_stamps(buf); run(); torch.cuda.synchronize(); lib.sea_debug_perf_stamps(buf)
     tot = sum(buf[i] for i in range(5)); print({n: round(buf[i] / tot, 3) for i, n in enumerate(["stage", "features", "A+den", "O+S", "ksum"])}, "cycles/chunk", tot / (N * H * T / 64))

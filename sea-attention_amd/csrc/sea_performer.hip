@@ -21,10 +21,18 @@
 #include <type_traits>
 
 #ifdef SEA_STAMP
-__device__ unsigned long long sea_dbg_perf[8];
+__device__ unsigned long long sea_dbg_perf[16];
+__device__ unsigned long long sea_dbg_wg[2048];   // [start, end] (s_memrealtime, 100 MHz) of every workgroup of the wide kernel's output pass
 #define PSTAMP(i) do { if (threadIdx.x == 0) { unsigned long long _t = __builtin_amdgcn_s_memtime(); atomicAdd(&sea_dbg_perf[i], _t - _tprev); _tprev = _t; } } while (0)
+// (the wide kernel keeps its deltas in registers and adds them once at the end: an atomic per phase sits in front of every vmcnt wait)
+#define WSTAMP(i) do { if (!STATE_ONLY && threadIdx.x == 0 && (blockIdx.y == 0 || blockIdx.y == gridDim.y - 1)) { unsigned long long _t = __builtin_amdgcn_s_memtime(); _tacc[i] += _t - _tprev; _tprev = _t; } } while (0)
+#define WSTAMP_FLUSH() do { if (!STATE_ONLY && threadIdx.x == 0 && (blockIdx.y == 0 || blockIdx.y == gridDim.y - 1)) for (int _i = 0; _i < 4; ++_i) atomicAdd(&sea_dbg_perf[_i + (blockIdx.y ? 0 : 4)], _tacc[_i]); \
+    if (threadIdx.x == 0) atomicAdd(&sea_dbg_perf[STATE_ONLY ? 8 : 9], __builtin_amdgcn_s_memtime() - _tstart); \
+    if (!STATE_ONLY && threadIdx.x == 0) { const int _w = blockIdx.y * gridDim.x + blockIdx.x; if (_w < 1024) { sea_dbg_wg[2 * _w] = _rstart; sea_dbg_wg[2 * _w + 1] = __builtin_amdgcn_s_memrealtime(); } } } while (0)
 #else
 #define PSTAMP(i) do {} while (0)
+#define WSTAMP(i) do {} while (0)
+#define WSTAMP_FLUSH() do {} while (0)
 #endif
 
 namespace sea {
@@ -511,10 +519,8 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   unsigned short* sAh = sKl + C * LDK2 + (NSET - 1) * (2 * C * LDQ2 + 2 * C * LDK2);   // [C][LDA]   (behind the last set)
   unsigned short* sAl = sAh + C * LDA;
   float* sKsum = reinterpret_cast<float*>(sAl + C * LDA);           // [FP]
-  float* sDen = sKsum + FP;                                         // [C]
-  float* sDenP = sDen + C;                                          // [C][DSL]
+  float* sDenP = sKsum + FP;                                        // [C][DSL]
   float* sKsP = sDenP + C * DSL;                                    // [NW][FP]   per-wave k-sum increments
-  float* sRinv = sKsP + NW * FP;                                    // [C]        1 / (absolute row index + 1)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -614,6 +620,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   };
 #ifdef SEA_STAMP
   unsigned long long _tprev = __builtin_amdgcn_s_memtime();
+  const unsigned long long _rstart64 = __builtin_amdgcn_s_memrealtime();
 #endif
   issue_qk(t_begin);
   issue_v(t_begin);
@@ -655,7 +662,8 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   //       other phi image;
   //   P2  (c_{j+1}): A tiles and partials of chunk j+1;  [pos | v] of chunk j+1 and q, k of chunk j+2 go from the prefetch
   //       registers to LDS (their old images were last read in P1), the loads of chunks j+2 / j+3 are issued;
-  //   P3  denominators, 1 / row index and the k-sum of chunk j+1.
+  //   (until round 4 a third phase P3 -- denominators, 1 / row index and the k-sum of chunk j+1 on a few threads, behind its own
+  //   barrier; now the first lines of (d), see there: TWO barriers per chunk).
   // Results leave straight from the accumulators (8-byte pieces: phase (d) holds four consecutive columns of a row per lane).
   auto rows_of = [&](int t0) { return min(C, t_end - t0); };
   // aligned step, open chunk (always the call's last): its rows produce output but do NOT enter the state -- S, the k-sum
@@ -793,24 +801,30 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
       if (lane < FG) *reinterpret_cast<float4*>(sKsP + wv * FP + fc * 4) = make_float4(k4[0], k4[1], k4[2], k4[3]);
     }
   };
-  auto phase_c2 = [&](int t0, bool upd) {
-    if (tid < C) {
-      float s = 0.f;
-#pragma unroll
-      for (int i = 0; i < DSL; ++i) s += sDenP[tid * DSL + i];
-      sDen[tid] = 1.0f / s;                                  // the 16 column waves multiply by the reciprocal
-      sRinv[tid] = 1.0f / (float)(row_base + t0 + tid + 1);
-    } else if (tid >= C && tid < C + FP) {
-      const int f = tid - C;
-      float s = sKsum[f];
-#pragma unroll
-      for (int i = 0; i < NW; ++i) s += sKsP[i * FP + f];         // fixed order: bitwise reproducible
-      if (upd) sKsum[f] = s;
-    }
-  };
   // ---- (d) O = A V + phi(Q) S over this wave's 16 columns; (e) S += phi(K)^T V ------------------------------
   auto phase_de = [&](int t0, int rows, bool upd, const unsigned short* sQh, const unsigned short* sQl, const unsigned short* sKh,
                       const unsigned short* sKl) {
+    // what a phase of its own (and its barrier) did until round 4: the k-sum takes this chunk's increments (the partials of (c)
+    // read it before, the next chunk's (c) runs behind the next barrier), and every lane sums the denominator partials of ITS
+    // rows -- the same additions in the same order in every lane that holds the row, so nothing changes in the results
+    if (tid < FP) {
+      float s = sKsum[tid];
+#pragma unroll
+      for (int i = 0; i < NW; ++i) s += sKsP[i * FP + tid];       // fixed order: bitwise reproducible
+      if (upd) sKsum[tid] = s;
+    }
+    float dn[RB], ri[RB];
+    if constexpr (!STATE_ONLY) {
+#pragma unroll
+      for (int ib = 0; ib < RB; ++ib) {
+        const int row = ib * 16 + li;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < DSL; ++i) s += sDenP[row * DSL + i];
+        dn[ib] = 1.0f / s;
+        ri[ib] = 1.0f / (float)(row_base + t0 + row + 1);
+      }
+    }
     {
       const int jb = wv, e0 = jb * 16;
       // V fragments (B operand, k = chunk row): rows 32ks + 8lg + {0..3 | 4..7}, columns e0 .. e0+15
@@ -876,10 +890,9 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 #pragma unroll
       for (int ib = 0; ib < RB; ++ib) {
         const int row = ib * 16 + li;
-        const float dn = sDen[row];
         unsigned short ob[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) ob[r] = S16<T>::bits(o[ib][r] * dn);
+        for (int r = 0; r < 4; ++r) ob[r] = S16<T>::bits(o[ib][r] * dn[ib]);
         const uint2 w2 = pack4(ob);
         typedef __attribute__((ext_vector_type(2))) unsigned int bu2;
         __builtin_amdgcn_raw_buffer_store_b64(bu2{w2.x, w2.y}, ro, (row < rows && t0 + row >= lead) ? ((t0 + row) * (3 * D) + col) * 2 : (int)OOB, 0, 0);
@@ -896,10 +909,9 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 #pragma unroll
         for (int ib = 0; ib < RB; ++ib) {
           const int row = ib * 16 + li;
-          const float ri = sRinv[row];
           unsigned short gb4[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) gb4[r] = S16<T>::bits((cum[ib][r] + csum[r]) * ri);
+          for (int r = 0; r < 4; ++r) gb4[r] = S16<T>::bits((cum[ib][r] + csum[r]) * ri[ib]);
           const uint2 w2 = pack4(gb4);
           typedef __attribute__((ext_vector_type(2))) unsigned int bu2;
           __builtin_amdgcn_raw_buffer_store_b64(bu2{w2.x, w2.y}, rg, (row < rows && t0 + row >= lead) ? ((t0 + row) * D + gcol) * 2 : (int)OOB, 0, 0);
@@ -935,7 +947,7 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
     phase_de(t0, rows_of(t0), upd_of(t0), sQh + buf * PHI, sQl + buf * PHI, sKh + buf * PHI, sKl + buf * PHI);
   };
   if (t_begin < t_end) {
-    // prologue: chunk 0 through (b), (c), (c'); chunk 1's q, k staged; loads of chunk 1 ([pos | v]) and chunk 2 (q, k) in flight
+    // prologue: chunk 0 through (b), (c); chunk 1's q, k staged; loads of chunk 1 ([pos | v]) and chunk 2 (q, k) in flight
     stage_qk();
     stage_v(t_begin);
     issue_qk(t_begin + C);
@@ -946,8 +958,6 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
     run_c(0);
     stage_qk();
     issue_qk(t_begin + 2 * C);
-    __syncthreads();
-    phase_c2(t_begin, upd_of(t_begin));
     __syncthreads();
     int buf = 0;
     for (int t0 = t_begin; t0 < t_end; t0 += C, buf ^= (NSET - 1)) {
@@ -968,9 +978,6 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
       }
       __syncthreads();
       PSTAMP(1);
-      if (has_next) phase_c2(t0 + C, upd_of(t0 + C));
-      __syncthreads();
-      PSTAMP(2);
     }
   }
   if constexpr (STATE_ONLY) {
@@ -984,6 +991,9 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
   } else {
     // the block that walked the last rows holds the final state (aligned step: the state at the last chunk boundary)
     if (p.state_out && seg == p.nseg - 1) write_state();
+#ifdef SEA_STAMP
+    if (threadIdx.x == 0) { const int _w = blockIdx.y * gridDim.x + blockIdx.x; if (_w < 1024) { sea_dbg_wg[2 * _w] = _rstart64; sea_dbg_wg[2 * _w + 1] = __builtin_amdgcn_s_memrealtime(); } }
+#endif
   }
 }
 
@@ -993,7 +1003,9 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 // on the first C * D / 8 threads, the head dimension zero-padded to whole 32-wide k-steps (D = 80: 96) in the operand
 // images of the feature-map product, and a V image of 512-byte rows whose chunk swizzle spreads the eight rows of a
 // transposing read over the eight 8-bank groups.  Everything else -- split operands, transposed products, transposing
-// reads, the cumulative average on the matrix cores, segments, state images -- is the D = 64 kernel's.
+// reads, the cumulative average on the matrix cores, segments, state images, and (round 4) the chunk walk pipelined over
+// three barriers with two sets of phi images and results stored straight from the accumulators -- is the D = 64 kernel's.
+// The 25 KB of result tiles the first version flushed one chunk later paid for the second image set (d = 128: 120 KB).
 template <typename T, int D, int C, int NBT, bool STATE_ONLY>
 __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
   constexpr int NW = 8, NTH = 512, E = 2 * D, CPR = D / 8;
@@ -1005,34 +1017,26 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
   constexpr int KF = (NBT + 1) / 2;            // 32-wide k-steps over the (padded) features
   constexpr int FP = KF * 32;                  // padded feature count
   constexpr int RB = C / 16, EB = E / 16, JB = (EB + NW - 1) / NW, NPART = 8;
-  // LDS row strides picked with a bank model of the two access patterns (64 banks x 4 B; b128 row reads are served in
-  // 4 lane groups of 16, transposing b64 reads in 2 of 32): 160 / 224 B rows make the operand row reads conflict-free
-  // (4 cycles per wave instruction; the first version's 144 B rows: 8), 192 B rows halve the conflicts of the
-  // transposing reads of phi(K) (4 cycles; 144 B: 8; the conflict-free 2 needs a swizzle); rows stay 16-byte multiples
+  // (b) runs on all eight waves: a (Q | K, row block) pair is shared by BW waves, each taking FBP of the feature blocks
+  constexpr int BW = NW / (2 * RB), FBP = (NBT + BW - 1) / BW;
+  static_assert(2 * RB * BW == NW, "feature-map product: whole waves per (tensor, row block)");
+  // LDS row strides: see the D = 64 kernel (bank model of the b128 row reads and the transposing b64 reads)
   constexpr int LDQ2 = FP + 16;                // phi(Q) rows (elements): row reads only
   constexpr int LDK2 = (FP == 64) ? 96 : FP + 8; // phi(K) rows (16-byte multiples): transposing reads + a few row reads
   constexpr int LDA = C + 16;                  // A rows: row reads only
   constexpr int DSL = RB + NPART;              // denominator partial slots per row
+  constexpr int PHI = 2 * C * LDQ2 + 2 * C * LDK2;          // elements of one phi image set (Qh, Ql, Kh, Kl)
   extern __shared__ __attribute__((aligned(16))) char smem_b[];
   unsigned short* sW = reinterpret_cast<unsigned short*>(smem_b);   // [KC][NBP][8]  projection, k-chunked (zero padded)
   unsigned short* sQ = sW + KC * NBP * 8;                           // [KC][C][8]    (chunks >= D / 8: zero)
   unsigned short* sK = sQ + KC * C * 8;                             // [KC][C][8]
   unsigned short* sV = sK + KC * C * 8;                             // [C][EL] 512-byte rows, chunk-swizzled
-  unsigned short* sQh = sV + C * EL;                                // [C][LDQ2]
-  unsigned short* sQl = sQh + C * LDQ2;
-  unsigned short* sKh = sQl + C * LDQ2;                             // [C][LDK2]
-  unsigned short* sKl = sKh + C * LDK2;
-  unsigned short* sAh = sKl + C * LDK2;                             // [C][LDA]
+  unsigned short* sPhi = sV + C * EL;                               // [2][ [C][LDQ2] x 2, [C][LDK2] x 2 ]: two chunks in flight
+  unsigned short* sAh = sPhi + 2 * PHI;                             // [C][LDA]
   unsigned short* sAl = sAh + C * LDA;
-  constexpr int LDO = E + 8;
-  unsigned short* sO = sAl + C * LDA;                               // [C][LDO]  the chunk's result rows, flushed one chunk later
-  constexpr int LDG = D + 8;
-  unsigned short* sAvg = sO + C * LDO;                              // [C][LDG]  cumulative-average rows (optional output)
-  float* sKsum = reinterpret_cast<float*>(sAvg + C * LDG);          // [FP]
-  float* sDen = sKsum + FP;                                         // [C]
-  float* sDenP = sDen + C;                                          // [C][DSL]
+  float* sKsum = reinterpret_cast<float*>(sAl + C * LDA);           // [FP]
+  float* sDenP = sKsum + FP;                                        // [C][DSL]
   float* sKsP = sDenP + C * DSL;                                    // [NW][FP]   per-wave k-sum increments
-  float* sRinv = sKsP + NW * FP;                                    // [C]        1 / (absolute row index + 1)
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1064,16 +1068,20 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
   if constexpr (KC > CPR)                                  // padded k-chunks of the q / k images: zero, never written again
     for (int i = tid; i < (KC - CPR) * C * 8; i += NTH) sQ[CPR * C * 8 + i] = sK[CPR * C * 8 + i] = 0;
   // phi and A images: padded features / upper-triangular tiles are written once (zero) and never again
-  for (int i = tid; i < 2 * C * LDQ2 + 2 * C * LDK2 + 2 * C * LDA; i += NTH) sQh[i] = 0;
+  for (int i = tid; i < 2 * PHI + 2 * C * LDA; i += NTH) sPhi[i] = 0;
   for (int i = tid; i < C * DSL; i += NTH) sDenP[i] = 0.f;   // slots of key blocks above the diagonal stay zero
 
-  // carry image of one (n, h, segment): per-thread state registers, the k-sum, the per-thread column sum of v
+  // carry image of one (n, h, segment): per-thread state registers, the k-sum, the column sums of v
   constexpr int CARRY = JB * NBT * 4 * NTH + FP + JB * NTH;
   f4 S[JB][NBT];
-  float csum[JB];                                          // running column sums of v (cumulative-average output)
+  // running column sums of v (cumulative-average output): in the transposed accumulator layout of (d) a lane owns the four
+  // columns e0 + 4 lg + r of each of its wave's blocks; image slot of column r of block jq: jq * NTH + (tid & ~15) + r
+  float csum[JB][4];
+  const int cslot = (tid & ~15);
 #pragma unroll
   for (int jq = 0; jq < JB; ++jq) {
-    csum[jq] = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) csum[jq][r] = 0.f;
 #pragma unroll
     for (int b = 0; b < NBT; ++b) S[jq][b] = f4{0.f, 0.f, 0.f, 0.f};
   }
@@ -1087,7 +1095,8 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
         for (int b = 0; b < NBT; ++b)
 #pragma unroll
           for (int r = 0; r < 4; ++r) S[jq][b][r] = cr[((jq * NBT + b) * 4 + r) * NTH + tid];
-        csum[jq] = cr[JB * NBT * 4 * NTH + FP + jq * NTH + tid];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) csum[jq][r] = cr[JB * NBT * 4 * NTH + FP + jq * NTH + cslot + r];
       }
       if (tid < FP) ks0 = cr[JB * NBT * 4 * NTH + tid];
     }
@@ -1100,7 +1109,8 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
           for (int b = 0; b < NBT; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) S[jq][b][r] += cr[((jq * NBT + b) * 4 + r) * NTH + tid];
-          csum[jq] += cr[JB * NBT * 4 * NTH + FP + jq * NTH + tid];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) csum[jq][r] += cr[JB * NBT * 4 * NTH + FP + jq * NTH + cslot + r];
         }
         if (tid < FP) ks0 += cr[JB * NBT * 4 * NTH + tid];
       }
@@ -1108,8 +1118,11 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
     if (tid < FP) sKsum[tid] = ks0;
   }
 
-  // one 16-byte piece of each tensor per thread and chunk; prefetched one chunk ahead
-  const int sr = tid / CPR, sc = tid - sr * CPR;   // staging row, 8-element column chunk
+  // one 16-byte piece of each tensor per thread and chunk; q, k prefetched two chunks ahead, [pos | v] one
+  // (D = 80: the LAST C * D / 8 = 320 threads stage -- waves 0 and 1 carry a second column block in (d)(e))
+  const bool stager = tid >= NTH - STG;
+  const int stid = stager ? tid - (NTH - STG) : 0;
+  const int sr = stid / CPR, sc = stid - sr * CPR;   // staging row, 8-element column chunk
   // All global traffic goes through buffer instructions with hardware range checking: a row beyond T reads zeros /
   // drops its store WITHOUT a branch.  (Branches around loads and stores make the compiler's vmcnt bookkeeping
   // pessimistic: the wait for the prefetched chunk then also waits for every output store of the previous one.)
@@ -1120,33 +1133,29 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
   const __amdgpu_buffer_rsrc_t rq = mk(qb, p.qs[2]), rk = mk(kb, p.ks[2]), rv = mk(vb, p.vs[2]), rp = mk(pb, p.pos_stride);
   const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(ob, 0, (int)((int64_t)TL * 3 * D * 2), 0x00020000);
   typedef __attribute__((ext_vector_type(4))) unsigned int bu4;
+  typedef __attribute__((ext_vector_type(2))) unsigned int bu2;
   const bool want_avg = p.avg != nullptr;                  // block-uniform
   T* gb = reinterpret_cast<T*>(p.avg) + (want_avg ? (int64_t)nh * p.T * D - (int64_t)lead * D : 0);
   const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(gb, 0, want_avg ? (int)((int64_t)TL * D * 2) : 0, 0x00020000);
-  bu4 pq, pk, pv, pp;
-  auto issue_loads = [&](int t0n) {
+  // two sets of prefetch registers: every load has two chunk times between issue and use (the last segment's k, v and every
+  // segment's q come from HBM cold -- the state pass reads k, v of the segments before the last only -- and one chunk time did
+  // not cover that: the workgroups of the last segment ran 10 us behind the others)
+  struct Pre { bu4 q, k, v, p; };
+  Pre pa, pn;
+  auto issue_qk = [&](int t0n, Pre& r) {
     const int t = t0n + sr;
-    const bool ok = t < t_end && (STG == NTH || tid < STG);
-    pq = __builtin_amdgcn_raw_buffer_load_b128(rq, (ok && !STATE_ONLY && t >= lead) ? (int)((t * p.qs[2] + sc * 8) * 2) : (int)OOB, 0, 0);
-    pk = __builtin_amdgcn_raw_buffer_load_b128(rk, ok ? (int)((t * p.ks[2] + sc * 8) * 2) : (int)OOB, 0, 0);
-    pv = __builtin_amdgcn_raw_buffer_load_b128(rv, ok ? (int)((t * p.vs[2] + sc * 8) * 2) : (int)OOB, 0, 0);
-    pp = __builtin_amdgcn_raw_buffer_load_b128(rp, ok ? (int)((t * p.pos_stride + sc * 8) * 2) : (int)OOB, 0, 0);
+    const bool ok = t < t_end && stager;
+    r.q = __builtin_amdgcn_raw_buffer_load_b128(rq, (ok && !STATE_ONLY && t >= lead) ? (int)((t * p.qs[2] + sc * 8) * 2) : (int)OOB, 0, 0);
+    r.k = __builtin_amdgcn_raw_buffer_load_b128(rk, ok ? (int)((t * p.ks[2] + sc * 8) * 2) : (int)OOB, 0, 0);
   };
-  issue_loads(t_begin);
-  // the result tile of a chunk leaves LDS as 16-byte row pieces at the START of the next chunk, i.e. before that
-  // chunk's prefetch loads are issued: a wait for those loads never has younger stores in front of it
-  auto flush_out = [&](int t0p, int rowsp) {
-#pragma unroll
-    for (int i = tid; i < C * (E / 8); i += NTH) {
-      const int row = i / (E / 8), ch = i - row * (E / 8);
-      const bu4 v = *reinterpret_cast<const bu4*>(sO + row * LDO + ch * 8);
-      __builtin_amdgcn_raw_buffer_store_b128(v, ro, (row < rowsp && t0p + row >= lead) ? ((t0p + row) * (3 * D) + ch * 8) * 2 : (int)OOB, 0, 0);
-    }
-    if (want_avg && (STG == NTH || tid < STG)) {           // C * D / 8 pieces: one per staging thread
-      const bu4 v = *reinterpret_cast<const bu4*>(sAvg + sr * LDG + sc * 8);
-      __builtin_amdgcn_raw_buffer_store_b128(v, rg, (sr < rowsp && t0p + sr >= lead) ? ((t0p + sr) * D + sc * 8) * 2 : (int)OOB, 0, 0);
-    }
+  auto issue_v = [&](int t0n, Pre& r) {
+    const int t = t0n + sr;
+    const bool ok = t < t_end && stager;
+    r.v = __builtin_amdgcn_raw_buffer_load_b128(rv, ok ? (int)((t * p.vs[2] + sc * 8) * 2) : (int)OOB, 0, 0);
+    r.p = __builtin_amdgcn_raw_buffer_load_b128(rp, ok ? (int)((t * p.pos_stride + sc * 8) * 2) : (int)OOB, 0, 0);
   };
+  issue_qk(t_begin, pa);
+  issue_v(t_begin, pa);
   // swizzled chunk position inside a row of the V image (conflict-free transposing reads):
   // 512-byte rows (32 chunks): rows {r..r+3, r+8..r+11} of one transposing read get the eight values of
   // (row & 3) | (bit 3 of row) << 2 XOR-ed into bits 1..3 of the chunk index -> eight disjoint 8-bank groups
@@ -1163,84 +1172,105 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
     return cat8(pack4(o0), pack4(o1));
   };
 
-  uint4 tril[RB][C / 32];                                  // loop-invariant A operands of the prefix-sum product
+  uint4 tril[RB][C / 32];                                  // loop-invariant operands of the prefix-sum product
 #pragma unroll
   for (int ib = 0; ib < RB; ++ib)
 #pragma unroll
     for (int ks = 0; ks < C / 32; ++ks) tril[ib][ks] = tril_frag(ib, ks);
 
-  auto write_state = [&]() {                               // this thread's part of the (n, h) image
-    float* cw = p.state_out + (int64_t)nh * CARRY;
+  auto write_image = [&](float* cw) {                      // this thread's part of an (n, h[, segment]) image
 #pragma unroll
     for (int jq = 0; jq < JB; ++jq) {
 #pragma unroll
       for (int b = 0; b < NBT; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) cw[((jq * NBT + b) * 4 + r) * NTH + tid] = S[jq][b][r];
-      cw[JB * NBT * 4 * NTH + FP + jq * NTH + tid] = csum[jq];
+      float* cs = cw + JB * NBT * 4 * NTH + FP + jq * NTH + tid;    // lane li = 0 writes the group's four sums, lanes >= 4 zeros
+      if (li == 0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) cs[r] = csum[jq][r];
+      } else if (li >= 4) cs[0] = 0.f;
     }
     if (tid < FP) cw[JB * NBT * 4 * NTH + tid] = sKsum[tid];
   };
 
-  for (int t0 = t_begin; t0 < t_end; t0 += C) {
-    const int rows = min(C, t_end - t0);
-    const bool upd = !(p.aligned && rows < C);             // an open last chunk leaves the state at the boundary (see the d = 64 kernel)
-    // ---- (a) staging ---------------------------------------------------------------------------------
-    if (!STATE_ONLY) __builtin_amdgcn_raw_buffer_store_b128(pv, ro, (sr < rows && t0 + sr >= lead) ? ((t0 + sr) * (3 * D) + 2 * D + sc * 8) * 2 : (int)OOB, 0, 0);
-    if (STG == NTH || tid < STG) {
-      // row slot XOR chunk: the 16 lanes of a b128 store (one row x 16 chunks at D = 128; chunk images are 512 B = 0 mod 64
-      // banks apart) land in 16 different 4-bank groups instead of one; the reads below permute inside their 16-row runs
-      *reinterpret_cast<bu4*>(sQ + (sc * C + (sr ^ sc)) * 8) = pq;
-      *reinterpret_cast<bu4*>(sK + (sc * C + (sr ^ sc)) * 8) = pk;
-      *reinterpret_cast<bu4*>(sV + sr * EL + vchunk(sr, sc) * 8) = pp;
-      *reinterpret_cast<bu4*>(sV + sr * EL + vchunk(sr, CPR + sc) * 8) = pv;
+  // ---- the chunk walk: the D = 64 kernel's three-barrier pipeline (P1 = (d)(e) of chunk j + (b) of chunk j+1 into the other
+  // image set; P2 = (c) of chunk j+1, staging of [pos | v] of chunk j+1 and q, k of chunk j+2, loads issued; P3 = denominators
+  // and k-sum of chunk j+1) ----------------------------------------------------------------------------------------------------
+  auto rows_of = [&](int t0) { return min(C, t_end - t0); };
+  auto upd_of = [&](int t0) { return !(p.aligned && rows_of(t0) < C); };   // an open last chunk leaves the state at the boundary
+  auto stage_qk = [&](const Pre& r) {
+    // row slot XOR chunk: the 16 lanes of a b128 store (one row x 16 chunks at D = 128; chunk images are 512 B = 0 mod 64
+    // banks apart) land in 16 different 4-bank groups instead of one; the reads of (b) permute inside their 16-row runs
+    if (stager) {
+      *reinterpret_cast<bu4*>(sQ + (sc * C + (sr ^ sc)) * 8) = r.q;
+      *reinterpret_cast<bu4*>(sK + (sc * C + (sr ^ sc)) * 8) = r.k;
     }
-    if (!STATE_ONLY && t0 > t_begin) flush_out(t0 - C, C);                     // (block-uniform)
-    issue_loads(t0 + C);                                                      // rows beyond T come back as zeros
-    __syncthreads();
-
-    // ---- (b) feature maps, transposed: X^T[f][t] = sum_d W[f][d] x[t][d]; wave = (Q | K, row block) ----------
-    if (wv < 2 * RB && (!STATE_ONLY || wv >= RB)) {          // the state-only pass needs phi(K) alone (wave-uniform)
-      const int which = wv / RB, rb = wv - which * RB;
+  };
+  auto stage_v = [&](int t0, const Pre& r) {                 // chunk t0's [pos | v] rows; v also is the third block of the output
+    const int rows = rows_of(t0);
+    if (!STATE_ONLY) __builtin_amdgcn_raw_buffer_store_b128(r.v, ro, (stager && sr < rows && t0 + sr >= lead) ? ((t0 + sr) * (3 * D) + 2 * D + sc * 8) * 2 : (int)OOB, 0, 0);
+    if (stager) {
+      *reinterpret_cast<bu4*>(sV + sr * EL + vchunk(sr, sc) * 8) = r.p;
+      *reinterpret_cast<bu4*>(sV + sr * EL + vchunk(sr, CPR + sc) * 8) = r.v;
+    }
+  };
+  // ---- (b) feature maps, transposed: X^T[f][t] = sum_d W[f][d] x[t][d]; wave = (Q | K, row block, part of the feature blocks) ----
+  auto phase_b = [&](int rows, unsigned short* set) {
+    const int which = wv / (NW / 2);
+    if (!STATE_ONLY || which == 1) {                         // the state-only pass needs phi(K) alone (wave-uniform)
+      // D = 80: waves 0 and 1 (SIMDs 0, 1) own a second column block in (d)(e), so the larger share of the feature blocks goes
+      // to the waves of SIMDs 2 and 3
+      const int rb = wv & (RB - 1), part = (BW - 1) - ((wv % (NW / 2)) / RB);
       const unsigned short* src = which ? sK : sQ;
-      f4 acc[NBT];
+      f4 acc[FBP];
 #pragma unroll
-      for (int fb = 0; fb < NBT; ++fb) acc[fb] = f4{0.f, 0.f, 0.f, 0.f};
+      for (int fb = 0; fb < FBP; ++fb) acc[fb] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < DP / 32; ++ks) {
         const uint4 bx = *reinterpret_cast<const uint4*>(src + ((4 * ks + lg) * C + ((rb * 16 + li) ^ ((4 * ks + lg) & 15))) * 8);
 #pragma unroll
-        for (int fb = 0; fb < NBT; ++fb) {
-          const uint4 aw = *reinterpret_cast<const uint4*>(sW + ((4 * ks + lg) * NBP + fb * 16 + li) * 8);
-          acc[fb] = S16<T>::mfma(aw, bx, acc[fb]);
+        for (int fb = 0; fb < FBP; ++fb) {
+          const int fbg = part * FBP + fb;                   // (wave-uniform)
+          if (fbg < NBT) {
+            const uint4 aw = *reinterpret_cast<const uint4*>(sW + ((4 * ks + lg) * NBP + fbg * 16 + li) * 8);
+            acc[fb] = S16<T>::mfma(aw, bx, acc[fb]);
+          }
         }
       }
-      unsigned short* dh = which ? sKh : sQh;
-      unsigned short* dl = which ? sKl : sQl;
+      const int ldx = which ? LDK2 : LDQ2;
+      unsigned short* dh = set + (which ? 2 * C * LDQ2 : 0);
+      unsigned short* dl = dh + C * ldx;
       const int row = rb * 16 + li;                          // lane: 4 consecutive features of one row
 #pragma unroll
-      for (int fb = 0; fb < NBT; ++fb) {
-        unsigned short hh[4], ll[4];
+      for (int fb = 0; fb < FBP; ++fb) {
+        const int fbg = part * FBP + fb;
+        if (fbg < NBT) {
+          unsigned short hh[4], ll[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int f = fb * 16 + lg * 4 + r;
-          float val = fmaxf(cnorm * acc[fb][r], 0.f) + 1e-3f;
-          if (f >= p.nb || row >= rows) val = 0.f;           // padded features / rows beyond T contribute nothing
-          split16<T>(val, hh[r], ll[r]);
+          for (int r = 0; r < 4; ++r) {
+            const int f = fbg * 16 + lg * 4 + r;
+            float val = fmaxf(cnorm * acc[fb][r], 0.f) + 1e-3f;
+            if (f >= p.nb || row >= rows) val = 0.f;           // padded features / rows beyond T contribute nothing
+            split16<T>(val, hh[r], ll[r]);
+          }
+          // feature 32kk + 16a + 4g + j is stored at position 32kk + 8g + 4a + j: the 8 features lane group g needs of
+          // a 32-wide k-step in (d) (4 of tile 2kk, 4 of tile 2kk+1) are then one 16-byte piece
+          const int pos = (fbg >> 1) * 32 + lg * 8 + (fbg & 1) * 4;
+          *reinterpret_cast<uint2*>(dh + row * ldx + pos) = pack4(hh);
+          *reinterpret_cast<uint2*>(dl + row * ldx + pos) = pack4(ll);
         }
-        // feature 32kk + 16a + 4g + j is stored at position 32kk + 8g + 4a + j: the 8 features lane group g needs of
-        // a 32-wide k-step in (d) (4 of tile 2kk, 4 of tile 2kk+1) are then one 16-byte piece
-        const int pos = (fb >> 1) * 32 + lg * 8 + (fb & 1) * 4;
-        const int ldx = which ? LDK2 : LDQ2;
-        *reinterpret_cast<uint2*>(dh + row * ldx + pos) = pack4(hh);
-        *reinterpret_cast<uint2*>(dl + row * ldx + pos) = pack4(ll);
       }
     }
-    __syncthreads();
-
-    // ---- (c) A^T tiles (lower triangle), denominator and k-sum partials ------------------------------------
+  };
+  // ---- (c) A^T tiles (lower triangle), denominator and k-sum partials ------------------------------------
+  auto phase_c = [&](const unsigned short* set) {
+    const unsigned short* sQh = set;
+    const unsigned short* sQl = sQh + C * LDQ2;
+    const unsigned short* sKh = sQl + C * LDQ2;
+    const unsigned short* sKl = sKh + C * LDK2;
     if constexpr (!STATE_ONLY)
-    for (int tile = wv; tile < RB * (RB + 1) / 2; tile += NW) {
+    for (int tile = wv; tile < RB * (RB + 1) / 2; tile += NW) {   // (the first waves: they stage nothing at D = 80)
       int ib = 0, rem = tile;
       while (rem > ib) { rem -= ib + 1; ++ib; }              // tile -> (query block ib, key block jb <= ib)
       const int jb = rem;
@@ -1291,7 +1321,7 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
         s = fmaf(S16<T>::val((unsigned short)(qh.y >> 16)) + S16<T>::val((unsigned short)(ql.y >> 16)), ks.w + 1e-6f, s);
       }
       if (part < NPART) sDenP[row * DSL + RB + part] = s;
-      // k-sum increment: wave w owns rows 8w .. 8w+7; lane = (4-position group fc, row lane rr)
+      // k-sum increment: wave w owns rows 4w .. 4w+3; lane = (4-position group fc, row lane rr)
       constexpr int FG = FP / 4, RRN = 64 / FG, RPL = (C / NW) / RRN;
       const int fc = lane % FG, rr = lane / FG;
       float k4[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1318,28 +1348,39 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
       }
       if (lane < FG) *reinterpret_cast<float4*>(sKsP + wv * FP + fc * 4) = make_float4(k4[0], k4[1], k4[2], k4[3]);
     }
-    __syncthreads();
-    if (tid < C) {
-      float s = 0.f;
+  };
+  // ---- (d) O = A V + phi(Q) S over this wave's column blocks; (e) S += phi(K)^T V ------------------------------
+  auto phase_de = [&](int t0, int rows, bool upd, const unsigned short* set) {
+    const unsigned short* sQh = set;
+    const unsigned short* sQl = sQh + C * LDQ2;
+    const unsigned short* sKh = sQl + C * LDQ2;
+    const unsigned short* sKl = sKh + C * LDK2;
+    // what a phase of its own (and its barrier) did in the first version: the k-sum takes this chunk's increments (the partials
+    // of (c) read it before, the next chunk's (c) runs behind the next barrier), and every lane sums the denominator partials of
+    // ITS rows -- the same additions in the same order in every lane that holds the row
+    if (tid < FP) {
+      float s = sKsum[tid];
 #pragma unroll
-      for (int i = 0; i < DSL; ++i) s += sDenP[tid * DSL + i];
-      sDen[tid] = 1.0f / s;                                  // the 16 column waves multiply by the reciprocal
-      sRinv[tid] = 1.0f / (float)(row_base + t0 + tid + 1);
-    } else if (tid >= C && tid < C + FP) {
-      const int f = tid - C;
-      float s = sKsum[f];
-#pragma unroll
-      for (int i = 0; i < NW; ++i) s += sKsP[i * FP + f];         // fixed order: bitwise reproducible
-      if (upd) sKsum[f] = s;
+      for (int i = 0; i < NW; ++i) s += sKsP[i * FP + tid];       // fixed order: bitwise reproducible
+      if (upd) sKsum[tid] = s;
     }
-    __syncthreads();
-
-    // ---- (d) O = A V + phi(Q) S over this wave's 16 columns; (e) S += phi(K)^T V ------------------------------
+    float dn[RB], ri[RB];
+    if constexpr (!STATE_ONLY) {
+#pragma unroll
+      for (int ib = 0; ib < RB; ++ib) {
+        const int row = ib * 16 + li;
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < DSL; ++i) s += sDenP[row * DSL + i];
+        dn[ib] = 1.0f / s;
+        ri[ib] = 1.0f / (float)(row_base + t0 + row + 1);
+      }
+    }
 #pragma unroll
     for (int jq = 0; jq < JB; ++jq) {
       const int jb = wv + jq * NW, e0 = jb * 16;
       if (EB % NW != 0 && jb >= EB) break;                 // wave-uniform: no such column block
-      // V fragments (B operand, k = chunk row): rows 32ks + 8lg + {0..3 | 4..7}, columns e0 .. e0+15
+      // V fragments (k = chunk row): rows 32ks + 8lg + {0..3 | 4..7}, columns e0 .. e0+15
       uint4 vf[C / 32];
       {
         const int q = li >> 2, pp_ = li & 3;
@@ -1355,13 +1396,16 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
         if (want_avg && jb >= EB / 2) {                    // column total of the chunk = the last row's prefix
           f4 cum = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int ks = 0; ks <= (RB - 1) / 2; ++ks) cum = S16<T>::mfma(tril[RB - 1][ks], vf[ks], cum);
-          csum[jq] += __shfl(cum[3], 48 + li);
+          for (int ks = 0; ks <= (RB - 1) / 2; ++ks) cum = S16<T>::mfma(vf[ks], tril[RB - 1][ks], cum);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) csum[jq][r] += __shfl(cum[r], (lane & 48) | 15);
         }
       } else {
       f4 o[RB];
 #pragma unroll
       for (int ib = 0; ib < RB; ++ib) o[ib] = f4{0.f, 0.f, 0.f, 0.f};
+      // Operands SWAPPED as in the D = 64 kernel (O^T = V^T A^T + S^T phi(Q)^T; the A and B fragment layouts mirror each other):
+      // the accumulator of query block ib holds, per lane, row ib*16 + li and the four consecutive columns e0 + 4 lg + r.
       // A V: key k-step ks covers key blocks 2ks, 2ks+1; query block ib needs k-steps <= ib/2
 #pragma unroll
       for (int ib = 0; ib < RB; ++ib) {
@@ -1369,11 +1413,11 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
         for (int ks = 0; ks <= ib / 2; ++ks) {
           const uint4 ah = *reinterpret_cast<const uint4*>(sAh + (ib * 16 + li) * LDA + ks * 32 + lg * 8);
           const uint4 al = *reinterpret_cast<const uint4*>(sAl + (ib * 16 + li) * LDA + ks * 32 + lg * 8);
-          o[ib] = S16<T>::mfma(ah, vf[ks], o[ib]);
-          o[ib] = S16<T>::mfma(al, vf[ks], o[ib]);
+          o[ib] = S16<T>::mfma(vf[ks], ah, o[ib]);
+          o[ib] = S16<T>::mfma(vf[ks], al, o[ib]);
         }
       }
-      // phi(Q) S: the state tiles, split, are the B operand; k-step kk pairs feature blocks 2kk and 2kk+1
+      // phi(Q) S: the state tiles, split; k-step kk pairs feature blocks 2kk and 2kk+1
 #pragma unroll
       for (int kk = 0; kk < KF; ++kk) {
         unsigned short h0[4], h1[4], l0[4], l1[4];
@@ -1388,19 +1432,20 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
         for (int ib = 0; ib < RB; ++ib) {
           const uint4 ah = *reinterpret_cast<const uint4*>(sQh + (ib * 16 + li) * LDQ2 + kk * 32 + lg * 8);
           const uint4 al = *reinterpret_cast<const uint4*>(sQl + (ib * 16 + li) * LDQ2 + kk * 32 + lg * 8);
-          o[ib] = S16<T>::mfma(ah, bh, o[ib]);
-          o[ib] = S16<T>::mfma(ah, bl, o[ib]);
-          o[ib] = S16<T>::mfma(al, bh, o[ib]);
+          o[ib] = S16<T>::mfma(bh, ah, o[ib]);
+          o[ib] = S16<T>::mfma(bl, ah, o[ib]);
+          o[ib] = S16<T>::mfma(bh, al, o[ib]);
         }
       }
-      const int col = e0 + li;
+      const int col = e0 + 4 * lg;
 #pragma unroll
       for (int ib = 0; ib < RB; ++ib) {
+        const int row = ib * 16 + li;
+        unsigned short o4[4];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = ib * 16 + lg * 4 + r;
-          sO[row * LDO + col] = S16<T>::bits(o[ib][r] * sDen[row]);
-        }
+        for (int r = 0; r < 4; ++r) o4[r] = S16<T>::bits(o[ib][r] * dn[ib]);
+        const uint2 w2 = pack4(o4);
+        __builtin_amdgcn_raw_buffer_store_b64(bu2{w2.x, w2.y}, ro, (row < rows && t0 + row >= lead) ? ((t0 + row) * (3 * D) + col) * 2 : (int)OOB, 0, 0);
       }
       if (want_avg && jb >= EB / 2) {                      // wave-uniform: this wave's 16 columns are v features
         f4 cum[RB];
@@ -1408,17 +1453,22 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
         for (int ib = 0; ib < RB; ++ib) {
           cum[ib] = f4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-          for (int ks = 0; ks <= ib / 2; ++ks) cum[ib] = S16<T>::mfma(tril[ib][ks], vf[ks], cum[ib]);
+          for (int ks = 0; ks <= ib / 2; ++ks) cum[ib] = S16<T>::mfma(vf[ks], tril[ib][ks], cum[ib]);
         }
         const int gcol = col - D;
 #pragma unroll
-        for (int ib = 0; ib < RB; ++ib)
+        for (int ib = 0; ib < RB; ++ib) {
+          const int row = ib * 16 + li;
+          unsigned short g4[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = ib * 16 + lg * 4 + r;
-            sAvg[row * LDG + gcol] = S16<T>::bits((cum[ib][r] + csum[jq]) * sRinv[row]);
-          }
-        if (upd) csum[jq] += __shfl(cum[RB - 1][3], 48 + li);   // column total of the chunk = its last row's prefix
+          for (int r = 0; r < 4; ++r) g4[r] = S16<T>::bits((cum[ib][r] + csum[jq][r]) * ri[ib]);
+          const uint2 w2 = pack4(g4);
+          __builtin_amdgcn_raw_buffer_store_b64(bu2{w2.x, w2.y}, rg, (row < rows && t0 + row >= lead) ? ((t0 + row) * D + gcol) * 2 : (int)OOB, 0, 0);
+        }
+        if (upd) {                                         // column totals of the chunk = its last row's prefix (lane li = 15)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) csum[jq][r] += __shfl(cum[RB - 1][r], (lane & 48) | 15);
+        }
       }
       }
       // (e) S[f][e] += sum_s phi(k_s)[f] V[s][e]: A operand = phi(K)^T by transposing reads of the row-major images
@@ -1438,23 +1488,81 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
         }
       }
     }
-    __syncthreads();
-  }
-  if constexpr (STATE_ONLY) {
-    float* cw = p.carry + ((int64_t)nh * (p.nseg - 1) + seg) * CARRY;
-#pragma unroll
-    for (int jq = 0; jq < JB; ++jq) {
-#pragma unroll
-      for (int b = 0; b < NBT; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) cw[((jq * NBT + b) * 4 + r) * NTH + tid] = S[jq][b][r];
-      cw[JB * NBT * 4 * NTH + FP + jq * NTH + tid] = csum[jq];
+  };
+  // D = 80 keeps the phases one after the other (four barriers): pipelined, the median workgroup is 7 % faster (105 vs 113.6 us on
+  // 1 x 32 x 8192) but the workgroups of the LAST segment -- the only ones whose k, v, pos rows the state pass has not just read --
+  // run 10 us behind, and the launch ends later (128.5 vs 121.9 us; two-chunk prefetch: 5 us behind) -- DESIGN.md section 9
+  constexpr bool PIPE = D != 80;
+#ifdef SEA_STAMP
+  unsigned long long _tacc[4] = {0, 0, 0, 0};
+  unsigned long long _tprev = __builtin_amdgcn_s_memtime();
+  const unsigned long long _tstart = _tprev, _rstart = __builtin_amdgcn_s_memrealtime();
+#endif
+  if constexpr (!PIPE) {
+    for (int t0 = t_begin; t0 < t_end; t0 += C) {
+      stage_qk(pa);
+      stage_v(t0, pa);
+      issue_qk(t0 + C, pa);
+      issue_v(t0 + C, pa);
+      __syncthreads();
+      WSTAMP(0);
+      phase_b(rows_of(t0), sPhi);
+      __syncthreads();
+      WSTAMP(1);
+      phase_c(sPhi);
+      __syncthreads();
+      WSTAMP(2);
+      phase_de(t0, rows_of(t0), upd_of(t0), sPhi);
+      __syncthreads();
+      WSTAMP(3);
     }
-    if (tid < FP) cw[JB * NBT * 4 * NTH + tid] = sKsum[tid];
+  } else
+  if (t_begin < t_end) {
+    // prologue: chunk 0 through (b), (c); chunk 1's q, k staged; in flight: [pos | v] of chunks 1 (set A) and 2 (set B), q, k of
+    // chunks 2 (B) and 3 (A)
+    stage_qk(pa);
+    stage_v(t_begin, pa);
+    issue_qk(t_begin + C, pa);
+    issue_v(t_begin + C, pa);
+    issue_qk(t_begin + 2 * C, pn);
+    issue_v(t_begin + 2 * C, pn);
+    __syncthreads();
+    phase_b(rows_of(t_begin), sPhi);
+    __syncthreads();
+    phase_c(sPhi);
+    stage_qk(pa);
+    issue_qk(t_begin + 3 * C, pa);
+    __syncthreads();
+    // iteration j: [pos | v] of chunk j+1 leaves set `rv_` (refilled with chunk j+3), q, k of chunk j+2 leave set `rqk_` (refilled
+    // with chunk j+4); the sets swap roles every iteration, so the walk is unrolled by two
+    auto iter = [&](int t0, int buf, Pre& rv_, Pre& rqk_) {
+      const bool has_next = t0 + C < t_end;                  // block-uniform
+      phase_de(t0, rows_of(t0), upd_of(t0), sPhi + buf * PHI);
+      WSTAMP(0);
+      if (has_next) phase_b(rows_of(t0 + C), sPhi + (buf ^ 1) * PHI);
+      __syncthreads();
+      WSTAMP(1);
+      if (has_next) {
+        phase_c(sPhi + (buf ^ 1) * PHI);
+        stage_v(t0 + C, rv_);
+        issue_v(t0 + 3 * C, rv_);
+        stage_qk(rqk_);
+        issue_qk(t0 + 4 * C, rqk_);
+      }
+      __syncthreads();
+      WSTAMP(2);
+    };
+    for (int t0 = t_begin; t0 < t_end; t0 += 2 * C) {
+      iter(t0, 0, pa, pn);
+      if (t0 + C < t_end) iter(t0 + C, 1, pn, pa);
+    }
+  }
+  WSTAMP_FLUSH();
+  if constexpr (STATE_ONLY) {
+    write_image(p.carry + ((int64_t)nh * (p.nseg - 1) + seg) * CARRY);
   } else {
-    const int t0l = t_begin + ((t_end - t_begin - 1) / C) * C;
-    flush_out(t0l, t_end - t0l);
-    if (p.state_out && seg == p.nseg - 1) write_state();
+    // the block that walked the last rows holds the final state (aligned step: the state at the last chunk boundary)
+    if (p.state_out && seg == p.nseg - 1) write_image(p.state_out + (int64_t)nh * CARRY);
   }
 }
 
@@ -1495,7 +1603,7 @@ static int launch_perf_bf16(const PerfParams& p, hipStream_t s) {
   constexpr int D = 64, C = 64, NTH = 512, E = 2 * D, NBP = NBT * 16, FP = ((NBT + 1) / 2) * 32, LDQ2 = FP + 16, LDK2 = (FP == 64) ? 96 : FP + 8, LDA = C + 16;
   constexpr int NSET = (FP == 64) ? 2 : 1;                   // phi image sets (performer_bf16_kernel)
   constexpr size_t lds = 2 * ((D / 8) * NBP * 8 + 2 * (D / 8) * C * 8 + C * E + NSET * (2 * C * LDQ2 + 2 * C * LDK2) + 2 * C * LDA) +
-                         sizeof(float) * (FP + C + C * (C / 16 + NTH / C) + 8 * FP + C);
+                         sizeof(float) * (FP + C * (C / 16 + NTH / C) + 8 * FP);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool configured = false;
   if (!configured) {
@@ -1516,10 +1624,10 @@ constexpr int64_t perf_bf16_carry_floats() { return (int64_t)NBT * 4 * 512 + ((N
 // the wide-head form of the 16-bit kernel (d = 128: 32-row chunks, two column blocks per wave)
 template <typename T, int D, int C, int NBT>
 static int launch_perf_bf16w(const PerfParams& p, hipStream_t s) {
-  constexpr int NTH = 512, E = 2 * D, NBP = NBT * 16, FP = ((NBT + 1) / 2) * 32, LDQ2 = FP + 16, LDK2 = (FP == 64) ? 96 : FP + 8, LDA = C + 16;
+  constexpr int NTH = 512, NBP = NBT * 16, FP = ((NBT + 1) / 2) * 32, LDQ2 = FP + 16, LDK2 = (FP == 64) ? 96 : FP + 8, LDA = C + 16;
   constexpr int KC = (D + 31) / 32 * 4, EL = 256;
-  constexpr size_t lds = 2 * (KC * NBP * 8 + 2 * KC * C * 8 + C * EL + 2 * C * LDQ2 + 2 * C * LDK2 + 2 * C * LDA + C * (E + 8) + C * (D + 8)) +
-                         sizeof(float) * (FP + C + C * (C / 16 + 8) + 8 * FP + C);
+  constexpr size_t lds = 2 * (KC * NBP * 8 + 2 * KC * C * 8 + C * EL + 2 * (2 * C * LDQ2 + 2 * C * LDK2) + 2 * C * LDA) +
+                         sizeof(float) * (FP + C * (C / 16 + 8) + 8 * FP);
   static_assert(lds <= 160 * 1024, "LDS budget");
   static bool configured = false;
   if (!configured) {
@@ -1557,9 +1665,13 @@ static int dispatch_perf(const PerfParams& p, int D, int nbt, hipStream_t s) {
 }
 
 #ifdef SEA_STAMP
+extern "C" int sea_debug_perf_wg(unsigned long long* host2048) {
+  (void)hipMemcpyFromSymbol(host2048, HIP_SYMBOL(sea_dbg_wg), sizeof(unsigned long long) * 2048);
+  return 0;
+}
 extern "C" int sea_debug_perf_stamps(unsigned long long* host8) {
-  (void)hipMemcpyFromSymbol(host8, HIP_SYMBOL(sea_dbg_perf), sizeof(unsigned long long) * 8);
-  unsigned long long z[8] = {0};
+  (void)hipMemcpyFromSymbol(host8, HIP_SYMBOL(sea_dbg_perf), sizeof(unsigned long long) * 16);
+  unsigned long long z[16] = {0};
   (void)hipMemcpyToSymbol(HIP_SYMBOL(sea_dbg_perf), z, sizeof(z));
   return 0;
 }
