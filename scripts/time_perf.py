@@ -8,14 +8,18 @@ torch.manual_seed(0)
 fa = FastAttention(D, nb_features=int(D * math.log(D) / 8), causal=True, generalized_attention=True).to(dev)
 q = (torch.randn((N, H, T, D), device=dev) * D ** -0.5).to(dt); k = torch.randn((N, H, T, D), device=dev).to(dt); v = torch.randn((N, H, T, D), device=dev).to(dt)
 pos = torch.randn((T, D), device=dev).to(dt)
-def run(): return ops.performer_value(q, k, v, pos, fa.projection_matrix)
+WA = bool(os.environ.get('WANT_AVG'))
+def run():
+    r = ops.performer_value(q, k, v, pos, fa.projection_matrix, want_avg=WA)
+    return r[0] if WA else r
 for _ in range(3): run()
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
-for _ in range(10): out = run()
+IT = int(os.environ.get('ITERS', 10))
+for _ in range(IT): out = run()
 e1.record(); torch.cuda.synchronize()
-print(json.dumps({"performer_us": round(e0.elapsed_time(e1) / 10 * 1e3, 1), "checksum": float(out.float().abs().mean())}))
+print(json.dumps({"performer_us": round(e0.elapsed_time(e1) / IT * 1e3, 1), "checksum": float(out.float().abs().mean())}))
 if os.environ.get("STAMPS"):
     import ctypes
     from sea_attention_amd import _lib

@@ -813,17 +813,18 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
       for (int i = 0; i < NW; ++i) s += sKsP[i * FP + tid];       // fixed order: bitwise reproducible
       if (upd) sKsum[tid] = s;
     }
-    float dn[RB], ri[RB];
+    // (a lane sums ONE row -- lane group g the rows of block g % RB -- and the reciprocals travel by lane permutes: four rows and
+    // eight divisions per lane made the phase VALU-bound, 2.5 % slower than the barrier it replaces at 256 workgroups)
+    float dn[RB], ri1 = 0.f;
     if constexpr (!STATE_ONLY) {
+      const int myrow = (lg % RB) * 16 + li;
+      float s = 0.f;
 #pragma unroll
-      for (int ib = 0; ib < RB; ++ib) {
-        const int row = ib * 16 + li;
-        float s = 0.f;
+      for (int i = 0; i < DSL; ++i) s += sDenP[myrow * DSL + i];
+      const float d1 = 1.0f / s;
+      ri1 = 1.0f / (float)(row_base + t0 + myrow + 1);
 #pragma unroll
-        for (int i = 0; i < DSL; ++i) s += sDenP[row * DSL + i];
-        dn[ib] = 1.0f / s;
-        ri[ib] = 1.0f / (float)(row_base + t0 + row + 1);
-      }
+      for (int ib = 0; ib < RB; ++ib) dn[ib] = __shfl(d1, ib * 16 + li);
     }
     {
       const int jb = wv, e0 = jb * 16;
@@ -909,9 +910,10 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
 #pragma unroll
         for (int ib = 0; ib < RB; ++ib) {
           const int row = ib * 16 + li;
+          const float ri = __shfl(ri1, ib * 16 + li);
           unsigned short gb4[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) gb4[r] = S16<T>::bits((cum[ib][r] + csum[r]) * ri[ib]);
+          for (int r = 0; r < 4; ++r) gb4[r] = S16<T>::bits((cum[ib][r] + csum[r]) * ri);
           const uint2 w2 = pack4(gb4);
           typedef __attribute__((ext_vector_type(2))) unsigned int bu2;
           __builtin_amdgcn_raw_buffer_store_b64(bu2{w2.x, w2.y}, rg, (row < rows && t0 + row >= lead) ? ((t0 + row) * D + gcol) * 2 : (int)OOB, 0, 0);
@@ -1364,17 +1366,18 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
       for (int i = 0; i < NW; ++i) s += sKsP[i * FP + tid];       // fixed order: bitwise reproducible
       if (upd) sKsum[tid] = s;
     }
-    float dn[RB], ri[RB];
+    // (a lane sums ONE row -- lane group g the rows of block g % RB -- and the reciprocals travel by lane permutes: four rows and
+    // eight divisions per lane made the phase VALU-bound, 2.5 % slower than the barrier it replaces at 256 workgroups)
+    float dn[RB], ri1 = 0.f;
     if constexpr (!STATE_ONLY) {
+      const int myrow = (lg % RB) * 16 + li;
+      float s = 0.f;
 #pragma unroll
-      for (int ib = 0; ib < RB; ++ib) {
-        const int row = ib * 16 + li;
-        float s = 0.f;
+      for (int i = 0; i < DSL; ++i) s += sDenP[myrow * DSL + i];
+      const float d1 = 1.0f / s;
+      ri1 = 1.0f / (float)(row_base + t0 + myrow + 1);
 #pragma unroll
-        for (int i = 0; i < DSL; ++i) s += sDenP[row * DSL + i];
-        dn[ib] = 1.0f / s;
-        ri[ib] = 1.0f / (float)(row_base + t0 + row + 1);
-      }
+      for (int ib = 0; ib < RB; ++ib) dn[ib] = __shfl(d1, ib * 16 + li);
     }
 #pragma unroll
     for (int jq = 0; jq < JB; ++jq) {
@@ -1459,9 +1462,10 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
 #pragma unroll
         for (int ib = 0; ib < RB; ++ib) {
           const int row = ib * 16 + li;
+          const float ri = __shfl(ri1, ib * 16 + li);
           unsigned short g4[4];
 #pragma unroll
-          for (int r = 0; r < 4; ++r) g4[r] = S16<T>::bits((cum[ib][r] + csum[jq][r]) * ri[ib]);
+          for (int r = 0; r < 4; ++r) g4[r] = S16<T>::bits((cum[ib][r] + csum[jq][r]) * ri);
           const uint2 w2 = pack4(g4);
           __builtin_amdgcn_raw_buffer_store_b64(bu2{w2.x, w2.y}, rg, (row < rows && t0 + row >= lead) ? ((t0 + row) * D + gcol) * 2 : (int)OOB, 0, 0);
         }
