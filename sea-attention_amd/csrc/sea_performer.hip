@@ -1139,9 +1139,8 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
   const bool want_avg = p.avg != nullptr;                  // block-uniform
   T* gb = reinterpret_cast<T*>(p.avg) + (want_avg ? (int64_t)nh * p.T * D - (int64_t)lead * D : 0);
   const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc(gb, 0, want_avg ? (int)((int64_t)TL * D * 2) : 0, 0x00020000);
-  // two sets of prefetch registers: every load has two chunk times between issue and use (the last segment's k, v and every
-  // segment's q come from HBM cold -- the state pass reads k, v of the segments before the last only -- and one chunk time did
-  // not cover that: the workgroups of the last segment ran 10 us behind the others)
+  // two sets of prefetch registers: every load has two chunk times between issue and use (d = 128: 202.7 -> 199.9 us; halves the lag
+  // of the last segment's workgroups in the pipelined walk)
   struct Pre { bu4 q, k, v, p; };
   Pre pa, pn;
   auto issue_qk = [&](int t0n, Pre& r) {
@@ -1494,8 +1493,8 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
     }
   };
   // D = 80 keeps the phases one after the other (four barriers): pipelined, the median workgroup is 7 % faster (105 vs 113.6 us on
-  // 1 x 32 x 8192) but the workgroups of the LAST segment -- the only ones whose k, v, pos rows the state pass has not just read --
-  // run 10 us behind, and the launch ends later (128.5 vs 121.9 us; two-chunk prefetch: 5 us behind) -- DESIGN.md section 9
+  // 1 x 32 x 8192) but the workgroups of the LAST segment run 10 us behind (every chunk's P2 is longer; not a cold-cache effect: a
+  // warming walk changes nothing), and the launch ends later (128.5 vs 121.9 us; two-chunk prefetch: 5 us behind) -- DESIGN.md section 9
   constexpr bool PIPE = D != 80;
 #ifdef SEA_STAMP
   unsigned long long _tacc[4] = {0, 0, 0, 0};
