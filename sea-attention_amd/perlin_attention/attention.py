@@ -98,6 +98,16 @@ def _kl_and_mse(est_scores, truth_scores, causal_mask, fp_min):
     return kl + mse
 
 
+def _softmax_like_reference(x: torch.Tensor, training: bool) -> torch.Tensor:
+    """`softmax_bf16` (attention.py:62-72): plain softmax at inference; in training under 16-bit autocast the softmax runs in
+    fp32 and the result returns to the input dtype."""
+    if not training:
+        return torch.softmax(x, dim=-1)
+    op_dtype = torch.float32 if torch.get_autocast_gpu_dtype() in (torch.bfloat16, torch.float16) else x.dtype
+    y = torch.softmax(x.to(op_dtype), dim=-1)
+    return y.to(x.dtype)
+
+
 class PerlinAttention(nn.Module):
     def __init__(self, config, perlin_config: PerlinAttentionConfig = None):
         super().__init__()
@@ -204,8 +214,17 @@ class PerlinAttention(nn.Module):
                 ModuleBenchmark('cnn.lnorm2', nn.LayerNorm(T_M)))        # keeps the causal model from exploding
         self.attention_predictor_dec_scaler = nn.Sequential(nn.Linear(d * 2, 2))
 
+        # ---- compressed predictor (attention.py:293-312): softmax over a codebook per patch, patches concatenated to the map ----
         if pc.attention_predictor_method == 'comp':
-            raise NotImplementedError("attention_predictor_method='comp' (attention.py:293-312) is outside this build")
+            self.attention_predictor_comp_length = pc.attention_predictor_comp_patch_count * pc.attention_predictor_comp_patch_size
+            self.attention_predictor_comp_codebook = nn.Parameter(
+                torch.randn((pc.attention_predictor_comp_book_size, pc.attention_predictor_comp_patch_size)))
+            self.attention_predictor_comp_enc = nn.Sequential(
+                nn.Dropout(0.1), nn.Linear(pv, d * 2), nn.LayerNorm(d * 2), nn.GELU())
+            self.attention_predictor_comp_dec_row = nn.Sequential(
+                nn.Linear(d * 2, pc.attention_predictor_comp_book_size * pc.attention_predictor_comp_patch_count))
+        elif pc.attention_predictor_method != 'mlp':
+            raise Exception(f"attention_predictor_method {pc.attention_predictor_method!r}")      # (attention.py:663)
 
         # ---- output ------------------------------------------------------------------------------
         self.norm_performer = nn.LayerNorm(config.hidden_size)
@@ -349,9 +368,28 @@ class PerlinAttention(nn.Module):
             with timer("performer_value"):
                 performer_value = torch.cat([performer_context_layer, v], dim=-1)
                 bench.register_temp_buffer('performer_value', performer_value)
-        fused_mlp = self._fused_mlp_ok(performer_value)
         self._fused_gates = None
         self._fused_selection = None
+        if self.pconfig.attention_predictor_method == 'comp':
+            # attention.py:649-661: the small MLP and the codebook product stay torch modules (library GEMMs); the map's width is
+            # patch_count * patch_size, whatever attention_predictor_length says; steps H..L below are the HIP kernels as always
+            with timer("predictor"):
+                N, H, T, _ = performer_value.shape
+                pc = self.pconfig
+                t_attention_predictor = self.attention_predictor_comp_enc(performer_value)
+                score = self.attention_predictor_comp_dec_row(t_attention_predictor)
+                score = score.view(N, H, T, pc.attention_predictor_comp_patch_count, pc.attention_predictor_comp_book_size)
+                score = _softmax_like_reference(score, self.training)
+                score = torch.matmul(score.view(-1, pc.attention_predictor_comp_book_size),
+                                     self.attention_predictor_comp_codebook.to(score.dtype))
+                estimated_attention_score = score.view(N, H, T, -1)
+                bench.register_temp_buffer('t_attention_predictor', t_attention_predictor)
+            with timer("mask_softmax"):
+                estimated_attention_probs = _softmax_like_reference(estimated_attention_score, self.training)
+            bench.register_temp_buffer('estimated_attention_score', estimated_attention_score)
+            bench.register_temp_buffer('estimated_attention_probs', estimated_attention_probs)
+            return v, t_attention_predictor, estimated_attention_score, estimated_attention_probs
+        fused_mlp = self._fused_mlp_ok(performer_value)
         if fused_mlp:
             with timer("predictor"):
                 want_scores = get_bench().activate_temp_buffers or (not self.benchmarking)
@@ -500,6 +538,7 @@ class PerlinAttention(nn.Module):
         if not self.pconfig.causal:
             raise NotImplementedError("non-causal (BERT) SEA is outside this build's scope (SURVEY.md 2.1 #12)")
         if self.pconfig.use_cache or last_state is not None:
+            assert self.pconfig.attention_predictor_method != 'comp', "the compressed predictor has no cached form (attention.py:650)"
             return self._forward_cached(q, k, v, q_for_atten, k_for_atten, v_for_atten, q_for_score, k_for_score,
                                         attention_mask, last_state)
 

@@ -22,7 +22,7 @@ class PerlinAttentionConfig:
     random_lookup: bool = False                    # (reference ablation; off)
     random_lookup_count: int = 3
     # ---- steps D-G: attention predictor ------------------------------------------------------------------------------
-    attention_predictor_method: str = 'mlp'        # 'mlp' (this build) | 'comp' (not built)
+    attention_predictor_method: str = 'mlp'        # 'mlp' | 'comp' (codebook predictor, attention.py:293-312, 649-661)
     attention_predictor_length: int = 128          # T_M, width of the compressed attention map
     attention_predictor_backend: str = 'performer'
     attention_predictor_comp_book_size: int = 8    # 'comp' predictor only

@@ -248,3 +248,61 @@ def test_sparse_mode_returns_the_csr_probabilities_on_request():
     rowsum = dense_p.sum(-1)                                                 # each non-empty (row, head): rs
     nonempty = (ops.flat_csr_to_dense(out.partial_attention_mask, T, H) > 0).any(-1)
     assert ((rowsum - scale.squeeze(-1)) * nonempty).abs().max().item() < 1e-5 and torch.all(rowsum[~nonempty] == 0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_compressed_predictor_method(dtype):
+    """`attention_predictor_method='comp'` (attention.py:293-312, 649-661): the map is softmax-over-codebook patches; its width
+    is patch_count * patch_size, not attention_predictor_length.  Dense mode == sparse mode (the reference's consistency
+    protocol), the map == the formula written out here, the CSR == the oracle's top-k + interpolation on that map."""
+    from oracle import sea_oracle as O
+    N, H, T, d, k = 2, 4, 256, 32, 8
+    S.seed(42)
+    pc = PerlinAttentionConfig(k=k, attention_predictor_length=64, performer_nb_factor=8, causal=True, k_flatten=True,
+                               k_flatten_dim='causal_batch', context_output_method='mix', attention_predictor_method='comp',
+                               attention_predictor_comp_book_size=8, attention_predictor_comp_patch_size=4,
+                               attention_predictor_comp_patch_count=8)
+    layer = PerlinSelfAttention(Cfg(H * d, H, T), pc).to(DEV).to(dtype).eval()
+    att = layer.attention
+    assert att.attention_predictor_comp_length == 32 and tuple(att.attention_predictor_comp_codebook.shape) == (8, 4)
+    assert {"attention_predictor_comp_codebook", "attention_predictor_comp_enc.1.weight", "attention_predictor_comp_enc.2.bias",
+            "attention_predictor_comp_dec_row.0.weight"} <= set(att.state_dict())            # the reference's parameter names
+    S.seed(3)
+    x = torch.randn((N, H, T, d), device=DEV)
+    q, kk, v = (x * d ** -0.5).to(dtype), torch.randn_like(x).to(dtype), torch.randn_like(x).to(dtype)
+    mask = causal_mask(N, T, dtype)
+    out_d, bd = run(layer, q, kk, v, mask, False)
+    out_s, bs = run(layer, q, kk, v, mask, True)
+    T_M = 32
+    probs = bs['estimated_attention_probs']
+    assert tuple(probs.shape) == (N, H, T, T_M)
+    # the formula, from the captured Performer output
+    pv = bs['performer_value']
+    t_pred = att.attention_predictor_comp_enc(pv)
+    sc = att.attention_predictor_comp_dec_row(t_pred).view(N, H, T, 8, 8)
+    ref = torch.softmax(torch.matmul(torch.softmax(sc, -1).view(-1, 8), att.attention_predictor_comp_codebook).view(N, H, T, -1), -1)
+    tol = 1e-5 if dtype == torch.float32 else 2e-2
+    assert (probs.float() - ref.float()).abs().max().item() <= tol
+    assert (bd['estimated_attention_probs'].float() - probs.float()).abs().max().item() <= tol
+    # selection + interpolation on the layer's own map == oracle, bit for bit
+    out_f, _ = run(layer, q, kk, v, mask, True, capture=False)
+    csr = out_f.partial_attention_mask
+    pm = out_f.estimated_attention_probs_m.float().cpu()
+    keep = O.keep_counts_module(H, T, T_M, k)
+    crow, col = O.resize_m_to_t_csr(O.grouped_topk_mask(pm, keep), k, T, True)
+    assert torch.equal(csr.crow.cpu().long(), crow)
+    for n in range(N):
+        z = int(crow[n, -1])
+        assert torch.equal(csr.col[n, :z].cpu().long(), col[n, :z])
+    # dense mode and sparse mode agree on the context (fp32: the reference's 1e-5 SSE bar)
+    if dtype == torch.float32:
+        assert (out_d.context_layer.float() - out_s.context_layer.float()).square().sum().item() <= 1e-5
+        assert torch.equal(bd['partial_attention_mask'] > -1, bs['partial_attention_mask'] > 0)
+    else:
+        assert torch.isfinite(out_s.context_layer).all()
+    # no cached form (attention.py:650)
+    from sea_attention_amd.perlin_attention.attention_state import PerlinAttentionState
+    with pytest.raises(AssertionError):
+        with torch.no_grad():
+            att(q[:, :, -1:], kk, v, q[:, :, -1:], kk, v, q[:, :, -1:], kk, mask[:, :, -1:], None, None,
+                last_state=PerlinAttentionState(att))

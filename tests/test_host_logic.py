@@ -434,3 +434,24 @@ def test_flat_csr_items_share_storage_and_pending_state():
     _ = sub.col                                              # a non-fused reader of the part runs the PARENT's emit launch
     assert fired == [1] and not csr.col_is_pending and not sub.col_is_pending
     assert not csr.items(0, 1).col_is_pending
+
+
+def test_compressed_predictor_parameters_and_unknown_method():
+    """`attention_predictor_method='comp'` builds the reference's parameters under the reference's names (attention.py:293-312);
+    anything else than 'mlp' / 'comp' raises like the reference's `raise Exception()` (attention.py:663)."""
+    from sea_attention_amd.perlin_attention import PerlinAttentionConfig, PerlinSelfAttention
+
+    class Cfg:
+        hidden_size, num_attention_heads, max_position_embeddings = 128, 4, 256
+
+    pc = PerlinAttentionConfig(k=8, attention_predictor_length=64, causal=True, attention_predictor_method='comp',
+                               attention_predictor_comp_book_size=8, attention_predictor_comp_patch_size=4,
+                               attention_predictor_comp_patch_count=8)
+    att = PerlinSelfAttention(Cfg(), pc).attention
+    sd = att.state_dict()
+    assert tuple(sd["attention_predictor_comp_codebook"].shape) == (8, 4)
+    assert tuple(sd["attention_predictor_comp_enc.1.weight"].shape) == (64, 96)          # Linear(3 d -> 2 d) behind the Dropout
+    assert tuple(sd["attention_predictor_comp_dec_row.0.weight"].shape) == (8 * 8, 64)   # book_size * patch_count
+    assert att.attention_predictor_comp_length == 32
+    with pytest.raises(Exception):
+        PerlinSelfAttention(Cfg(), PerlinAttentionConfig(causal=True, attention_predictor_method='vqvae'))
