@@ -537,6 +537,11 @@ class PerlinAttention(nn.Module):
             self._warning_messages = ''
         if not self.pconfig.causal:
             raise NotImplementedError("non-causal (BERT) SEA is outside this build's scope (SURVEY.md 2.1 #12)")
+        # the causal model pools the heads of a row ('causal_batch'); the reference turns k_flatten=False into the per-query
+        # pooling, which asserts `not causal` (attention.py:786-788, 851), and 'batch' / 'head' do the same (:834, :839)
+        assert self.pconfig.k_flatten and self.pconfig.k_flatten_dim == 'causal_batch', \
+            f"causal SEA selects per row over the pooled heads (k_flatten=True, k_flatten_dim='causal_batch'); got " \
+            f"k_flatten={self.pconfig.k_flatten}, k_flatten_dim={self.pconfig.k_flatten_dim!r}"
         if self.pconfig.use_cache or last_state is not None:
             assert self.pconfig.attention_predictor_method != 'comp', "the compressed predictor has no cached form (attention.py:650)"
             return self._forward_cached(q, k, v, q_for_atten, k_for_atten, v_for_atten, q_for_score, k_for_score,

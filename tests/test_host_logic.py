@@ -455,3 +455,22 @@ def test_compressed_predictor_parameters_and_unknown_method():
     assert att.attention_predictor_comp_length == 32
     with pytest.raises(Exception):
         PerlinSelfAttention(Cfg(), PerlinAttentionConfig(causal=True, attention_predictor_method='vqvae'))
+
+
+@pytest.mark.parametrize("kw", [dict(k_flatten=False), dict(k_flatten_dim='batch'), dict(k_flatten_dim='head')])
+def test_causal_model_refuses_other_poolings(kw):
+    """The reference's per-query / per-batch / per-head poolings assert `not causal` (attention.py:834, 839, 851): the causal module
+    refuses them before any kernel runs instead of selecting with the wrong pooling."""
+    from sea_attention_amd.perlin_attention import PerlinAttentionConfig, PerlinSelfAttention
+
+    class Cfg:
+        hidden_size, num_attention_heads, max_position_embeddings = 64, 2, 64
+
+    pc = PerlinAttentionConfig(k=4, attention_predictor_length=32, causal=True)
+    layer = PerlinSelfAttention(Cfg(), pc).eval()
+    for name, val in kw.items():
+        setattr(layer.attention.pconfig, name, val)
+    x = torch.randn((1, 2, 16, 32))
+    mask = torch.zeros((1, 1, 16, 16))
+    with pytest.raises(AssertionError, match="causal SEA selects per row"):
+        layer(None, None, None, query_layer=x, key_layer=x, value_layer=x, attention_mask=mask)
