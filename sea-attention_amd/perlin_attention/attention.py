@@ -169,6 +169,10 @@ class PerlinAttention(nn.Module):
         self.performer = FastAttention(dim_heads=d, nb_features=self.performer_nb_features,
                                        causal=pc.causal, generalized_attention=pc.causal)
         self.performer_proj_updater = ProjectionUpdater(self.performer, 1000)
+        if pc.attention_predictor_backend != 'performer':
+            # 'cosformer' (attention.py:169-179, 535-549) needs the reference's third-party cosformer module and is commented
+            # "not supported" there; anything else raises in the reference's forward (:550)
+            raise Exception(f"attention_predictor_backend {pc.attention_predictor_backend!r}: this build estimates with the Performer only")
 
         # ---- predictor: MLP encoder, row decoder, CNN ---------------------------------------------
         pv = d * 3
@@ -631,6 +635,8 @@ class PerlinAttention(nn.Module):
                 loss = loss + l2
 
             bench.register_temp_buffer('partial_context_layer_sparse', partial_context_layer)
+            if self.pconfig.random_lookup:
+                raise Exception("random_lookup is a dead ablation in the reference as well (`raise Exception()`, :1254-1255)")
             if self.pconfig.context_output_method != 'mix':
                 raise Exception("only context_output_method='mix' is live in the reference (:1286-1314)")
 

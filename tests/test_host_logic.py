@@ -474,3 +474,15 @@ def test_causal_model_refuses_other_poolings(kw):
     mask = torch.zeros((1, 1, 16, 16))
     with pytest.raises(AssertionError, match="causal SEA selects per row"):
         layer(None, None, None, query_layer=x, key_layer=x, value_layer=x, attention_mask=mask)
+
+
+def test_dead_reference_options_raise_instead_of_being_ignored():
+    """`attention_predictor_backend != 'performer'` and `random_lookup` are not served: both raise (the reference raises for
+    `random_lookup` itself, attention.py:1254-1255; its cosformer backend needs a module this build does not carry)."""
+    from sea_attention_amd.perlin_attention import PerlinAttentionConfig, PerlinSelfAttention
+
+    class Cfg:
+        hidden_size, num_attention_heads, max_position_embeddings = 64, 2, 64
+
+    with pytest.raises(Exception, match="attention_predictor_backend"):
+        PerlinSelfAttention(Cfg(), PerlinAttentionConfig(causal=True, attention_predictor_backend='cosformer'))
