@@ -248,6 +248,67 @@ class SeaOPTAttention(nn.Module):
         return y, (out.partial_attention_probs if output_attentions else None), present
 
 
+class SeaOPTDecoderLayer(nn.Module):
+    """One OPT decoder layer around `SeaOPTAttention` (role of `OPTDecoderLayer`, perlin_opt.py:638-800: pre- or post-norm
+    self-attention + feed-forward, same sub-module names so the reference layer's state dict loads as it is).  It exists for
+    the reference's measurement protocol -- `benchmark_bert.exam` (src/main/benchmark_bert.py:162-239) times
+    `decoder.layers[0]` with `fc1` / `fc2` / `out_proj` replaced by `nn.Identity` -- and for the drop-in check against the
+    reference's own layer (tests/test_reference_callers.py).  Dropout is the reference's (`p` applied in training only)."""
+
+    def __init__(self, hidden_size: int, num_heads: int, ffn_dim: int, max_position_embeddings: int = 2048, bias: bool = True,
+                 do_layer_norm_before: bool = True, activation=None, dropout: float = 0.0, layer_norm_elementwise_affine=True):
+        super().__init__()
+        self.embed_dim = hidden_size
+        self.self_attn = SeaOPTAttention(hidden_size, num_heads, bias=bias, max_position_embeddings=max_position_embeddings)
+        self.do_layer_norm_before = do_layer_norm_before
+        self.dropout = dropout
+        self.activation_fn = activation or nn.ReLU()                 # OPT's activation_function = "relu"
+        self.self_attn_layer_norm = nn.LayerNorm(hidden_size, elementwise_affine=layer_norm_elementwise_affine)
+        self.fc1 = nn.Linear(hidden_size, ffn_dim, bias=bias)
+        self.fc2 = nn.Linear(ffn_dim, hidden_size, bias=bias)
+        self.final_layer_norm = nn.LayerNorm(hidden_size, elementwise_affine=layer_norm_elementwise_affine)
+
+    def exam_surgery(self, benchmarking: bool = True):
+        """benchmark_bert.py:162-203 on this layer: the sparse mode on every module that has the switch, `fc1` / `fc2` /
+        `out_proj` -> Identity (the layer then costs its attention, two LayerNorms and the residual adds)."""
+        for m in self.modules():
+            if hasattr(m, "benchmarking"):
+                m.benchmarking = benchmarking
+        self.fc1, self.fc2, self.self_attn.out_proj = nn.Identity(), nn.Identity(), nn.Identity()
+        return self
+
+    def forward(self, hidden_states, attention_mask=None, layer_head_mask=None, past_key_value=None,
+                output_attentions=False, use_cache=False):
+        dtype = self.self_attn.q_proj.weight.dtype
+        if hidden_states.dtype != dtype:
+            hidden_states = hidden_states.to(dtype)
+        residual = hidden_states
+        if self.do_layer_norm_before:
+            hidden_states = self.self_attn_layer_norm(hidden_states)
+        hidden_states, attn_weights, present = self.self_attn(
+            hidden_states=hidden_states, past_key_value=past_key_value, attention_mask=attention_mask,
+            layer_head_mask=layer_head_mask, output_attentions=output_attentions, use_cache=use_cache)
+        hidden_states = residual + nn.functional.dropout(hidden_states, p=self.dropout, training=self.training)
+        if not self.do_layer_norm_before:
+            hidden_states = self.self_attn_layer_norm(hidden_states)
+        shape = hidden_states.shape
+        hidden_states = hidden_states.reshape(-1, shape[-1])
+        residual = hidden_states
+        if self.do_layer_norm_before:
+            hidden_states = self.final_layer_norm(hidden_states)
+        hidden_states = self.fc2(self.activation_fn(self.fc1(hidden_states)))
+        hidden_states = nn.functional.dropout(hidden_states, p=self.dropout, training=self.training)
+        hidden_states = (residual + hidden_states).view(shape)
+        if not self.do_layer_norm_before:
+            hidden_states = self.final_layer_norm(hidden_states)
+        out = (hidden_states,)
+        if output_attentions:
+            out += (attn_weights,)
+        if use_cache:
+            out += (present,)
+        return out
+
+
 def causal_additive_mask(N: int, T_dst: int, T_src: int, dtype, device) -> torch.Tensor:
     """(N, 1, T_dst, T_src) mask as the OPT decoder prepares it: 0 where key s may be seen by query t
     (s <= T_src - T_dst + t), the dtype's lowest value elsewhere."""
