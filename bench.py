@@ -85,6 +85,12 @@ def parse_args(argv=None):
                     help="positions of the generation leg (batch 1 and the headline batch) after the timed steps; 0 = off (the "
                          "profiling scripts pass 0: its one-row launches share kernel names with the layer's and would dilute a "
                          "profiler's per-kernel averages)")
+    ap.add_argument("--repeats", type=int, default=4,
+                    help="after the timed K steps, time K steps this many more times and report min / median / max of ms_per_step "
+                         "(`repeats`); `value` stays the first timed region")
+    ap.add_argument("--no-eager-outputs", action="store_true",
+                    help="skip the leg that materialises estimated_attention_probs and the CSR's col_indices every step "
+                         "(the reference's eager outputs, attention.py:1343 + causal_resize_m_to_t.py:757-762)")
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on a box without N GPUs: the process group runs on gloo; with one GPU every rank uses cuda:0 and "
                          "walks the multi-rank code path of this script (shards, graph capture beside a process group, pipelined "
@@ -192,7 +198,8 @@ class LayerBench:
     step (everything up to the fused sparse-attention launch captured, that launch eager between HIP events), the
     A/B of the attention kernel paths, and the roofline block of the attention launch."""
 
-    def __init__(self, wname, NB, dtype_name, dev, ctx_dtype_name=None, inspect_padding=False, seed_offset=0, override=None):
+    def __init__(self, wname, NB, dtype_name, dev, ctx_dtype_name=None, inspect_padding=False, seed_offset=0, override=None,
+                 layer_attrs=None):
         import torch
         import sea_attention_amd as S
         from sea_attention_amd.perlin_attention import PerlinAttentionConfig, PerlinSelfAttention
@@ -214,6 +221,9 @@ class LayerBench:
         # the synthetic batch carries no padding by construction; telling the module removes the per-layer host
         # sync the reference pays to find that out (attention.py:434) and lets the CPU enqueue ahead of the GPU
         layer.attention.assume_not_padded = None if inspect_padding else True
+        for a_, v_ in (layer_attrs or {}).items():              # e.g. the eager-outputs twin: lazy_attention_probs / lazy_csr_columns off
+            assert hasattr(layer.attention, a_), a_
+            setattr(layer.attention, a_, v_)
         self.layer = layer
         torch.manual_seed(42 + seed_offset)
         self.q = (torch.randn((NB, H, T, d), device=dev) * d ** -0.5).to(self.dtype)
@@ -368,28 +378,33 @@ class LayerBench:
         achieved = alg_bytes / t_attn_s / 1e9
         fused_ij = path in ("gather", "auto") and ops.fused_interp_supported(self.dtype, d, w["T_M"])
         same_launch = lambda a_, b_: a_ == b_ or (fused_ij and {a_, b_} <= {"gather", "auto"})   # both run the fused gather launch
-        traffic, l2_req, traffic_note = None, None, "no PMC pass on record (scripts/gpu_pmc.sh writes profiles/traffic_latest.json)"
-        tp = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tp):
+        traffic, l2_req, traffic_note = None, None, "no PMC pass on record (scripts/gpu_pmc.sh + scripts/pmc_to_traffic.py write profiles/traffic_*.json)"
+        # one record per workload (profiles/traffic_<workload>.json, traffic_latest.json = the headline's): the counters belong to
+        # the launch they were taken on -- same kernel sources, same entry count, same kernel path, same output dtype
+        import glob
+        why = []
+        for tp in sorted(glob.glob(os.path.join(ROOT, "profiles", "traffic_*.json"))):
             try:
                 rec = json.load(open(tp))
-                if rec.get("kernel_source_sha256") != _attn_source_sha():
-                    traffic_note = "profiles/traffic_latest.json was taken on other kernel sources: not reported"
-                elif rec.get("nnz") != Z:
-                    traffic_note = "profiles/traffic_latest.json was taken on another workload (entry count differs): not reported"
-                elif (rec.get("attention_path") is not None and not same_launch(rec.get("attention_path"), path)) \
-                        or rec.get("context_dtype") not in (None, str(self.ctx_dtype)):
-                    # the counters belong to the launch they were taken on: same kernel path, same output dtype
-                    traffic_note = (f"profiles/traffic_latest.json was taken on path {rec.get('attention_path')} / context "
-                                    f"{rec.get('context_dtype')}, this run is {path} / {self.ctx_dtype}: not reported")
-                else:
-                    traffic = rec.get("sea_sparse_attention_hbm_bytes_per_launch")
-                    l2_req = rec.get("sea_sparse_attention_l2_requests_per_launch")
-                    if l2_req is None:                                   # records of round 3: sum over the attention kernels
-                        l2_req = sum(v_.get("l2_requests_per_launch", 0) for k_, v_ in rec.get("kernels", {}).items() if "sparse_attn" in k_) or None
-                    traffic_note = rec.get("note", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command")
             except Exception:
-                pass
+                continue
+            name = os.path.basename(tp)
+            if rec.get("kernel_source_sha256") != _attn_source_sha():
+                why.append(f"{name}: other kernel sources")
+            elif rec.get("nnz") != Z:
+                why.append(f"{name}: another workload (entry count differs)")
+            elif (rec.get("attention_path") is not None and not same_launch(rec.get("attention_path"), path)) \
+                    or rec.get("context_dtype") not in (None, str(self.ctx_dtype)):
+                why.append(f"{name}: path {rec.get('attention_path')} / context {rec.get('context_dtype')}, this run is {path} / {self.ctx_dtype}")
+            else:
+                traffic = rec.get("sea_sparse_attention_hbm_bytes_per_launch")
+                l2_req = rec.get("sea_sparse_attention_l2_requests_per_launch")
+                if l2_req is None:                                   # records of round 3: sum over the attention kernels
+                    l2_req = sum(v_.get("l2_requests_per_launch", 0) for k_, v_ in rec.get("kernels", {}).items() if "sparse_attn" in k_) or None
+                traffic_note = f"profiles/{name}: " + rec.get("note", "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this bench command")
+                break
+        if traffic is None and why:
+            traffic_note = "no matching PMC record: " + "; ".join(why[:4])
         gname = "sparse_attn_rows80_kernel" if d == 80 and esz == 2 else "sparse_attn_rows_kernel"
         if fused_ij:      # steps I + J in one launch: the kernel also expands the kept pixels and writes the CSR's columns
             gname += " (fused form: interpolation + attention, sea_sparse_attention_fused)"
@@ -420,7 +435,7 @@ class LayerBench:
 
 
 def short_leg(wname, NB, args, dev, ctx_dtype_name=None, dtype_name=None, override=None, sparse_kernel=None, steps=None,
-              want_regions=False):
+              want_regions=False, layer_attrs=None):
     """A short run of another BASELINE shape (or of the headline with another context dtype / data dtype / predictor length):
     same protocol as the headline (prewarm, A/B of the attention path, HIP-graph replay, HIP events around the attention
     launch).  `sparse_kernel`: a fixed path instead of the A/B (the grid legs); `want_regions`: per-region times of a few
@@ -428,7 +443,7 @@ def short_leg(wname, NB, args, dev, ctx_dtype_name=None, dtype_name=None, overri
     dtype_name = dtype_name or args.dtype
     steps = steps or args.other_steps
     ctx_dtype_name = ctx_dtype_name or ("fp32" if args.context_dtype == "fp32" else dtype_name)
-    lb = LayerBench(wname, NB, dtype_name, dev, ctx_dtype_name=ctx_dtype_name, override=override)
+    lb = LayerBench(wname, NB, dtype_name, dev, ctx_dtype_name=ctx_dtype_name, override=override, layer_attrs=layer_attrs)
     try:
         for _ in range(3):
             lb.forward()
@@ -784,6 +799,30 @@ def main(argv=None):
     ms_per_step = elapsed / args.steps * 1e3
     tokens_per_s = NB * world * T / (elapsed / args.steps)
 
+    # ---- the same K steps again, `--repeats` times (outside the timed region that `value` comes from): K x 2 ms is thin against
+    # box-to-box and run-to-run variance, so the line also says how stable the number is (min / median / max over all runs)
+    repeats = None
+    if args.repeats > 0:
+        runs = [ms_per_step]
+        for _ in range(args.repeats):
+            sync_all()
+            tr0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            if gather is not None:
+                gather.finish()
+            sync_all()
+            tr = torch.tensor([time.perf_counter() - tr0], device=dev, dtype=torch.float64)
+            if world > 1:
+                dist.all_reduce(tr, op=dist.ReduceOp.MAX)
+            runs.append(float(tr.item()) / args.steps * 1e3)
+        srt = sorted(runs)
+        repeats = {"runs": len(runs), "steps_each": args.steps, "ms_per_step_min": round(srt[0], 4),
+                   "ms_per_step_median": round(srt[len(srt) // 2] if len(srt) % 2 else 0.5 * (srt[len(srt) // 2 - 1] + srt[len(srt) // 2]), 4),
+                   "ms_per_step_max": round(srt[-1], 4), "ms_per_step_all": [round(r_, 4) for r_ in runs],
+                   "note": "run 0 is the timed region `value` / `ms_per_step` report; the others repeat it back to back (same barrier + "
+                           "synchronize bracket, max over ranks)"}
+
     # ---- N > 1: the collective by itself and the compute by itself (outside the timed region) -------------------------
     collective = None
     if world > 1:
@@ -994,8 +1033,18 @@ def main(argv=None):
         except Exception as e_:                                   # the twin is informational: never fail the bench line on it
             cpu["full_layer"] = {"error": f"{type(e_).__name__}: {e_}"[:200]}
 
+    if cpu is not None:
+        # which GPU number each CPU number is the twin of (the headline `value` is the WHOLE layer, A..L)
+        fl = cpu.get("full_layer") or {}
+        cpu["gpu_over_cpu"] = {
+            "whole_layer": (round(tokens_per_s / fl["value"], 1) if fl.get("value") else None),
+            "kernel_level": (round(kernel_path["value"] / cpu["value"], 1) if kernel_path and cpu.get("value") else None),
+            "note": "whole_layer = `value` (steps A..L on the GPU) / cpu_baseline.full_layer (the same layer in the dense torch mode on "
+                    "the host cores); kernel_level = kernel_path.value (steps H..K on the GPU, probs given) / cpu_baseline.value (the "
+                    "oracle's dense port of the same steps).  `value` / cpu_baseline.value would compare a whole layer with a part of one"}
     graph_on = lb.graph is not None
     capture_error = lb.capture_error
+    lazy_flags = (bool(getattr(lb.layer.attention, "lazy_attention_probs", False)), bool(getattr(lb.layer.attention, "lazy_csr_columns", False)))
     headline_workload = (f"{args.workload} SEA attention layer forward (sparse mode, steps A-L), "
                          f"H={H} d={d} T={T} k={k} predictor_length={T_M} nbf={w['nbf']}, "
                          f"batch {NB} sequences/GPU, random-init weights seed 42, "
@@ -1006,11 +1055,16 @@ def main(argv=None):
                          + ("unpadded batch declared to the module (assume_not_padded: no mask inspection sync)"
                             if not args.inspect_padding else "module inspects the mask for padding (one host sync)")
                          + f", sparse kernel path {path}"
+                         + (f", module defaults lazy_attention_probs={lazy_flags[0]} / lazy_csr_columns={lazy_flags[1]} (the (N,H,T,T_M) "
+                            "probability map and the CSR's column array -- outputs the reference materialises every step, "
+                            "attention.py:1343, causal_resize_m_to_t.py:757-762 -- are computed on first read, not by the step: the "
+                            "`eager_outputs` leg times the step that writes both)" if any(lazy_flags) else
+                            ", eager outputs (probability map and CSR columns written every step, as the reference does)")
                          + (f", + {'gloo (rehearsal)' if args.rehearse else 'RCCL'} all-gather of context shards" if world > 1 else "")
                          + (", layer replayed as a HIP graph + eager fused-attention launch" if graph_on else ", eager launches"))
 
     # ---- the other BASELINE shapes + the reference-default (fp32 context) twin of the headline: short legs, rank 0's GPU ----
-    other, ctx_twin, train, fp32_leg, grid, long_ctx = None, None, None, None, None, None
+    other, ctx_twin, train, fp32_leg, grid, long_ctx, eager_out = None, None, None, None, None, None, None
     del out, ctx, q, kk, v, mask, layer
     lb.release()
     if gather is not None:
@@ -1027,6 +1081,17 @@ def main(argv=None):
                                              "the headline layer writing context_layer in fp32, the reference's default (flat_csr_sdbmm.py:347)")
         except Exception as e:
             ctx_twin = {"error": f"{type(e).__name__}: {e}"[:300]}
+        if not args.no_eager_outputs:
+            _stage("eager-outputs leg")
+            try:   # the headline with the reference's eager outputs: the map and the column array written by every step
+                eager_out = short_leg(args.workload, NB, args, dev, ctx_dtype_name="fp32" if args.context_dtype == "fp32" else args.dtype,
+                                      layer_attrs=dict(lazy_attention_probs=False, lazy_csr_columns=False))
+                eager_out["note"] = ("lazy_attention_probs=False, lazy_csr_columns=False: estimated_attention_probs (N,H,T,T_M) and the flat "
+                                     "CSR's col_indices are materialised inside every step, as the reference's benchmarking branch does "
+                                     "(attention.py:1343, causal_resize_m_to_t.py:669,757-762); everything else as the headline")
+                eager_out["ratio_to_headline"] = round(eager_out["ms_per_step"] / ms_per_step, 4)
+            except Exception as e:
+                eager_out = {"error": f"{type(e).__name__}: {e}"[:300]}
         for wn, nb_ in OTHER_LEGS:
             if wn == args.workload and nb_ == NB:
                 continue
@@ -1078,6 +1143,7 @@ def main(argv=None):
                        "parallelism": f"dp{world} (batch shards)"},
             "graph": graph_on, "graph_capture_error": capture_error,
             "roofline": roof, "cpu_baseline": cpu, "output_check": output_check, "attention_path_ab": ab,
+            "repeats": repeats, "eager_outputs": eager_out,
             "collective": collective, twin_name: ctx_twin, "other_workloads": other, "fp32_data": fp32_leg,
             "reference_grid": grid, "long_context": long_ctx, "train_step": train,
             "kernel_path": kernel_path, "decode": decode,

@@ -34,8 +34,11 @@ extern "C" {
  *   1  rounds 1-2
  *   2  round 3: sea_performer_causal_step / _at read k / v / pos FROM THE LAST CHUNK BOUNDARY (T + t_base % C rows) and take the
  *      state image at that boundary;  round 4: sea_predictor_mlp's w2_packed / vectors pad every decoder half to whole
- *      16-row tiles (identical for Wd % 16 == 0), sea_predictor_tail_select accepts probs = NULL and any T_m % 4 == 0 <= 512 */
-#define SEA_ABI_VERSION 2
+ *      16-row tiles (identical for Wd % 16 == 0), sea_predictor_tail_select accepts probs = NULL and any T_m % 4 == 0 <= 512
+ *   3  round 5: new entry points the binding requires (sea_causal_conv_c8_z, sea_predictor_tail_z, sea_predictor_tail_select_z,
+ *      sea_causal_conv_c8_f32);
+ *      no existing signature changed */
+#define SEA_ABI_VERSION 3
 
 enum sea_dtype { SEA_F32 = 0, SEA_F16 = 1, SEA_BF16 = 2 };
 
@@ -302,6 +305,12 @@ int sea_predictor_tail(const void* y, int dtype, int64_t N, int64_t C, int64_t H
                        const void* gamma, const void* beta, float eps,
                        void* probs, void* scores, sea_stream_t stream);
 
+/* The same tail from z = the 1x1 convolution's output (N, T, H, W4) fp32, as sea_causal_conv_c8_z writes it (16-bit maps;
+ * conv_b (>= H) fp32 is still needed: the zero-padded border pixels of the padded 1x1 convolution are the bias alone). */
+int sea_predictor_tail_z(const float* z, int dtype, int64_t N, int64_t H, int64_t T, int64_t W4, int64_t up, int64_t T_m,
+                         const float* conv_b, const void* gamma, const void* beta, float eps, void* probs, void* scores,
+                         sea_stream_t stream);
+
 /* Predictor tail + grouped top-k selection in one launch: sea_predictor_tail (MFMA variant, 16-bit
  * channels-last / C8 input) followed by sea_topk_select on the probability map it produces, with the map's values
  * handed over on chip -- the (N,H,T,T_m) map is never re-read, and `probs` MAY BE NULL (round 4): the map is then not
@@ -320,6 +329,16 @@ int sea_predictor_tail_select(const void* y, int dtype, int64_t N, int64_t C, in
                               void* probs, void* scores, const int32_t* keep, int64_t keep_stride_n,
                               int64_t T_src, int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz,
                               int32_t* head_off, sea_stream_t stream);
+
+/* The same launch fed with z (N, T, H, W4) fp32 = the 1x1 convolution's output from sea_causal_conv_c8_z (round 5): the "z
+ * tile" of a row -- loads of y and of the weights, MFMAs, LDS stores: a third of a row's life in this issue-bound kernel --
+ * becomes a 16-byte-per-lane copy into LDS.  Everything else (and every bit of the result) as sea_predictor_tail_select;
+ * a caller that wants the map later runs sea_predictor_tail_z on the same z. */
+int sea_predictor_tail_select_z(const float* z, int dtype, int64_t N, int64_t H, int64_t T, int64_t W4, int64_t up,
+                                int64_t T_m, const float* conv_b, const void* gamma, const void* beta, float eps,
+                                void* probs, void* scores, const int32_t* keep, int64_t keep_stride_n, int64_t T_src,
+                                int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz, int32_t* head_off,
+                                sea_stream_t stream);
 
 /* Causal cumulative average out[n,h,t,:] = sum_{s<=t} v[n,h,s,:] / (t+1), fp32 accumulation.
  * Replaces `avg_v.cumsum(-2) / arange(1..T)` (attention.py:1220-1222).  out (N,H,T,D) contiguous. */
@@ -347,6 +366,29 @@ int sea_split_layernorm_c8(const void* x, int dtype, int64_t N, int64_t C, int64
 int sea_causal_conv_c8(const void* x, int dtype, int64_t N, int64_t T, int64_t W, int64_t Cin, int64_t Cout,
                        const void* w_packed, int64_t CinP, const float* bias, int ksize, int dilation, int pad_w,
                        int relu, void* y, sea_stream_t stream);
+
+/* fp32 twin of sea_causal_conv_c8 (round 5): exact fp32 products and accumulation on v_mfma_f32_16x16x4_f32, for callers that
+ * keep the reference's fp32 measurement protocol (src/main/benchmark_bert.py:196-239).  x (N,T,Cin/8,W,8), y (N,T,Cout/8,W,8)
+ * fp32 in the same channel-blocked layout; w_packed (Cout, ksize*ksize, CinP) fp32 = weight[co, ci, i, j] laid out
+ * [co][i*ksize+j][ci], ci zero-padded to CinP = Cin rounded up to 16; bias (Cout) fp32.  ksize 1 or 3, Cout <= 80;
+ * SEA_EUNSUPPORTED when the fp32 weight image (16*ceil(Cout/16) x ksize^2 x CinP x 4 B) exceeds the 160 KB LDS. */
+int sea_causal_conv_c8_f32(const float* x, int64_t N, int64_t T, int64_t W, int64_t Cin, int64_t Cout,
+                           const float* w_packed, int64_t CinP, const float* bias, int ksize, int dilation, int pad_w,
+                           int relu, float* y, sea_stream_t stream);
+
+/* The LAST (conv, ReLU) pair of the predictor CNN with the tail's 1x1 convolution in its epilogue (round 5).  `KeepRes` adds
+ * no residual (modules.py:42-55) and a 1x1 kernel commutes with the nearest x`up` upsample that sits between the two
+ * (attention.py:266-281), so  z = W1 . relu(conv(x) + bias) + b1  can be formed while the activation tile is still in the
+ * matrix pipe's registers: + ceil(H/16) * ceil(Cout/32) MFMAs per 16 pixels (+5.5 % at 64 -> 64 channels, 32 heads).
+ *   arguments up to `y` as sea_causal_conv_c8 (ksize = 3, Cout <= 80); y may be NULL (the activation is then not written);
+ *   conv1x1_w16 (16*ceil(H/16), Cp1) 16-bit row-major, zero padded, Cp1 = Cout rounded up to 32 (= sea_predictor_tail's
+ *   conv_w16); conv1x1_b (>= H) fp32; z (N, T, H, W) fp32 -- what sea_predictor_tail_z / sea_predictor_tail_select_z read.
+ * The activation enters the product rounded to `dtype` exactly as the y store rounds it, with the operand placement and k
+ * order of the tail kernels' own z stage: z is bit for bit what they compute from y. */
+int sea_causal_conv_c8_z(const void* x, int dtype, int64_t N, int64_t T, int64_t W, int64_t Cin, int64_t Cout,
+                         const void* w_packed, int64_t CinP, const float* bias, int ksize, int dilation, int pad_w,
+                         int relu, void* y, const void* conv1x1_w16, int64_t Cp1, const float* conv1x1_b, int64_t H,
+                         float* z, sea_stream_t stream);
 
 /* Predictor MLP of SEA's estimator in one launch, 16-bit data, bf16/f16 MFMA:
  *   enc  = GELU(LayerNorm_D1(x W1^T + b1))                      attention_predictor_enc      (attention.py:190-196)

@@ -8,7 +8,7 @@ TAG=${1:-r02}
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$TAG
 mkdir -p "$OUT"; cd "$GRAFT_REPO_ROOT"
-BENCH_ARGS="--steps 3 --warmup 1 --prewarm 2 --no-cpu-baseline --kernel-iters 0 --no-output-check --no-other-workloads --no-train-step --decode-steps 0 --sparse-kernel ${ATTN_PATH:-gather} ${BENCH_EXTRA:-}"
+BENCH_ARGS="--steps 3 --warmup 1 --prewarm 2 --no-cpu-baseline --kernel-iters 0 --no-output-check --no-other-workloads --no-train-step --decode-steps 0 --repeats 0 --sparse-kernel ${ATTN_PATH:-gather} ${BENCH_EXTRA:-}"
 echo "rocprofv3 --kernel-trace --pmc <C> --output-format csv -- python3 bench.py $BENCH_ARGS   (one pass per counter set: FETCH_SIZE | WRITE_SIZE | TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum; the layer's in-step launches only)" > "$OUT/command.txt"
 for C in FETCH_SIZE WRITE_SIZE "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum"; do
   N=$(echo $C | tr ' ' '_')

@@ -9,7 +9,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p "$OUT"
 cd "$GRAFT_REPO_ROOT"
 timeout -k 10 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT" -o trace -- \
-  python3 bench.py --steps ${BENCH_STEPS:-10} --warmup 3 --no-cpu-baseline --kernel-iters 0 --no-output-check --no-other-workloads --no-train-step --decode-steps 0 --sparse-kernel ${ATTN_PATH:-gather} ${BENCH_EXTRA:-} > "$OUT/bench.log" 2>&1
+  python3 bench.py --steps ${BENCH_STEPS:-10} --warmup 3 --no-cpu-baseline --kernel-iters 0 --no-output-check --no-other-workloads --no-train-step --decode-steps 0 --repeats 0 --sparse-kernel ${ATTN_PATH:-gather} ${BENCH_EXTRA:-} > "$OUT/bench.log" 2>&1
 echo "rocprof exit=$?"
 tail -2 "$OUT/bench.log"
 find "$OUT" -name "*stats*" | head

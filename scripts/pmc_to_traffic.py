@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 --pmc passes of scripts/gpu_pmc.sh (taken on bench.py's own in-layer launches) into
-profiles/<tag>_pmc_traffic.json (+ traffic_latest.json, stamped with the attention kernel's source hash: bench.py reports
-`roofline.traffic` only when the stamp matches the sources it runs).
+profiles/<tag>_pmc_traffic.json + profiles/traffic_<workload>_x<batch>.json (and traffic_latest.json for the headline
+workload), stamped with the attention kernel's source hash: bench.py's roofline() looks through profiles/traffic_*.json and
+reports `roofline.traffic` only from a record whose stamp, entry count, kernel path and context dtype match the launch it timed.
 HBM bytes per launch = (2*FETCH_SIZE + WRITE_SIZE) * 1024 on gfx950 for 16 B/lane loads (MI355X_MICROARCH.md, HBM section).
 usage: pmc_to_traffic.py <tag> [build note]"""
 import csv, json, os, shutil, sys, collections
@@ -27,7 +28,7 @@ bench_line = json.loads(log[-1]) if log else {}
 cmd_file = os.path.join(src, "command.txt")                 # written by scripts/gpu_pmc.sh: the command the passes really ran
 ab = bench_line.get("attention_path_ab") or {}
 wl = (bench_line.get("config") or {}).get("workload", "")
-out = {"round": 4, "build": note, "kernel_source_sha256": _attn_source_sha(),
+out = {"round": 5, "build": note, "kernel_source_sha256": _attn_source_sha(),
        "command": open(cmd_file).read().strip() if os.path.exists(cmd_file) else "(scripts/gpu_pmc.sh; command file missing)",
        "attention_path": ab.get("chosen") or ab.get("requested"),
        "context_dtype": "torch.float32" if "context_layer fp32" in wl else ("torch.bfloat16" if "context_layer bf16" in wl else None),
@@ -43,6 +44,11 @@ for name, c in acc.items():
     if "sparse_attn" in name:          # per-block dispatch launches the gather AND the tile kernel: the step's traffic is their sum
         out["sea_sparse_attention_hbm_bytes_per_launch"] = out.get("sea_sparse_attention_hbm_bytes_per_launch", 0) + int((2 * fs + ws) * 1024)
         out["sea_sparse_attention_l2_requests_per_launch"] = out.get("sea_sparse_attention_l2_requests_per_launch", 0) + int(req)
-for dst in (f"{tag}_pmc_traffic.json", "traffic_latest.json"):
+import re
+m = re.match(r"([\w.\-]+) SEA attention layer.*?batch (\d+) sequences/GPU", wl or "")
+slug = (m.group(1).replace(".", "").replace("-", "") + "_x" + m.group(2)) if m else "unknown"
+dsts = [f"{tag}_pmc_traffic.json", f"traffic_{slug}.json"] + (["traffic_latest.json"] if slug == "opt13b_x8" else [])
+for dst in dsts:
     json.dump(out, open(os.path.join(ROOT, "profiles", dst), "w"), indent=1)
+print("wrote", dsts)
 print(json.dumps({k: (v["hbm_bytes_per_launch_corrected"], v["l2_requests_per_launch"], v["l2_hit_rate"]) for k, v in out["kernels"].items()}, indent=1))

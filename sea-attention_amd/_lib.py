@@ -9,7 +9,7 @@ import torch
 from . import _build
 
 SEA_F32, SEA_F16, SEA_BF16 = 0, 1, 2
-ABI_VERSION = 2            # include/sea_hip.h: SEA_ABI_VERSION
+ABI_VERSION = 3            # include/sea_hip.h: SEA_ABI_VERSION
 _DTYPES = {torch.float32: SEA_F32, torch.float16: SEA_F16, torch.bfloat16: SEA_BF16}
 
 _lib = None
@@ -56,6 +56,12 @@ _SIGNATURES = {
                            ctypes.c_float, ptr, i64, ptr, ptr, ptr, ptr], c_int),
     "sea_split_layernorm_c8": ([ptr, c_int, i64, i64, i64, i64, i64, ptr, ptr, ctypes.c_float, ptr, ptr], c_int),
     "sea_causal_conv_c8": ([ptr, c_int, i64, i64, i64, i64, i64, ptr, i64, ptr, c_int, c_int, c_int, c_int, ptr, ptr], c_int),
+    "sea_causal_conv_c8_f32": ([ptr, i64, i64, i64, i64, i64, ptr, i64, ptr, c_int, c_int, c_int, c_int, ptr, ptr], c_int),
+    "sea_causal_conv_c8_z": ([ptr, c_int, i64, i64, i64, i64, i64, ptr, i64, ptr, c_int, c_int, c_int, c_int, ptr,
+                              ptr, i64, ptr, i64, ptr, ptr], c_int),
+    "sea_predictor_tail_z": ([ptr, c_int, i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ctypes.c_float, ptr, ptr, ptr], c_int),
+    "sea_predictor_tail_select_z": ([ptr, c_int, i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ctypes.c_float, ptr, ptr,
+                                     ptr, i64, i64, c_int, c_int, ptr, ptr, ptr, ptr], c_int),
     "sea_performer_causal": ([ptr, ptr, ptr, ptr, c_int, ptr, i64, i64, i64, i64, i64, _i64p, _i64p, _i64p, i64, ptr, ptr, ptr], c_int),
     "sea_performer_state_bytes": ([i64, i64, i64, i64, c_int], i64),
     "sea_performer_chunk_rows": ([i64, i64, c_int], i64),
@@ -184,6 +190,8 @@ def check(rc, what):
 
 def require_gpu(*tensors):
     for t in tensors:
+        if t is not None and type(t).__name__ == "LazyTensor":
+            t.materialize()          # what reaches the C ABI is the real tensor (ops.LazyTensor.data_ptr serves it)
         if t is not None and not t.is_cuda:
             raise RuntimeError(
                 "sea_attention_amd operators run only on an MI355X device tensor through libsea_hip.so; "

@@ -475,11 +475,12 @@ template <typename T, typename TO, int D, int RT, int NW>
 static int launch_tile_inst(AttnParams p, int KW, hipStream_t s) {
   const int wl = tile_wave_lds(D, RT, KW);
   const int lds = wl * NW;
-  static int lds_set = 0;                                   // per instantiation; grows monotonically (benign if two threads race)
-  if (lds > lds_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&sparse_attn_tile_kernel<T, TO, D, RT, NW>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return SEA_ELAUNCH;
-    lds_set = lds;
+  static int lds_set[64] = {0};                             // per instantiation and device; grows monotonically (benign if two threads race)
+  int dev_ = 0;
+  (void)hipGetDevice(&dev_);
+  if (lds > lds_set[dev_ & 63]) {
+    SEA_MAX_LDS((sparse_attn_tile_kernel<T, TO, D, RT, NW>), lds);
+    lds_set[dev_ & 63] = lds;
   }
   const int rpb = NW * 16 * RT;
   p.TB = (p.T_dst + rpb - 1) / rpb;

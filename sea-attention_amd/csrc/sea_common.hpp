@@ -31,6 +31,28 @@ void set_error(const char* fmt, ...);
     }                                                                       \
   } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to the DEVICE that is current when it is set, and the call is a slow
+// driver round trip: one flag per (call site, device), not one per process.  `static DevOnce once; if (once.first()) ...`
+struct DevOnce {
+  unsigned long long seen = 0;                     // bit d: configured on device d (a racing first call sets it twice: harmless)
+  bool first() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess) return true;
+    const unsigned long long m = 1ull << (d & 63);
+    const unsigned long long old = __atomic_fetch_or(&seen, m, __ATOMIC_RELAXED);
+    return (old & m) == 0;
+  }
+};
+// a failed attribute call fails the launch that needed it (rc < 0 + sea_last_error), it is not discarded
+#define SEA_MAX_LDS(fn, bytes)                                                                                       \
+  do {                                                                                                               \
+    const hipError_t _ea = hipFuncSetAttribute((const void*)(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); \
+    if (_ea != hipSuccess) {                                                                                         \
+      ::sea::set_error("hipFuncSetAttribute(MaxDynamicSharedMemorySize = %d): %s", (int)(bytes), hipGetErrorString(_ea)); \
+      return SEA_ELAUNCH;                                                                                            \
+    }                                                                                                                \
+  } while (0)
+
 // ---- element access ------------------------------------------------------------------------
 template <typename T> struct Elem;
 template <> struct Elem<float> {

@@ -317,11 +317,10 @@ static int launch_mlp(const MlpParams& p, int nt1, int nt2, hipStream_t s) {
     if (lds > 160 * 1024) break;                                                                                    \
     int64_t blocks = (nitems + NW - 1) / NW;                                                                        \
     if (blocks > 256) blocks = 256;               /* persistent: one workgroup per CU keeps the weights in LDS */   \
-    static bool configured = false;                                                                                 \
-    if (!configured) {                                                                                              \
-      (void)hipFuncSetAttribute((const void*)predictor_mlp_kernel<T, A, B, NW, true, false, PW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);  \
-      (void)hipFuncSetAttribute((const void*)predictor_mlp_kernel<T, A, B, NW, false, false, PW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      configured = true;                                                                                            \
+    static DevOnce once;                                                                                            \
+    if (once.first()) {                                                                                             \
+      SEA_MAX_LDS((predictor_mlp_kernel<T, A, B, NW, true, false, PW>), 160 * 1024);                                \
+      SEA_MAX_LDS((predictor_mlp_kernel<T, A, B, NW, false, false, PW>), 160 * 1024);                               \
     }                                                                                                               \
     if (stage) hipLaunchKernelGGL((predictor_mlp_kernel<T, A, B, NW, true, false, PW>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);  \
     else hipLaunchKernelGGL((predictor_mlp_kernel<T, A, B, NW, false, false, PW>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);       \
@@ -334,11 +333,8 @@ static int launch_mlp(const MlpParams& p, int nt1, int nt2, hipStream_t s) {
     if (lds <= 160 * 1024 && p.KS1 <= 12) {
       int64_t blocks = (nitems + NW - 1) / NW;
       if (blocks > 256) blocks = 256;
-      static bool configured = false;
-      if (!configured) {
-        (void)hipFuncSetAttribute((const void*)predictor_mlp_kernel<T, A, B, NW, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        configured = true;
-      }
+      static DevOnce once;
+      if (once.first()) SEA_MAX_LDS((predictor_mlp_kernel<T, A, B, NW, true, true>), 160 * 1024);
       hipLaunchKernelGGL((predictor_mlp_kernel<T, A, B, NW, true, true>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);
       rc = SEA_OK;
     }

@@ -1584,11 +1584,10 @@ static int launch_perf(const PerfParams& p, hipStream_t s) {
       : sizeof(float) * (NBP * (D + 2) + 2 * C * (D + 2) + C * (E + 16) + 2 * C * (NBP + 2) + NBP + C +
                          C * (C / 16 + NW * 64 / C));
   static_assert(lds <= 160 * 1024, "LDS budget");
-  static bool configured = false;   // one per template instantiation; the attribute call is a slow driver round trip
-  if (lds > 64 * 1024 && !configured) {
-    (void)hipFuncSetAttribute((const void*)performer_kernel<T, D, NBT, C, NW, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)performer_kernel<T, D, NBT, C, NW, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    configured = true;
+  static DevOnce once;              // one per template instantiation and device; the attribute call is a slow driver round trip
+  if (lds > 64 * 1024 && once.first()) {
+    SEA_MAX_LDS((performer_kernel<T, D, NBT, C, NW, false>), lds);
+    SEA_MAX_LDS((performer_kernel<T, D, NBT, C, NW, true>), lds);
   }
   if (p.seg_len % C != 0) return SEA_EINVAL;
   if (p.nseg > 1)
@@ -1608,11 +1607,10 @@ static int launch_perf_bf16(const PerfParams& p, hipStream_t s) {
   constexpr size_t lds = 2 * ((D / 8) * NBP * 8 + 2 * (D / 8) * C * 8 + C * E + NSET * (2 * C * LDQ2 + 2 * C * LDK2) + 2 * C * LDA) +
                          sizeof(float) * (FP + C * (C / 16 + NTH / C) + 8 * FP);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute((const void*)performer_bf16_kernel<T, NBT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)performer_bf16_kernel<T, NBT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    configured = true;
+  static DevOnce once;
+  if (once.first()) {
+    SEA_MAX_LDS((performer_bf16_kernel<T, NBT, false>), lds);
+    SEA_MAX_LDS((performer_bf16_kernel<T, NBT, true>), lds);
   }
   if (p.seg_len % C != 0) return SEA_EINVAL;
   if (p.nseg > 1)
@@ -1632,11 +1630,10 @@ static int launch_perf_bf16w(const PerfParams& p, hipStream_t s) {
   constexpr size_t lds = 2 * (KC * NBP * 8 + 2 * KC * C * 8 + C * EL + 2 * (2 * C * LDQ2 + 2 * C * LDK2) + 2 * C * LDA) +
                          sizeof(float) * (FP + C * (C / 16 + 8) + 8 * FP);
   static_assert(lds <= 160 * 1024, "LDS budget");
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute((const void*)performer_bf16w_kernel<T, D, C, NBT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipFuncSetAttribute((const void*)performer_bf16w_kernel<T, D, C, NBT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    configured = true;
+  static DevOnce once;
+  if (once.first()) {
+    SEA_MAX_LDS((performer_bf16w_kernel<T, D, C, NBT, false>), lds);
+    SEA_MAX_LDS((performer_bf16w_kernel<T, D, C, NBT, true>), lds);
   }
   if (p.seg_len % C != 0) return SEA_EINVAL;
   if (p.nseg > 1)

@@ -493,8 +493,7 @@ static int launch_tail(const TailParams& p, size_t lds, dim3 grid, hipStream_t s
   const int E = (p.T_M + 63) / 64;
 #define SEA_TAIL(EE)                                                                                         \
   do {                                                                                                       \
-    if (lds > 64 * 1024)                                                                                     \
-      (void)hipFuncSetAttribute((const void*)predictor_tail_kernel<T, EE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (lds > 64 * 1024) SEA_MAX_LDS((predictor_tail_kernel<T, EE>), lds);   /* per launch: the size varies with the shape */ \
     hipLaunchKernelGGL((predictor_tail_kernel<T, EE>), grid, dim3(256), lds, s, p);                          \
   } while (0)
   switch (E) {
@@ -541,7 +540,7 @@ extern "C" int sea_predictor_tail(const void* y, int dtype, int64_t N, int64_t C
   p.y = y; p.w4 = conv_w; p.b4 = conv_b; p.gamma = gamma; p.beta = beta; p.probs = probs; p.scores = scores; p.eps = eps;
   p.N = (int)N; p.C = (int)C; p.H = (int)H; p.T = (int)T; p.W4 = (int)W4; p.UP = (int)up; p.T_M = (int)T_m;
   p.ys_n = y_strides[0]; p.ys_c = y_strides[1]; p.ys_t = y_strides[2]; p.ys_w = y_strides[3]; p.ys_c8 = y_strides[4];
-  p.w16 = conv_w16; p.Cp = (int)Cp;
+  p.w16 = conv_w16; p.Cp = (int)Cp; p.z = nullptr;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)(N * T));
   int rc;
@@ -552,6 +551,28 @@ extern "C" int sea_predictor_tail(const void* y, int dtype, int64_t N, int64_t C
   else if (dtype == SEA_F16) rc = launch_tail<__half>(p, lds, grid, s);
   else rc = launch_tail<__hip_bfloat16>(p, lds, grid, s);
   SEA_REQUIRE(rc == SEA_OK, rc, "%s: unsupported T_m", nm);
+  SEA_CHECK_LAUNCH(nm);
+  return SEA_OK;
+}
+
+// The tail from z = the 1x1 convolution's output, as sea_causal_conv_c8_z's epilogue writes it: (N, T, H, W4) fp32.
+extern "C" int sea_predictor_tail_z(const float* z, int dtype, int64_t N, int64_t H, int64_t T, int64_t W4, int64_t up, int64_t T_m,
+                                    const float* conv_b, const void* gamma, const void* beta, float eps, void* probs, void* scores,
+                                    sea_stream_t stream) {
+  const char* nm = "sea_predictor_tail_z";
+  SEA_REQUIRE(z && conv_b && gamma && beta && probs, SEA_EINVAL, "%s: null pointer", nm);
+  SEA_REQUIRE(dtype == SEA_F16 || dtype == SEA_BF16, SEA_EUNSUPPORTED, "%s: 16-bit maps only (dtype %d)", nm, dtype);
+  SEA_REQUIRE(N > 0 && H > 0 && T > 0 && W4 > 0 && up > 0 && T_m > 0, SEA_EINVAL, "%s: bad shape", nm);
+  SEA_REQUIRE(T_m <= 512 && W4 * up == T_m && T_m % 4 == 0 && W4 % 4 == 0, SEA_EUNSUPPORTED,
+              "%s: needs W4 * up == T_m <= 512, T_m %% 4 == 0, W4 %% 4 == 0", nm);
+  SEA_REQUIRE((((uintptr_t)probs | (uintptr_t)scores | (uintptr_t)z) & 15) == 0, SEA_EUNSUPPORTED, "%s: 16-byte alignment", nm);
+  TailParams p;
+  p.y = nullptr; p.w4 = nullptr; p.b4 = conv_b; p.gamma = gamma; p.beta = beta; p.probs = probs; p.scores = scores; p.eps = eps;
+  p.N = (int)N; p.C = 0; p.H = (int)H; p.T = (int)T; p.W4 = (int)W4; p.UP = (int)up; p.T_M = (int)T_m;
+  p.ys_n = p.ys_c = p.ys_t = p.ys_w = p.ys_c8 = 0; p.w16 = nullptr; p.Cp = 0; p.z = z;
+  hipStream_t s = (hipStream_t)stream;
+  const int rc = dtype == SEA_F16 ? launch_tail_mfma<__half>(p, dim3((unsigned)(N * T)), s) : launch_tail_mfma<__hip_bfloat16>(p, dim3((unsigned)(N * T)), s);
+  SEA_REQUIRE(rc == SEA_OK, rc, "%s: unsupported T_m / H for the tail's LDS plan", nm);
   SEA_CHECK_LAUNCH(nm);
   return SEA_OK;
 }

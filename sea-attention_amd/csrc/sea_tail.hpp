@@ -20,6 +20,8 @@ struct TailParams {
   int64_t ys_c8;                   // stride between blocks of 8 channels (8*ys_c for plain 4-D layouts; W*8 for C8)
   const void* w16;   // MFMA variant: (HP16, Cp) 16-bit row-major copy of the conv weight, zero padded
   int Cp;            // channels padded to a multiple of 32
+  const float* z;    // optional (N, T, H, W4) fp32: the 1x1 conv's output, already computed (sea_causal_conv_c8_z's epilogue);
+                     // y / w16 are then unused and the z tile is a copy into LDS
 };
 
 template <typename T, int E> __device__ inline void store_run(T* dst, const float* f, int j0, int T_M) {
@@ -60,6 +62,18 @@ __device__ __forceinline__ void tail_z_tile(const TailParams& p, float* s_z, int
   const int HP = ((p.H + 15) / 16) * 16;
   const int LDZ = p.W4 + 3;
   const float* __restrict__ bF = reinterpret_cast<const float*>(p.b4);
+  if (p.z) {                                         // block-uniform: z was produced by the convolution's epilogue
+    const float* zr = p.z + ((int64_t)n * p.T + t) * ((int64_t)p.H * p.W4);
+    const int qpr = p.W4 >> 2, nq = p.H * qpr;       // W4 % 4 == 0 (launchers check); 16-byte loads, one round trip
+    for (int i = threadIdx.x; i < nq; i += 256) {
+      const float4 v = *reinterpret_cast<const float4*>(zr + 4 * i);
+      const int h = p.W4 == 64 ? (i >> 4) : i / qpr;
+      float* d = s_z + h * LDZ + 4 * (i - h * qpr);
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    for (int h = threadIdx.x; h < HP; h += 256) { s_z[h * LDZ + p.W4] = h < p.H ? bF[h] : 0.f; s_z[h * LDZ + p.W4 + 1] = 0.f; }
+    return;
+  }
   const T* __restrict__ w16 = reinterpret_cast<const T*>(p.w16);
   const T* yb = reinterpret_cast<const T*>(p.y) + n * p.ys_n + t * p.ys_t;
   const int MT = (p.W4 + 15) / 16, NT = HP / 16, KC = p.Cp / 32;

@@ -1057,11 +1057,8 @@ static int launch_tail_select_gen(const TailParams& tp, const TopkParams& p, int
   dim3 grid((unsigned)rows), block(TK_THREADS);
 #define SEA_TSG(EV, PV)                                                                                            \
   do {                                                                                                             \
-    static bool configured = false;                                                                                \
-    if (lds > 48 * 1024 && !configured) {                                                                          \
-      (void)hipFuncSetAttribute((const void*)predictor_tail_select_gen_kernel<T, EV, PV>, hipFuncAttributeMaxDynamicSharedMemorySize, 148 * 1024); \
-      configured = true;                                                                                           \
-    }                                                                                                              \
+    static DevOnce once;                                                                                           \
+    if (lds > 48 * 1024 && once.first()) SEA_MAX_LDS((predictor_tail_select_gen_kernel<T, EV, PV>), 148 * 1024);   \
     hipLaunchKernelGGL((predictor_tail_select_gen_kernel<T, EV, PV>), grid, block, lds, s, tp, p);                 \
   } while (0)
 #define SEA_TSG_E(PV)                                                                                              \
@@ -1078,31 +1075,37 @@ static int launch_tail_select_gen(const TailParams& tp, const TopkParams& p, int
   return SEA_OK;
 }
 
-static int tail_select_common(const char* nm, const void* y, int dtype, int64_t N, int64_t C, int64_t H, int64_t T, int64_t W4,
+static int tail_select_common(const char* nm, const float* z, const void* y, int dtype, int64_t N, int64_t C, int64_t H, int64_t T, int64_t W4,
                               int64_t up, int64_t T_m, const int64_t* y_strides, const void* conv_b,
                               const void* conv_w16, int64_t Cp, const void* gamma, const void* beta, float eps,
                               void* probs, void* scores, const int32_t* keep, int64_t keep_stride_n,
                               int64_t T_src, const int32_t* t_src_dev, int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz,
                               int32_t* head_off, int32_t* crow1, sea_stream_t stream) {
   SEA_REQUIRE(crow1 == nullptr || T == 1, SEA_EINVAL, "%s: crow_out goes with one row per batch item (T = %lld)", nm, (long long)T);
-  SEA_REQUIRE(y && y_strides && conv_b && conv_w16 && gamma && beta && keep && bits && row_nnz && head_off, SEA_EINVAL,
+  SEA_REQUIRE((z || (y && y_strides && conv_w16)) && conv_b && gamma && beta && keep && bits && row_nnz && head_off, SEA_EINVAL,
               "%s: null pointer", nm);
   SEA_REQUIRE(dtype == SEA_F16 || dtype == SEA_BF16, SEA_EUNSUPPORTED, "%s: 16-bit data only (dtype %d)", nm, dtype);
-  SEA_REQUIRE(N > 0 && C > 0 && H > 0 && T > 0 && T_src >= T && max_k > 0, SEA_EINVAL, "%s: bad shape", nm);
+  SEA_REQUIRE(N > 0 && (z || C > 0) && H > 0 && T > 0 && T_src >= T && max_k > 0, SEA_EINVAL, "%s: bad shape", nm);
   const bool tm256 = T_m == 256 && W4 == 64 && up == 4 && H % 4 == 0;       // the register-resident form
   SEA_REQUIRE(W4 * up == T_m && T_m % 4 == 0 && T_m <= 512 && H <= 64 && H * T_m <= 16384 && W4 + 1 < 1024 && W4 * up + 2 <= 2 * T_m,
               SEA_EUNSUPPORTED, "%s: needs W4 * up == T_m, T_m %% 4 == 0, T_m <= 512, H <= 64, H * T_m <= 16384", nm);
   SEA_REQUIRE(tm256 || t_src_dev == nullptr, SEA_EUNSUPPORTED, "%s: the decode form takes T_m = 256 (W4 = 64, up = 4), H %% 4 == 0", nm);
-  SEA_REQUIRE(y_strides[1] == 1 && C % 8 == 0 && y_strides[0] % 8 == 0 && y_strides[2] % 8 == 0 && y_strides[3] % 8 == 0 &&
-                  y_strides[4] % 8 == 0 && Cp % 32 == 0 && Cp >= C &&
-                  (((uintptr_t)y | (uintptr_t)conv_w16 | (uintptr_t)probs | (uintptr_t)scores) & 15) == 0,
-              SEA_EUNSUPPORTED, "%s: y must be channels-last / C8 with 16-byte aligned vectors", nm);
+  if (z) {
+    SEA_REQUIRE(W4 % 4 == 0 && (((uintptr_t)z | (uintptr_t)probs | (uintptr_t)scores) & 15) == 0, SEA_EUNSUPPORTED,
+                "%s: z rows must be whole 16-byte vectors, 16-byte aligned", nm);
+  } else {
+    SEA_REQUIRE(y_strides[1] == 1 && C % 8 == 0 && y_strides[0] % 8 == 0 && y_strides[2] % 8 == 0 && y_strides[3] % 8 == 0 &&
+                    y_strides[4] % 8 == 0 && Cp % 32 == 0 && Cp >= C &&
+                    (((uintptr_t)y | (uintptr_t)conv_w16 | (uintptr_t)probs | (uintptr_t)scores) & 15) == 0,
+                SEA_EUNSUPPORTED, "%s: y must be channels-last / C8 with 16-byte aligned vectors", nm);
+  }
   SEA_REQUIRE(N * T < (1ll << 31), SEA_EUNSUPPORTED, "%s: too many rows", nm);
   TailParams tp;
   tp.y = y; tp.w4 = nullptr; tp.b4 = conv_b; tp.gamma = gamma; tp.beta = beta; tp.probs = probs; tp.scores = scores; tp.eps = eps;
   tp.N = (int)N; tp.C = (int)C; tp.H = (int)H; tp.T = (int)T; tp.W4 = (int)W4; tp.UP = (int)up; tp.T_M = (int)T_m;
-  tp.ys_n = y_strides[0]; tp.ys_c = y_strides[1]; tp.ys_t = y_strides[2]; tp.ys_w = y_strides[3]; tp.ys_c8 = y_strides[4];
-  tp.w16 = conv_w16; tp.Cp = (int)Cp;
+  tp.ys_n = tp.ys_c = tp.ys_t = tp.ys_w = tp.ys_c8 = 0;
+  if (!z) { tp.ys_n = y_strides[0]; tp.ys_c = y_strides[1]; tp.ys_t = y_strides[2]; tp.ys_w = y_strides[3]; tp.ys_c8 = y_strides[4]; }
+  tp.w16 = conv_w16; tp.Cp = (int)Cp; tp.z = z;
   TopkParams p;
   p.src = nullptr; p.sn = H * T * T_m; p.sh = T * T_m; p.st = T_m;        // (the packed-key selection never re-reads the map)
   p.H = (int)H; p.T_dst = (int)T; p.T_m = (int)T_m; p.T_src = (int)T_src;
@@ -1125,8 +1128,21 @@ extern "C" int sea_predictor_tail_select(const void* y, int dtype, int64_t N, in
                                          void* probs, void* scores, const int32_t* keep, int64_t keep_stride_n,
                                          int64_t T_src, int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz,
                                          int32_t* head_off, sea_stream_t stream) {
-  return tail_select_common("sea_predictor_tail_select", y, dtype, N, C, H, T, W4, up, T_m, y_strides, conv_b, conv_w16, Cp, gamma,
+  return tail_select_common("sea_predictor_tail_select", nullptr, y, dtype, N, C, H, T, W4, up, T_m, y_strides, conv_b, conv_w16, Cp, gamma,
                             beta, eps, probs, scores, keep, keep_stride_n, T_src, nullptr, is_causal, max_k, bits, row_nnz,
+                            head_off, nullptr, stream);
+}
+
+// The same launch fed with z = the 1x1 convolution's output (N, T, H, W4) fp32 as sea_causal_conv_c8_z's epilogue writes it:
+// the z tile of a row is then a copy into LDS instead of loads + MFMAs (a third of a row's life in this issue-bound kernel).
+extern "C" int sea_predictor_tail_select_z(const float* z, int dtype, int64_t N, int64_t H, int64_t T, int64_t W4, int64_t up,
+                                           int64_t T_m, const float* conv_b, const void* gamma, const void* beta, float eps,
+                                           void* probs, void* scores, const int32_t* keep, int64_t keep_stride_n, int64_t T_src,
+                                           int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz, int32_t* head_off,
+                                           sea_stream_t stream) {
+  SEA_REQUIRE(z, SEA_EINVAL, "sea_predictor_tail_select_z: null pointer");
+  return tail_select_common("sea_predictor_tail_select_z", z, nullptr, dtype, N, 0, H, T, W4, up, T_m, nullptr, conv_b, nullptr, 0,
+                            gamma, beta, eps, probs, scores, keep, keep_stride_n, T_src, nullptr, is_causal, max_k, bits, row_nnz,
                             head_off, nullptr, stream);
 }
 
@@ -1139,7 +1155,7 @@ extern "C" int sea_predictor_tail_select_at(const void* y, int dtype, int64_t N,
                                             int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz, int32_t* head_off,
                                             int32_t* crow_out, sea_stream_t stream) {
   SEA_REQUIRE(t_src_dev, SEA_EINVAL, "sea_predictor_tail_select_at: null pointer");
-  return tail_select_common("sea_predictor_tail_select_at", y, dtype, N, C, H, T, W4, up, T_m, y_strides, conv_b, conv_w16, Cp,
+  return tail_select_common("sea_predictor_tail_select_at", nullptr, y, dtype, N, C, H, T, W4, up, T_m, y_strides, conv_b, conv_w16, Cp,
                             gamma, beta, eps, probs, scores, keep_table, 0, T, t_src_dev, is_causal, max_k, bits, row_nnz,
                             head_off, crow_out, stream);
 }

@@ -133,7 +133,26 @@ class ChunkedContextGatherer:
         self.buf = [torch.empty((chunks, self.world, self.n_c) + rest, dtype=dtype, device=device) for _ in range(depth)]
         self._work = [[None] * chunks for _ in range(depth)]
         self._i = 0
+        # capability decided ONCE, here, by a probe collective every rank issues alike: a backend without the fused in-place
+        # form raises on all ranks together and all of them take the list form from then on.  Nothing is caught later -- a real
+        # communication failure on one rank must propagate, not silently switch that rank to a different collective
+        # (ranks issuing different collectives hang the job)
         self._sync_only = False
+        if self.world > 1:
+            probe_in = torch.zeros((1,), dtype=dtype, device=device)
+            probe_out = torch.zeros((self.world,), dtype=dtype, device=device)
+            try:
+                dist.all_gather_into_tensor(probe_out, probe_in, group=group, async_op=True).wait()
+            except NotImplementedError:
+                self._sync_only = True
+            except RuntimeError as e:
+                if not any(w in str(e).lower() for w in ("not supported", "not implemented", "unsupported", "does not support")):
+                    raise
+                self._sync_only = True
+            if self._sync_only and self.rank == 0:
+                import warnings
+                warnings.warn(f"ChunkedContextGatherer: backend {dist.get_backend(group)!r} has no asynchronous in-place all-gather; "
+                              "every chunk takes the blocking list form (no overlap with the next chunk's attention launch)")
 
     def next_slot(self) -> int:
         slot = self._i % self.depth
@@ -157,11 +176,8 @@ class ChunkedContextGatherer:
             return
         out = self.buf[slot][c].view((self.world * self.n_c,) + tuple(self.buf[slot].shape[3:]))
         if not self._sync_only:
-            try:
-                self._work[slot][c] = dist.all_gather_into_tensor(out, self.local_chunk(slot, c), group=self.group, async_op=True)
-                return
-            except (RuntimeError, NotImplementedError):   # backend without the fused / asynchronous form (every rank alike)
-                self._sync_only = True
+            self._work[slot][c] = dist.all_gather_into_tensor(out, self.local_chunk(slot, c), group=self.group, async_op=True)
+            return
         dist.all_gather(list(out.chunk(self.world, dim=0)), self.local_chunk(slot, c).clone(), group=self.group)
 
     def gathered(self, slot: int) -> torch.Tensor:

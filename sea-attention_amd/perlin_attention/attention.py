@@ -37,6 +37,7 @@ from . import ops
 
 timer = lambda name: get_bench().region(name)
 mem = lambda name: get_bench().mem_region(name)
+_C8_DECLINED = set()      # (dtype, Cin, Cout, k) of predictor convolutions the hand-written kernels declined: warned about once each
 
 
 def _safe_to(t, d):
@@ -143,6 +144,11 @@ class PerlinAttention(nn.Module):
         # 8) and `partial_attention_mask` keeps its columns pending -- any reader of `.col` / `.col_indices()` / the wire
         # format runs the emit launch then (bit-identical).  False = written by the step
         self.lazy_csr_columns = True
+        # C8 predictor CNN: True = the last (conv, ReLU) launch also evaluates the tail's 1x1 convolution on the tile it holds
+        # and hands z (N, T, H, T_M/4) fp32 to the tail instead of its activation (`sea_causal_conv_c8_z`; bit-identical, the
+        # activation of the last pair is then not written).  Built in round 5 and MEASURED SLOWER (conv2 +27 us, tail
+        # +-0 at OPT-1.3B x 8 -- the tail's z stage is latency its other resident waves already hide): off by default
+        self.conv_z_epilogue = False
         # sparse mode: kernel of steps J-L: "gather" (row-indexed gathers), "tile" (MFMA tile kernel, 16-bit data,
         # d in {64, 80, 128}; wins when neighbouring query rows keep mostly the same keys -- trained predictors), "auto"
         self.sparse_kernel = "auto"
@@ -313,8 +319,9 @@ class PerlinAttention(nn.Module):
                 and self._c8_cnn_ok(x, body))
 
     def _c8_cnn_ok(self, x, body):
-        """Channel-blocked (C8) MFMA conv pipeline: 16-bit data, body = (CausalConv2d k x k, ReLU)* + upsample + 1x1 conv."""
-        if x.dtype not in (torch.float16, torch.bfloat16):
+        """Channel-blocked (C8) MFMA conv pipeline: body = (CausalConv2d k x k, ReLU)* + upsample + 1x1 conv.  16-bit data on the
+        bf16 / f16 MFMA kernel; fp32 data (round 5) on the fp32-MFMA kernel while its weight image fits the LDS."""
+        if x.dtype not in (torch.float16, torch.bfloat16, torch.float32):
             return False
         W = self.pconfig.attention_predictor_length // 4
         if W % 8 or W > 512 or (len(body) - 2) % 2:
@@ -325,11 +332,64 @@ class PerlinAttention(nn.Module):
                     and conv.stride in (1, (1, 1)) and isinstance(conv.dilation, int)
                     and conv.dilation * (conv.kernel_size - 1) == 2 * conv.padding[1]
                     and conv.kernel_size in (1, 3)
-                    and conv.in_channels % 8 == 0 and conv.out_channels % 8 == 0 and conv.out_channels <= 128
-                    and 16 * ((conv.out_channels + 15) // 16) * (conv.kernel_size ** 2 * ((conv.in_channels + 31) // 32 * 32) * 2 + 4) <= 160 * 1024
-                    and (conv.out_channels + 15) // 16 in (1, 2, 3, 4, 5, 6, 8)):
+                    and conv.in_channels % 8 == 0 and conv.out_channels % 8 == 0 and conv.out_channels <= 128):
+                return False
+            if x.dtype == torch.float32:
+                fits = ops.conv_c8_f32_supported(conv.in_channels, conv.out_channels, conv.kernel_size)
+            else:
+                fits = (16 * ((conv.out_channels + 15) // 16) * (conv.kernel_size ** 2 * ((conv.in_channels + 31) // 32 * 32) * 2 + 4) <= 160 * 1024
+                        and (conv.out_channels + 15) // 16 in (1, 2, 3, 4, 5, 6, 7, 8))
+            if not fits:
+                # not silent: the layer still runs -- on the framework's convolutions (MIOpen), several times slower
+                key = (x.dtype, conv.in_channels, conv.out_channels, conv.kernel_size)
+                if key not in _C8_DECLINED:
+                    _C8_DECLINED.add(key)
+                    warnings.warn(f"SEA predictor CNN: {conv.in_channels} -> {conv.out_channels} channels, {conv.kernel_size} x "
+                                  f"{conv.kernel_size}, {x.dtype}: the weight image does not fit the 160 KB LDS of the hand-written "
+                                  "convolution kernel; this layer takes the framework's convolutions (MIOpen) instead")
                 return False
         return True
+
+    def _c8_cnn_and_tail(self, x, body, ln2, want_scores, allow_select, q, T_SRC):
+        """Steps F-G (+ H) on the C8 kernels: the (conv, ReLU) pairs of `cnn.keepres`, then upsample + 1x1 conv + area resize +
+        `cnn.lnorm2` + softmax -- with the top-k selection in the same launch when `allow_select` (sparse mode, unpadded
+        batch, nobody probing).  `conv_z_epilogue`: the LAST pair's launch also evaluates the 1x1 convolution on the tile it
+        holds (`sea_causal_conv_c8_z`) and hands z to the tail instead of the activation (bit-identical; the activation of the
+        last pair is then never written).  Returns (probs, scores); `self._fused_selection` is set when the selection ran."""
+        conv4 = body[-1].module
+        T_M_, Hh = self.pconfig.attention_predictor_length, self.num_attention_heads
+        w1 = conv4.weight[:, :, 0, 0]
+        pairs = list(range(0, len(body) - 2, 2))
+        last = body[pairs[-1]].module if pairs else None
+        use_z = (self.conv_z_epilogue and last is not None
+                 and ops.conv_z_supported(last.out_channels, Hh, last.kernel_size, x.shape[3]))
+        z = None
+        with timer("cnn.keepres"):
+            for li_ in pairs:                                                               # (conv, ReLU) pairs
+                conv = body[li_].module
+                with timer(body[li_].name):
+                    if use_z and li_ == pairs[-1]:
+                        _y, z = ops.causal_conv_c8_z(x, conv.weight, conv.bias, conv.kernel_size, conv.dilation, conv.padding[1],
+                                                     w1, conv4.bias, ln2.weight, ln2.bias, relu=True)
+                    else:
+                        x = ops.causal_conv_c8(x, conv.weight, conv.bias, conv.kernel_size, conv.dilation,
+                                               conv.padding[1], relu=True)
+            with timer("cnn.tail"):
+                if allow_select and ops.predictor_tail_select_supported(x, Hh, T_M_):
+                    # sparse mode, unpadded batch: the tail hands the map to the top-k selection in registers (one launch)
+                    keep, _z = self._keep_table(Hh, q.shape[-2], T_SRC, T_M_, q.device)
+                    probs, scores, sel = ops.predictor_tail_select(
+                        None if z is not None else x, w1, conv4.bias, ln2.weight, ln2.bias, up=4, T_m=T_M_,
+                        keep=keep, k=int(self.pconfig.k), T_src=T_SRC, is_causal=True, eps=ln2.eps,
+                        want_scores=want_scores, lazy_probs=self.lazy_attention_probs, z=z, map_dtype=x.dtype)
+                    self._fused_selection = (probs, sel)
+                elif z is not None:
+                    probs, scores = ops.predictor_tail_z(z, w1, conv4.bias, ln2.weight, ln2.bias, up=4, T_m=T_M_,
+                                                         dtype=x.dtype, eps=ln2.eps, want_scores=want_scores)
+                else:
+                    probs, scores = ops.predictor_tail(x, w1, conv4.bias, ln2.weight, ln2.bias, up=4,
+                                                       T_m=T_M_, eps=ln2.eps, want_scores=want_scores)
+        return probs, scores
 
     def _estimate(self, q, k, v, q_for_atten, k_for_atten, v_for_atten, dst_attention_mask, not_padded, T_SRC):
         """Steps A..G: value augmentation, Performer, predictor MLP + CNN, softmax over T_M."""
@@ -406,31 +466,9 @@ class PerlinAttention(nn.Module):
                         self._fused_gates = (row_scale, avg_scale)
                 with timer("predictor.cnn"):
                     keepres, ln2 = self.attention_predictor_cnn[1].module, self.attention_predictor_cnn[2].module
-                    body = list(keepres.net.children())
-                    with timer("cnn.keepres"):
-                        for li_ in range(0, len(body) - 2, 2):                              # (conv, ReLU) pairs
-                            conv = body[li_].module
-                            with timer(body[li_].name):
-                                x = ops.causal_conv_c8(x, conv.weight, conv.bias, conv.kernel_size, conv.dilation,
-                                                       conv.padding[1], relu=True)
-                        conv4 = body[-1].module
-                        T_M_ = self.pconfig.attention_predictor_length
-                        Hh = self.num_attention_heads
-                        with timer("cnn.tail"):
-                            if (self.benchmarking and not_padded and not get_bench().activate_temp_buffers
-                                    and ops.predictor_tail_select_supported(x, Hh, T_M_)):
-                                # sparse mode, unpadded batch: the tail hands the map to the top-k selection in
-                                # registers (one launch; the map is still written, it is part of the module's output)
-                                keep, _z = self._keep_table(Hh, q.shape[-2], T_SRC, T_M_, q.device)
-                                estimated_attention_probs, estimated_attention_score, sel = ops.predictor_tail_select(
-                                    x, conv4.weight[:, :, 0, 0], conv4.bias, ln2.weight, ln2.bias, up=4, T_m=T_M_,
-                                    keep=keep, k=int(self.pconfig.k), T_src=T_SRC, is_causal=True, eps=ln2.eps,
-                                    want_scores=want_scores, lazy_probs=self.lazy_attention_probs)
-                                self._fused_selection = (estimated_attention_probs, sel)
-                            else:
-                                estimated_attention_probs, estimated_attention_score = ops.predictor_tail(
-                                    x, conv4.weight[:, :, 0, 0], conv4.bias, ln2.weight, ln2.bias, up=4,
-                                    T_m=T_M_, eps=ln2.eps, want_scores=want_scores)
+                    estimated_attention_probs, estimated_attention_score = self._c8_cnn_and_tail(
+                        x, list(keepres.net.children()), ln2, want_scores,
+                        self.benchmarking and not_padded and not get_bench().activate_temp_buffers, q, T_SRC)
                 bench.register_temp_buffer('t_attention_predictor', t_attention_predictor)
             bench.register_temp_buffer('estimated_attention_score', estimated_attention_score)
             bench.register_temp_buffer('estimated_attention_probs', estimated_attention_probs)
@@ -469,38 +507,25 @@ class PerlinAttention(nn.Module):
                     body = list(keepres.net.children())
                     c8 = self._c8_cnn_ok(dec, body)
                     with timer("cnn.lnorm1"):
-                        if c8:   # 16-bit data: the CNN runs channel-blocked (C8) on the hand-written MFMA conv kernel
+                        if c8 and dec.dtype != torch.float32:   # the CNN runs channel-blocked (C8) on the hand-written MFMA conv kernels
                             x = ops.split_layernorm_c8(dec, self.attention_predictor_dec_row_splits, ln1.weight, ln1.bias, ln1.eps)
+                        elif c8:                                # fp32 data: LayerNorm kernel + one re-layout pass
+                            x = ops.to_c8(ops.split_layernorm(dec, self.attention_predictor_dec_row_splits, ln1.weight, ln1.bias, ln1.eps))
                         else:
                             x = ops.split_layernorm(dec, self.attention_predictor_dec_row_splits, ln1.weight, ln1.bias, ln1.eps)
-                    with timer("cnn.keepres"):
-                        if c8:
-                            for li_ in range(0, len(body) - 2, 2):                          # (conv, ReLU) pairs
-                                conv = body[li_].module
-                                with timer(body[li_].name):
-                                    x = ops.causal_conv_c8(x, conv.weight, conv.bias, conv.kernel_size, conv.dilation,
-                                                             conv.padding[1], relu=True)
-                        else:
+                    if c8:
+                        estimated_attention_probs, estimated_attention_score = self._c8_cnn_and_tail(
+                            x, body, ln2, want_scores,
+                            query_skips == 1 and self.benchmarking and not_padded and not get_bench().activate_temp_buffers, q, T_SRC)
+                    else:
+                        with timer("cnn.keepres"):
                             for layer in body[:-2]:                                           # causal convs + ReLUs
                                 x = layer(x)
-                        conv4 = body[-1].module
-                        T_M_ = self.pconfig.attention_predictor_length
-                        Hh = self.num_attention_heads
-                        with timer("cnn.tail"):
-                            if (c8 and query_skips == 1 and self.benchmarking and not_padded
-                                    and not get_bench().activate_temp_buffers
-                                    and ops.predictor_tail_select_supported(x, Hh, T_M_)):
-                                # as on the fused-MLP path: tail + top-k selection in one launch
-                                keep, _z = self._keep_table(Hh, q.shape[-2], T_SRC, T_M_, q.device)
-                                estimated_attention_probs, estimated_attention_score, sel = ops.predictor_tail_select(
-                                    x, conv4.weight[:, :, 0, 0], conv4.bias, ln2.weight, ln2.bias, up=4, T_m=T_M_,
-                                    keep=keep, k=int(self.pconfig.k), T_src=T_SRC, is_causal=True, eps=ln2.eps,
-                                    want_scores=want_scores, lazy_probs=self.lazy_attention_probs)
-                                self._fused_selection = (estimated_attention_probs, sel)
-                            else:
+                            conv4 = body[-1].module
+                            with timer("cnn.tail"):
                                 estimated_attention_probs, estimated_attention_score = ops.predictor_tail(
                                     x, conv4.weight[:, :, 0, 0], conv4.bias, ln2.weight, ln2.bias, up=4,
-                                    T_m=T_M_, eps=ln2.eps, want_scores=want_scores)
+                                    T_m=self.pconfig.attention_predictor_length, eps=ln2.eps, want_scores=want_scores)
                     if query_skips > 1:
                         estimated_attention_probs = estimated_attention_probs.repeat_interleave(query_skips, dim=-2)
                         if estimated_attention_score is not None:

@@ -12,7 +12,7 @@ from .flat_csr import (FlatCSR, fused_interp_supported, attention_few_rows, topk
                        keep_table_causal, keep_table_kernel_test, z_capacity, csr_from_selection)
 from .predictor import (split_layernorm, predictor_tail, cumavg, performer_value, performer_supported, performer_avg_supported,
                         performer_step, performer_plan, performer_chunk_rows,
-                        split_layernorm_c8, causal_conv_c8, pack_conv_weight, to_c8, from_c8,
+                        split_layernorm_c8, causal_conv_c8, causal_conv_c8_z, conv_z_supported, conv_c8_f32_supported, predictor_tail_z, pack_conv_weight, to_c8, from_c8,
                         predictor_mlp, predictor_mlp_supported, predictor_tail_select,
                         predictor_tail_select_supported, clear_prep_cache, prep_generation, pinned_prep, LazyTensor, realize,
                         decode_stage, c8_window_shift)

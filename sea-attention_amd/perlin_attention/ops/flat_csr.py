@@ -292,14 +292,24 @@ _BWD_WS = {}
 
 
 def _bwd_workspace(nbytes: int, device) -> torch.Tensor:
-    """Scratch of the gather backward (16 B per CSR slot + two int32 per (head, key)): one buffer per device, grown on demand
-    and re-used by every layer's backward (they run one after another on the stream; the contents are undefined between
-    calls) instead of a fresh ~1 GB allocation per layer at OPT-1.3B x 8."""
-    key = (device.type, device.index)
+    """Scratch of the gather backward (16 B per CSR slot + two int32 per (head, key)): one buffer per (device, stream), grown
+    on demand and re-used by every layer's backward on that stream (they run one after another there; the contents are
+    undefined between calls) instead of a fresh ~1 GB allocation per layer at OPT-1.3B x 8.  Keyed by the
+    stream as well: two backward passes on different streams (or threads) of one device never share scratch, so the caching
+    allocator's stream ordering is not needed.  While a HIP graph is being captured the buffer is NOT cached (a block
+    allocated then belongs to the graph's private pool: a global must not point into it) -- the capture gets its own."""
+    if torch.cuda.is_current_stream_capturing():
+        return torch.empty((nbytes,), dtype=torch.uint8, device=device)
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _BWD_WS.get(key)
     if ws is None or ws.numel() < nbytes:
         _BWD_WS[key] = ws = torch.empty((nbytes,), dtype=torch.uint8, device=device)
     return ws[:nbytes]
+
+
+def clear_bwd_workspace():
+    """Release the cached backward scratch (about 1 GB per device and stream at OPT-1.3B x 8); `clear_prep_cache()` calls it."""
+    _BWD_WS.clear()
 
 
 class _SparseAttentionFn(torch.autograd.Function):

@@ -21,7 +21,11 @@ class LazyTensor(torch.Tensor):
     thunk once and proceeds on the real tensor.  Used for `estimated_attention_probs(_m)` in sparse mode: the module
     returns the (N,H,T,T_m) map (attention.py:1343) but nothing on the hot path reads it, and writing it is 537 MB per
     step at OPT-1.3B x 8 -- the fused tail + selection launch keeps it on chip and this handle recomputes it from the
-    kept conv output on demand (same kernel code: bit-identical values)."""
+    kept conv output on demand (same kernel code: bit-identical values).
+    The thunk reads the layer's weights and the kept intermediate AT FIRST ACCESS, on the stream that is current then: a
+    caller that edits the weights in place (or loads a state dict) between the step and the first read gets the map of the
+    NEW weights, not the one the selection used -- `ops.realize(t)` first, or run the module with
+    `lazy_attention_probs = False` (the reference's eager tensor)."""
 
     @staticmethod
     def __new__(cls, shape, dtype, device, thunk):
@@ -42,6 +46,23 @@ class LazyTensor(torch.Tensor):
     @property
     def is_materialized(self) -> bool:
         return self._real is not None
+
+    # C-level consumers (ctypes bindings, numpy, pickling) see the real tensor: a wrapper subclass has no storage, its own
+    # data_ptr() would be 0 -- and an optional pointer argument would then be skipped without any error
+    def data_ptr(self):
+        return self.materialize().data_ptr()
+
+    def numpy(self, *a, **kw):
+        return self.materialize().numpy(*a, **kw)
+
+    def tolist(self):
+        return self.materialize().tolist()
+
+    def __reduce_ex__(self, proto):
+        return self.materialize().__reduce_ex__(proto)
+
+    def __deepcopy__(self, memo):
+        return self.materialize().clone()
 
     def __repr__(self):
         return f"LazyTensor(shape={tuple(self.shape)}, dtype={self.dtype}, device={self.device}, materialized={self._real is not None})"
@@ -73,6 +94,8 @@ def clear_prep_cache():
     global _prep_generation
     _prep_generation += 1
     _prep_cache.clear()
+    from .flat_csr import clear_bwd_workspace
+    clear_bwd_workspace()
 
 
 def prep_generation() -> int:
@@ -154,25 +177,49 @@ def predictor_tail(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.Tensor, 
     H = conv_w.shape[0]
     assert conv_w.shape == (H, C) and W4 * up == T_m
     dt = y.dtype
-    Hpad = (H + 7) // 8 * 8
-
-    def build():
-        cw = torch.zeros((C, Hpad), dtype=torch.float32, device=y.device)  # transposed, head axis padded: scalar-cache reads
-        cw[:, :H] = conv_w.to(dt).float().t()
-        cb = torch.zeros((Hpad,), dtype=torch.float32, device=y.device)
-        cb[:H] = conv_b.to(dt).float()
-        w16, Cp = None, 0
-        if dt != torch.float32:                                           # row-major 16-bit copy for the MFMA variant
-            Cp, HP = (C + 31) // 32 * 32, (H + 15) // 16 * 16
-            w16 = torch.zeros((HP, Cp), dtype=dt, device=y.device)
-            w16[:H, :C] = conv_w.to(dt)
-        return cw, cb, ln_w.to(dt).contiguous(), ln_b.to(dt).contiguous(), w16, Cp
-    cw, cb, g, b, w16, Cp = _cached("tail", (conv_w, conv_b, ln_w, ln_b), dt, build)
+    cw, cb, g, b, w16, Cp = _tail_pack(conv_w, conv_b, ln_w, ln_b, dt, y.device)
     probs = torch.empty((N, H, T, T_m), dtype=dt, device=y.device)
     scores = torch.empty_like(probs) if want_scores else None
     _lib.check(lib.sea_predictor_tail(_p(y), _lib.dtype_code(dt), N, C, H, T, W4, up, T_m, _lib.strides5_blocked(y),
                                       _p(cw), _p(cb), _p(w16), Cp, _p(g), _p(b), float(eps), _p(probs), _p(scores),
                                       _lib.stream_ptr()), "sea_predictor_tail")
+    return probs, scores
+
+
+def _tail_pack(conv_w, conv_b, ln_w, ln_b, dt, device):
+    """The cached re-layout of the tail's constants (one entry shared by predictor_tail / _select / _z and conv_z)."""
+    H, C = conv_w.shape
+    Hpad = (H + 7) // 8 * 8
+
+    def build():
+        cw = torch.zeros((C, Hpad), dtype=torch.float32, device=device)  # transposed, head axis padded: scalar-cache reads
+        cw[:, :H] = conv_w.to(dt).float().t()
+        cb = torch.zeros((Hpad,), dtype=torch.float32, device=device)
+        cb[:H] = conv_b.to(dt).float()
+        w16, Cp = None, 0
+        if dt != torch.float32:                                           # row-major 16-bit copy for the MFMA variant
+            Cp, HP = (C + 31) // 32 * 32, (H + 15) // 16 * 16
+            w16 = torch.zeros((HP, Cp), dtype=dt, device=device)
+            w16[:H, :C] = conv_w.to(dt)
+        return cw, cb, ln_w.to(dt).contiguous(), ln_b.to(dt).contiguous(), w16, Cp
+    return _cached("tail", (conv_w, conv_b, ln_w, ln_b), dt, build)
+
+
+@_lib.device_guarded
+def predictor_tail_z(z: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor,
+                     up: int, T_m: int, dtype: torch.dtype, eps: float = 1e-5, want_scores: bool = False):
+    """predictor_tail from z (N, T, H, W4) fp32 = the 1x1 convolution's output as `causal_conv_c8_z` writes it
+    (`sea_predictor_tail_z`): area resize -> LayerNorm -> softmax; probs (N,H,T,T_m) of `dtype` [, scores]."""
+    lib = _lib.load()
+    _lib.require_gpu(z, conv_w, conv_b, ln_w, ln_b)
+    N, T, H, W4 = z.shape
+    assert z.dtype == torch.float32 and z.is_contiguous() and conv_w.shape[0] == H and W4 * up == T_m
+    assert dtype in (torch.float16, torch.bfloat16)
+    _cw, cb, g, b, _w16, _Cp = _tail_pack(conv_w, conv_b, ln_w, ln_b, dtype, z.device)
+    probs = torch.empty((N, H, T, T_m), dtype=dtype, device=z.device)
+    scores = torch.empty_like(probs) if want_scores else None
+    _lib.check(lib.sea_predictor_tail_z(_p(z), _lib.dtype_code(dtype), N, H, T, W4, up, T_m, _p(cb), _p(g), _p(b), float(eps),
+                                        _p(probs), _p(scores), _lib.stream_ptr()), "sea_predictor_tail_z")
     return probs, scores
 
 
@@ -193,45 +240,48 @@ def predictor_tail_select_supported(y: torch.Tensor, H: int, T_m: int, decode: b
 
 
 @_lib.device_guarded
-def predictor_tail_select(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor,
+def predictor_tail_select(y: Optional[torch.Tensor], conv_w: torch.Tensor, conv_b: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor,
                           up: int, T_m: int, keep: torch.Tensor, k: int, T_src: int, is_causal: bool = True,
                           eps: float = 1e-5, want_scores: bool = False, t_src_dev: Optional[torch.Tensor] = None,
-                          lazy_probs: bool = False, crow_out: Optional[torch.Tensor] = None):
+                          lazy_probs: bool = False, crow_out: Optional[torch.Tensor] = None,
+                          z: Optional[torch.Tensor] = None, map_dtype: Optional[torch.dtype] = None):
     """predictor_tail + grouped top-k selection in one launch.  Returns (probs, scores, (bits, row_nnz, head_off));
     feed the triple to flat_csr.csr_from_selection.  Bit-identical to predictor_tail followed by topk_to_csr.
     `lazy_probs`: the launch does NOT write the (N,H,T,T_m) map (nobody on the hot path reads it); `probs` is then a
-    `LazyTensor` that runs `predictor_tail` on the kept `y` the first time anything touches its values.
+    `LazyTensor` that runs `predictor_tail` on the kept `y` (or `predictor_tail_z` on the kept `z`) the first time anything
+    touches its values -- with the weights as they are AT THAT MOMENT: realize it (`ops.realize`) before editing them.
+    `z` (with `y = None`, `map_dtype`): the 1x1 convolution's output (N, T, H, W4) fp32 from `causal_conv_c8_z`
+    (`sea_predictor_tail_select_z`: the row's z tile is a copy instead of loads + MFMAs).
     Decode form (`sea_predictor_tail_select_at`, a step replayed as a HIP graph): `t_src_dev` is a one-element int32
     device tensor holding the sequence length (T_src is ignored) and `keep` a table over absolute row indices."""
     lib = _lib.load()
-    _lib.require_gpu(y, conv_w, conv_b, ln_w, ln_b, keep)
-    if y.dim() == 5:
-        N, T, C8, W4, _e = y.shape
-        # rows of C8 blocks; the batch and row strides are free (a decode step hands over the last row of a window: no copy)
-        assert _e == 8 and y.stride()[2:] == (W4 * 8, 8, 1) and y.stride(0) % 8 == 0 and y.stride(1) % 8 == 0
-        C = C8 * 8
-    else:
-        N, C, T, W4 = y.shape
     H = conv_w.shape[0]
-    assert conv_w.shape == (H, C) and W4 * up == T_m and predictor_tail_select_supported(y, H, T_m, decode=t_src_dev is not None)
+    if z is not None:
+        assert y is None and t_src_dev is None and map_dtype in (torch.float16, torch.bfloat16)
+        _lib.require_gpu(z, conv_w, conv_b, ln_w, ln_b, keep)
+        N, T, Hz, W4 = z.shape
+        assert Hz == H and z.dtype == torch.float32 and z.is_contiguous() and W4 * up == T_m
+        assert predictor_tail_select_supported(torch.empty((0, 0, 1, 1, 8), dtype=map_dtype), H, T_m)
+        dt, dev = map_dtype, z.device
+    else:
+        _lib.require_gpu(y, conv_w, conv_b, ln_w, ln_b, keep)
+        if y.dim() == 5:
+            N, T, C8, W4, _e = y.shape
+            # rows of C8 blocks; the batch and row strides are free (a decode step hands over the last row of a window: no copy)
+            assert _e == 8 and y.stride()[2:] == (W4 * 8, 8, 1) and y.stride(0) % 8 == 0 and y.stride(1) % 8 == 0
+            C = C8 * 8
+        else:
+            N, C, T, W4 = y.shape
+        assert conv_w.shape == (H, C) and W4 * up == T_m and predictor_tail_select_supported(y, H, T_m, decode=t_src_dev is not None)
+        dt, dev = y.dtype, y.device
     assert keep.dtype == torch.int32 and keep.is_contiguous() and (t_src_dev is not None or keep.shape in ((T,), (N, T)))
-    dt = y.dtype
-    Hpad = (H + 7) // 8 * 8
-
-    def build():   # same cache entry layout as predictor_tail
-        cw = torch.zeros((C, Hpad), dtype=torch.float32, device=y.device)
-        cw[:, :H] = conv_w.to(dt).float().t()
-        cb = torch.zeros((Hpad,), dtype=torch.float32, device=y.device)
-        cb[:H] = conv_b.to(dt).float()
-        Cp, HP = (C + 31) // 32 * 32, (H + 15) // 16 * 16
-        w16 = torch.zeros((HP, Cp), dtype=dt, device=y.device)
-        w16[:H, :C] = conv_w.to(dt)
-        return cw, cb, ln_w.to(dt).contiguous(), ln_b.to(dt).contiguous(), w16, Cp
-    _cw, cb, g, b, w16, Cp = _cached("tail", (conv_w, conv_b, ln_w, ln_b), dt, build)
-    dev = y.device
+    _cw, cb, g, b, w16, Cp = _tail_pack(conv_w, conv_b, ln_w, ln_b, dt, dev)
     if lazy_probs:
         assert t_src_dev is None
-        probs = LazyTensor((N, H, T, T_m), dt, dev, lambda: predictor_tail(y, conv_w, conv_b, ln_w, ln_b, up, T_m, eps)[0])
+        if z is not None:
+            probs = LazyTensor((N, H, T, T_m), dt, dev, lambda: predictor_tail_z(z, conv_w, conv_b, ln_w, ln_b, up, T_m, dt, eps)[0])
+        else:
+            probs = LazyTensor((N, H, T, T_m), dt, dev, lambda: predictor_tail(y, conv_w, conv_b, ln_w, ln_b, up, T_m, eps)[0])
     else:
         probs = torch.empty((N, H, T, T_m), dtype=dt, device=dev)
     scores = torch.empty((N, H, T, T_m), dtype=dt, device=dev) if want_scores else None
@@ -247,6 +297,12 @@ def predictor_tail_select(y: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.T
             _p(y), _lib.dtype_code(dt), N, C, H, T, W4, up, T_m, _lib.strides5_blocked(y), _p(cb), _p(w16), Cp, _p(g), _p(b),
             float(eps), _p(probs), _p(scores), _p(keep), _p(t_src_dev), int(is_causal), int(k),
             _p(bits), _p(row_nnz), _p(head_off), _p(crow_out), _lib.stream_ptr()), "sea_predictor_tail_select_at")
+        return probs, scores, (bits, row_nnz, head_off)
+    if z is not None:
+        _lib.check(lib.sea_predictor_tail_select_z(
+            _p(z), _lib.dtype_code(dt), N, H, T, W4, up, T_m, _p(cb), _p(g), _p(b), float(eps),
+            _p(None if lazy_probs else probs), _p(scores), _p(keep), T if keep.ndim == 2 else 0, T_src, int(is_causal), int(k),
+            _p(bits), _p(row_nnz), _p(head_off), _lib.stream_ptr()), "sea_predictor_tail_select_z")
         return probs, scores, (bits, row_nnz, head_off)
     _lib.check(lib.sea_predictor_tail_select(
         _p(y), _lib.dtype_code(dt), N, C, H, T, W4, up, T_m, _lib.strides5_blocked(y), _p(cb), _p(w16), Cp, _p(g), _p(b),
@@ -527,9 +583,11 @@ def split_layernorm_c8(x: torch.Tensor, splits: int, weight: torch.Tensor, bias:
 
 def pack_conv_weight(weight: torch.Tensor, ksize: int, dtype: torch.dtype):
     """(Cout, Cin, >=ksize, ksize) -> (Cout, ksize*ksize*CinP) laid out [co][tap][ci], ci zero-padded to a multiple
-    of 32.  Only the first `ksize` kernel rows are live for the causal conv (modules.py:113-121)."""
+    of 32 (16-bit kernels: one MFMA k-step) or 16 (the fp32 kernel: four).  Only the first `ksize` kernel rows are live for
+    the causal conv (modules.py:113-121)."""
     Cout, Cin = weight.shape[:2]
-    CinP = (Cin + 31) // 32 * 32
+    pad = 16 if dtype == torch.float32 else 32
+    CinP = (Cin + pad - 1) // pad * pad
     w = weight[:, :, :ksize, :].to(dtype).permute(0, 2, 3, 1)                  # (Cout, k, k, Cin)
     packed = torch.zeros((Cout, ksize, ksize, CinP), dtype=dtype, device=weight.device)
     packed[..., :Cin] = w
@@ -540,7 +598,8 @@ def pack_conv_weight(weight: torch.Tensor, ksize: int, dtype: torch.dtype):
 def causal_conv_c8(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, ksize: int, dilation: int, pad_w: int,
                    relu: bool = True) -> torch.Tensor:
     """Causal (along T) dilated conv + bias (+ReLU) on a C8 activation (N, T, Cin/8, W, 8).
-    `weight` is the module's (Cout, Cin, 2k-1, k) parameter.  Returns (N, T, Cout/8, W, 8)."""
+    `weight` is the module's (Cout, Cin, 2k-1, k) parameter.  Returns (N, T, Cout/8, W, 8).  16-bit data: bf16 / f16 MFMA
+    (`sea_causal_conv_c8`); fp32 data: the fp32 MFMA, exact products (`sea_causal_conv_c8_f32`, `conv_c8_f32_supported`)."""
     lib = _lib.load()
     _lib.require_gpu(x, weight, bias)
     N, T, C8, W, _e = x.shape
@@ -550,10 +609,54 @@ def causal_conv_c8(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, ks
     (wp, CinP), bf = _cached("conv", (weight, bias), x.dtype,
                              lambda: (pack_conv_weight(weight, ksize, x.dtype), bias.to(x.dtype).float().contiguous()))
     y = torch.empty((N, T, Cout // 8, W, 8), dtype=x.dtype, device=x.device)
+    if x.dtype == torch.float32:
+        assert conv_c8_f32_supported(Cin, Cout, ksize)
+        _lib.check(lib.sea_causal_conv_c8_f32(_p(x), N, T, W, Cin, Cout, _p(wp), CinP, _p(bf), int(ksize), int(dilation),
+                                              int(pad_w), int(relu), _p(y), _lib.stream_ptr()), "sea_causal_conv_c8_f32")
+        return y
     _lib.check(lib.sea_causal_conv_c8(_p(x), _lib.dtype_code(x.dtype), N, T, W, Cin, Cout, _p(wp), CinP, _p(bf),
                                       int(ksize), int(dilation), int(pad_w), int(relu), _p(y), _lib.stream_ptr()),
                "sea_causal_conv_c8")
     return y
+
+
+def conv_c8_f32_supported(Cin: int, Cout: int, ksize: int) -> bool:
+    """Shapes `sea_causal_conv_c8_f32` takes: the fp32 weight image must fit the 160 KB LDS (24 -> 24 channels: 37 KB,
+    64 -> 64: 148 KB; 80 -> 80 does not)."""
+    nt, cinp = (Cout + 15) // 16, (Cin + 15) // 16 * 16
+    return (ksize in (1, 3) and Cin % 8 == 0 and Cout % 8 == 0 and Cout <= 80
+            and 16 * nt * (ksize * ksize * cinp * 4 + 4) <= 160 * 1024)
+
+
+def conv_z_supported(Cout: int, H: int, ksize: int, W: int) -> bool:
+    """Shapes `sea_causal_conv_c8_z` takes: a 3 x 3 layer of at most 80 output channels (5 MFMA tiles), H <= 64."""
+    return ksize == 3 and Cout % 8 == 0 and Cout <= 80 and 0 < H <= 64 and W % 4 == 0
+
+
+@_lib.device_guarded
+def causal_conv_c8_z(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor, ksize: int, dilation: int, pad_w: int,
+                     conv1x1_w: torch.Tensor, conv1x1_b: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor,
+                     relu: bool = True, want_y: bool = False):
+    """`causal_conv_c8` of the LAST (conv, ReLU) pair of the predictor CNN with the tail's 1x1 convolution in its epilogue
+    (`sea_causal_conv_c8_z`).  conv1x1_w (H, Cout) = the live row of the 1x1 kernel, conv1x1_b (H); ln_w / ln_b are only the
+    rest of the tail's cache key (one pack serves the conv epilogue and the tail launches).
+    Returns (y or None, z): z (N, T, H, W) fp32 = W1 . relu(conv(x) + bias) + b1 -- bit for bit what the tail kernels compute
+    from y; y (N, T, Cout/8, W, 8) only with `want_y`."""
+    lib = _lib.load()
+    _lib.require_gpu(x, weight, bias, conv1x1_w, conv1x1_b)
+    N, T, C8, W, _e = x.shape
+    assert _e == 8 and x.is_contiguous(), "input must be a dense C8 activation (N, T, Cin/8, W, 8)"
+    Cin, Cout, H = C8 * 8, weight.shape[0], conv1x1_w.shape[0]
+    assert weight.shape[1] == Cin and conv1x1_w.shape == (H, Cout) and conv_z_supported(Cout, H, ksize, W)
+    (wp, CinP), bf = _cached("conv", (weight, bias), x.dtype,
+                             lambda: (pack_conv_weight(weight, ksize, x.dtype), bias.to(x.dtype).float().contiguous()))
+    _cw, cb, _g, _b, w16, Cp = _tail_pack(conv1x1_w, conv1x1_b, ln_w, ln_b, x.dtype, x.device)
+    y = torch.empty((N, T, Cout // 8, W, 8), dtype=x.dtype, device=x.device) if want_y else None
+    z = torch.empty((N, T, H, W), dtype=torch.float32, device=x.device)
+    _lib.check(lib.sea_causal_conv_c8_z(_p(x), _lib.dtype_code(x.dtype), N, T, W, Cin, Cout, _p(wp), CinP, _p(bf),
+                                        int(ksize), int(dilation), int(pad_w), int(relu), _p(y), _p(w16), Cp, _p(cb), H, _p(z),
+                                        _lib.stream_ptr()), "sea_causal_conv_c8_z")
+    return y, z
 
 
 @_lib.device_guarded
@@ -568,7 +671,11 @@ def decode_stage(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_in: torch.
     assert one == 1 and k.shape == q.shape and v.shape == q.shape and q.dtype == k.dtype == v.dtype == q_in.dtype == kv_cache.dtype
     assert q_in.is_contiguous() and tuple(q_in.shape) == (N, H, 1, D) and kv_cache.is_contiguous() and kv_cache.shape[:3] == (2, N, H)
     assert counters.dtype == torch.int32 and counters.numel() == 2 and counters.is_contiguous()
-    q, k, v = (t if t.stride(-1) == 1 else t.contiguous() for t in (q, k, v))
+    # the kernel moves whole 16-byte vectors: rows contiguous along D, [n, h] strides in multiples of 8 elements, 16-byte aligned
+    # base.  Anything else (e.g. rows sliced out of a fused qkv buffer at an odd offset) is repacked here -- the session used
+    # to take any layout through `.copy_`
+    ok = lambda t: t.stride(-1) == 1 and t.stride(0) % 8 == 0 and t.stride(1) % 8 == 0 and t.data_ptr() % 16 == 0
+    q, k, v = (t if ok(t) else t.contiguous() for t in (q, k, v))
     st = lambda t: (ctypes_i64 * 2)(t.stride(0), t.stride(1))
     _lib.check(lib.sea_decode_stage(_p(q), _p(k), _p(v), _lib.dtype_code(q.dtype), N, H, D, st(q), st(k), st(v), _p(q_in),
                                     _p(kv_cache), kv_cache.shape[3], _p(counters), _lib.stream_ptr()), "sea_decode_stage")

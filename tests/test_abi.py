@@ -32,7 +32,7 @@ def test_library_builds_and_exports_everything():
     for name in _declared_symbols():
         assert hasattr(lib, name), f"{name} not exported"
     lib.sea_version.restype = ctypes.c_int
-    assert lib.sea_version() == 2
+    assert lib.sea_version() == 3
     # host-only helper: algorithmic bytes, SURVEY 8d (cfg 3, bf16, Z = 8.32 M -> 2.20 GB)
     lib.sea_sparse_attention_bytes.restype = ctypes.c_int64
     lib.sea_sparse_attention_bytes.argtypes = [ctypes.c_int64] * 5 + [ctypes.c_int]

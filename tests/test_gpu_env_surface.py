@@ -155,13 +155,15 @@ def test_query_skips_declines_the_fused_paths_cleanly_on_bf16(monkeypatch):
     monkeypatch.setenv("QUERY_SKIPS", "2")
     N, H, T, d, T_M, k = 1, 8, 1024, 64, 256, 32
     layer = make_layer(H, d, T_M, k, T, torch.bfloat16)
-    calls = _spy(monkeypatch, ["predictor_mlp", "predictor_tail_select", "predictor_tail", "topk_to_csr", "causal_conv_c8"])
+    calls = _spy(monkeypatch, ["predictor_mlp", "predictor_tail_select", "predictor_tail", "predictor_tail_z", "topk_to_csr",
+                               "causal_conv_c8", "causal_conv_c8_z"])
     S.seed(10)
     x = torch.randn((N, H, T, d), device=DEV).to(torch.bfloat16)
     mask = causal_mask(N, T, torch.bfloat16)
     out_s, _ = run(layer, x * d ** -0.5, x.clone(), x.clone(), mask, True, capture=False)
     assert calls["predictor_mlp"] == 0 and calls["predictor_tail_select"] == 0
-    assert calls["predictor_tail"] == 1 and calls["topk_to_csr"] == 1 and calls["causal_conv_c8"] == 2
+    assert calls["predictor_tail"] + calls["predictor_tail_z"] == 1 and calls["topk_to_csr"] == 1
+    assert calls["causal_conv_c8"] + calls["causal_conv_c8_z"] == 2
     p = out_s.estimated_attention_probs_m
     assert p.shape == (N, H, T, T_M) and torch.equal(p[:, :, 0::2], p[:, :, 1::2])
     out_d, bd = run(layer, x * d ** -0.5, x.clone(), x.clone(), mask, False)

@@ -65,7 +65,8 @@ def test_reference_grid_runs_on_the_fused_kernels(monkeypatch, T, K, T_M, dtype)
                 seen.update(q=a[0], k=a[1], v=a[2], csr=a[3], kw=kw, pending=a[3].col_is_pending)
             return real(*a, **kw)
         monkeypatch.setattr(A.ops, name, f)
-    for nm in ("performer_value", "predictor_mlp", "causal_conv_c8", "predictor_tail_select", "predictor_tail", "topk_to_csr",
+    for nm in ("performer_value", "predictor_mlp", "causal_conv_c8", "causal_conv_c8_z", "predictor_tail_select", "predictor_tail",
+               "predictor_tail_z", "topk_to_csr",
                "split_layernorm", "split_layernorm_c8", "sparse_attention", "cumavg"):
         count(nm)
     # any predictor module that runs its torch forward (library GEMM / MIOpen) is a fallback: none may
@@ -82,9 +83,11 @@ def test_reference_grid_runs_on_the_fused_kernels(monkeypatch, T, K, T_M, dtype)
     for h_ in hooks:
         h_.remove()
     assert ran == [], f"torch predictor modules ran: {ran}"
-    assert calls.get("performer_value") == 1 and calls.get("predictor_mlp") == 1 and calls.get("causal_conv_c8") == 2
+    # two (conv, ReLU) launches (the second one through sea_causal_conv_c8_z when the module's `conv_z_epilogue` is on)
+    assert calls.get("performer_value") == 1 and calls.get("predictor_mlp") == 1
+    assert calls.get("causal_conv_c8", 0) + calls.get("causal_conv_c8_z", 0) == 2
     assert calls.get("predictor_tail_select") == 1 and calls.get("sparse_attention") == 1
-    for nm in ("predictor_tail", "topk_to_csr", "split_layernorm", "split_layernorm_c8", "cumavg"):
+    for nm in ("predictor_tail", "predictor_tail_z", "topk_to_csr", "split_layernorm", "split_layernorm_c8", "cumavg"):
         assert nm not in calls, f"{nm} ran: the fused estimator was declined"
     assert seen["pending"], "the interpolation was not left to the attention launch"
     assert isinstance(out.estimated_attention_probs_m, A.ops.LazyTensor) and not out.estimated_attention_probs_m.is_materialized
@@ -135,4 +138,34 @@ def test_eager_map_switch_writes_the_same_map():
     assert isinstance(a.estimated_attention_probs, A.ops.LazyTensor) and not isinstance(b.estimated_attention_probs, A.ops.LazyTensor)
     assert torch.equal(a.context_layer, b.context_layer)
     assert torch.equal(a.estimated_attention_probs_m, b.estimated_attention_probs_m)
-    assert torch.equal(a.partial_attention_mask.col, b.partial_attention_mask.col)
+    ca, cb = a.partial_attention_mask, b.partial_attention_mask
+    assert torch.equal(ca.crow, cb.crow)
+    for i in range(2):                                   # (entries past a row's last one are capacity, never written)
+        z = int(ca.crow[i, -1])
+        assert torch.equal(ca.col[i, :z], cb.col[i, :z])
+
+
+@pytest.mark.parametrize("H,d,T,T_M,K", [(12, 64, 1024, 256, 64), (32, 64, 512, 256, 64), (12, 64, 512, 96, 32)])
+def test_conv_z_epilogue_switch_changes_no_bit(H, d, T, T_M, K):
+    """`conv_z_epilogue = True` (round 5: the tail's 1x1 convolution evaluated in the last conv launch's epilogue, z handed to
+    the tail instead of the activation) is an optimisation that measured slower and stays off by default; on, the layer's
+    outputs -- context, map, CSR -- are bit for bit the default's."""
+    dtype = torch.bfloat16
+    layer = build_layer(H, d, T, T_M, K, dtype)
+    S.seed(13)
+    x = torch.randn((2, H, T, d), device=DEV)
+    q, k, v = (x * d ** -0.5).to(dtype), torch.randn_like(x).to(dtype), torch.randn_like(x).to(dtype)
+    fp_min = torch.finfo(torch.float16).min / 2
+    mask = ((torch.arange(T, device=DEV).view(1, T) > torch.arange(T, device=DEV).view(T, 1)) * fp_min).view(1, 1, T, T).to(dtype).expand(2, 1, T, T)
+    assert layer.attention.conv_z_epilogue is False
+    with torch.no_grad():
+        a = layer(None, None, None, query_layer=q, key_layer=k, value_layer=v, attention_mask=mask)
+        layer.attention.conv_z_epilogue = True
+        b = layer(None, None, None, query_layer=q, key_layer=k, value_layer=v, attention_mask=mask)
+    assert torch.equal(a.context_layer, b.context_layer)
+    assert torch.equal(a.estimated_attention_probs_m, b.estimated_attention_probs_m)
+    ca, cb = a.partial_attention_mask, b.partial_attention_mask
+    assert torch.equal(ca.crow, cb.crow)
+    for i in range(2):
+        z = int(ca.crow[i, -1])
+        assert torch.equal(ca.col[i, :z], cb.col[i, :z])

@@ -210,6 +210,38 @@ def test_causal_conv_c8(ops, dtype, N, Cin, Cout, T, W, dil):
     torch.testing.assert_close(ops.from_c8(y).float().cpu(), ref1, atol=2e-2, rtol=2e-2)
 
 
+@pytest.mark.parametrize("dil", [2, 1, 3])
+@pytest.mark.parametrize("N,Cin,Cout,T,W", [(2, 24, 24, 40, 64), (1, 64, 64, 21, 64), (1, 24, 24, 33, 16), (1, 32, 48, 17, 128),
+                                            (1, 16, 32, 12, 40), (1, 24, 24, 9, 96), (1, 8, 8, 7, 24), (1, 40, 40, 13, 64)])
+def test_causal_conv_c8_fp32(ops, N, Cin, Cout, T, W, dil):
+    """`sea_causal_conv_c8_f32` (round 5): fp32 data on the fp32 MFMA -- exact fp32 products, so the bar is fp32 rounding noise
+    (the 16-bit kernels' 2e-2 becomes 1e-5), tap positions and causality as for the 16-bit kernel."""
+    assert ops.conv_c8_f32_supported(Cin, Cout, 3) and not ops.conv_c8_f32_supported(80, 80, 3)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((N, Cin, T, W), generator=g)
+    wt = torch.randn((Cout, Cin, 5, 3), generator=g) * (Cin * 9) ** -0.5
+    b = torch.randn(Cout, generator=g) * 0.1
+    for relu in (True, False):
+        ref = _causal_conv_ref(x.double(), wt.double(), b.double(), 3, dil, dil, relu) if False else \
+            torch.nn.functional.conv2d(torch.nn.functional.pad(x.double(), (0, 0, 2 * dil, 0)), wt[:, :, :3, :].double(), b.double(), 1, (0, dil), dil)
+        ref = torch.relu(ref) if relu else ref
+        y = ops.causal_conv_c8(ops.to_c8(x.to(DEV)), wt.to(DEV), b.to(DEV), 3, dil, dil, relu=relu)
+        assert y.dtype == torch.float32 and tuple(y.shape) == (N, T, Cout // 8, W, 8) and y.is_contiguous()
+        torch.testing.assert_close(ops.from_c8(y).double().cpu(), ref, atol=1e-5, rtol=1e-5)
+    xo = torch.zeros_like(x); xo[0, Cin // 2, T // 2, W // 3] = 1.0; xo[0, 0, T - 1, 0] = 1.0; xo[0, Cin - 1, 0, W - 1] = -2.0
+    ref = _causal_conv_ref(xo, wt, b, 3, dil, dil, False)
+    y = ops.from_c8(ops.causal_conv_c8(ops.to_c8(xo.to(DEV)), wt.to(DEV), b.to(DEV), 3, dil, dil, relu=False)).cpu()
+    torch.testing.assert_close(y, ref, atol=1e-6, rtol=1e-6)                      # one weight (+ bias) per lit output pixel
+    assert torch.equal(y == b.view(1, -1, 1, 1), ref == b.view(1, -1, 1, 1))      # and the same pixels stay at the bare bias
+    x2 = x.clone(); x2[:, :, T // 2:] += 50                                       # causality along T
+    y1 = ops.causal_conv_c8(ops.to_c8(x.to(DEV)), wt.to(DEV), b.to(DEV), 3, dil, dil)
+    y2 = ops.causal_conv_c8(ops.to_c8(x2.to(DEV)), wt.to(DEV), b.to(DEV), 3, dil, dil)
+    assert torch.equal(y1[:, :T // 2], y2[:, :T // 2])
+    w1 = torch.randn((Cout, Cin, 1, 1), generator=g) * Cin ** -0.5
+    y = ops.causal_conv_c8(ops.to_c8(x.to(DEV)), w1.to(DEV), b.to(DEV), 1, 1, 0, relu=False)
+    torch.testing.assert_close(ops.from_c8(y).cpu(), torch.nn.functional.conv2d(x, w1, b), atol=1e-5, rtol=1e-5)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,C,T,S,W", [(2, 12, 40, 2, 16), (1, 32, 70, 2, 64), (1, 40, 9, 2, 64), (1, 4, 5, 2, 128),
                                        (1, 12, 21, 2, 24), (1, 12, 13, 2, 96), (1, 4, 7, 2, 40)])    # lanes per row not a power of two
@@ -390,6 +422,48 @@ def test_predictor_tail_select_bit_identical(ops, dtype, N, H, T, k, T_M):
     c5, _ = ops.topk_to_csr(p5, keep, k, target_width=T)
     assert torch.equal(p4, p5) and p4.float().unique().numel() < 64
     assert torch.equal(c4.bits, c5.bits) and torch.equal(c4.crow, c5.crow)
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("N,H,T,k,T_M", [(2, 32, 150, 64, 256), (1, 12, 133, 16, 256), (1, 40, 100, 64, 256), (1, 4, 40, 8, 256),
+                                         (1, 20, 50, 16, 256), (1, 12, 90, 32, 96), (1, 12, 70, 32, 384), (1, 32, 40, 64, 128),
+                                         (1, 36, 30, 32, 256)])
+def test_conv_z_epilogue_bit_identical(ops, dtype, N, H, T, k, T_M):
+    """`sea_causal_conv_c8_z` (round 5): the last (conv, ReLU) launch with the tail's 1x1 convolution in its epilogue.  Its
+    activation is bitwise `causal_conv_c8`'s, z is what the tail's own z stage computes from that activation (checked through
+    the maps: tail(z) == tail(y) bit for bit, tail + selection likewise) and equals the fp32 product of the rounded operands."""
+    C, W4 = 2 * H, T_M // 4
+    if C % 8:
+        pytest.skip("C8 needs whole blocks of 8 channels")
+    assert ops.conv_z_supported(C, H, 3, W4)
+    g = torch.Generator().manual_seed(21)
+    x = ops.to_c8(torch.randn((N, C, T, W4), generator=g).to(dtype).to(DEV))
+    w = (torch.randn((C, C, 5, 3), generator=g) * (9 * C) ** -0.5).to(dtype).to(DEV)
+    b = (torch.randn(C, generator=g) * 0.1).to(dtype).to(DEV)
+    cw = (torch.randn((H, C), generator=g) * C ** -0.5).to(dtype).to(DEV)
+    cb = (torch.randn(H, generator=g) * 0.1).to(dtype).to(DEV)
+    lw = (torch.rand(T_M, generator=g) + 0.5).to(dtype).to(DEV)
+    lb = (torch.randn(T_M, generator=g) * 0.1).to(dtype).to(DEV)
+    y0 = ops.causal_conv_c8(x, w, b, 3, 2, 2, relu=True)
+    y1, z = ops.causal_conv_c8_z(x, w, b, 3, 2, 2, cw, cb, lw, lb, relu=True, want_y=True)
+    yn, z2 = ops.causal_conv_c8_z(x, w, b, 3, 2, 2, cw, cb, lw, lb, relu=True)
+    assert yn is None and torch.equal(z, z2) and torch.equal(y0, y1)
+    assert z.shape == (N, T, H, W4) and z.dtype == torch.float32
+    ref = torch.einsum("hc,nctw->nthw", cw.float(), ops.from_c8(y0).float()) + cb.float().view(1, 1, H, 1)
+    assert (z - ref).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+    p0, s0 = ops.predictor_tail(y0, cw, cb, lw, lb, up=4, T_m=T_M, want_scores=True)
+    p1, s1 = ops.predictor_tail_z(z, cw, cb, lw, lb, up=4, T_m=T_M, dtype=dtype, want_scores=True)
+    assert torch.equal(p0, p1) and torch.equal(s0, s1)
+    if ops.predictor_tail_select_supported(y0, H, T_M):
+        keep = ops.keep_table_causal(H, T, T_M, k, device=DEV)
+        pa, _, sa = ops.predictor_tail_select(y0, cw, cb, lw, lb, up=4, T_m=T_M, keep=keep, k=k, T_src=T)
+        pb, _, sb = ops.predictor_tail_select(None, cw, cb, lw, lb, up=4, T_m=T_M, keep=keep, k=k, T_src=T, z=z, map_dtype=dtype)
+        pl, _, sl = ops.predictor_tail_select(None, cw, cb, lw, lb, up=4, T_m=T_M, keep=keep, k=k, T_src=T, z=z, map_dtype=dtype,
+                                              lazy_probs=True)
+        assert torch.equal(pa, p0) and torch.equal(pb, p0)
+        for u, v_, w_ in zip(sa, sb, sl):
+            assert torch.equal(u, v_) and torch.equal(u, w_)
+        assert isinstance(pl, ops.LazyTensor) and not pl.is_materialized and torch.equal(pl, p0)
 
 
 @pytest.mark.parametrize("D", [64, 80, 128])

@@ -398,6 +398,31 @@ def test_lazy_tensor_computes_once_and_only_when_touched():
     assert ops.realize(x) is x
 
 
+def test_lazy_tensor_serves_c_level_consumers():
+    """a wrapper subclass has no storage -- `data_ptr()` must not hand 0 to the C ABI (an optional pointer would be
+    skipped silently), and numpy / pickling / deepcopy must see the real values."""
+    import copy
+    import io
+    import pickle
+    from sea_attention_amd import _lib
+    from sea_attention_amd.perlin_attention.ops import predictor as PR, flat_csr as FC
+    mk = lambda: ops.LazyTensor((2, 3), torch.float32, torch.device("cpu"), lambda: torch.arange(6.0).view(2, 3))
+    t = mk()
+    assert not t.is_materialized and t.data_ptr() != 0 and t.is_materialized and t.data_ptr() == t.materialize().data_ptr()
+    assert PR._p(mk()).value and FC._p(mk()).value
+    assert mk().numpy().sum() == 15.0 and mk().tolist() == [[0.0, 1.0, 2.0], [3.0, 4.0, 5.0]]
+    assert torch.equal(copy.deepcopy(mk()), torch.arange(6.0).view(2, 3))
+    assert torch.equal(pickle.loads(pickle.dumps(mk())), torch.arange(6.0).view(2, 3))
+    buf = io.BytesIO()
+    torch.save(mk(), buf)
+    buf.seek(0)
+    assert torch.equal(torch.load(buf), torch.arange(6.0).view(2, 3))
+    u = mk()
+    with pytest.raises(RuntimeError, match="no CPU fallback"):      # the device check looks at the REAL tensor
+        _lib.require_gpu(u)
+    assert u.is_materialized
+
+
 def test_fused_estimator_predicates_cover_the_reference_grid():
     y16 = torch.empty((1, 1, 1, 1, 8), dtype=torch.bfloat16)
     # src/main/benchmark_opt_ablation.py:160-186 (w in 64 / 128 / 256 / 384 at H = 12) and exp_long_context.py:152 (T_M = 96)
@@ -414,7 +439,15 @@ def test_fused_estimator_predicates_cover_the_reference_grid():
     layer = make_layer(H=12, d=64, T_M=96, k=16, max_pos=64)
     body = list(layer.attention.attention_predictor_cnn[1].module.net.children())
     assert layer.attention._c8_cnn_ok(torch.empty(1, dtype=torch.bfloat16), body)       # W = 24: no power-of-two requirement
-    assert not layer.attention._c8_cnn_ok(torch.empty(1, dtype=torch.float32), body)
+    assert layer.attention._c8_cnn_ok(torch.empty(1, dtype=torch.float32), body)        # round 5: fp32 data on the fp32-MFMA conv
+    assert not layer.attention._c8_cnn_ok(torch.empty(1, dtype=torch.float64), body)
+    assert ops.conv_c8_f32_supported(24, 24, 3) and ops.conv_c8_f32_supported(64, 64, 3) and not ops.conv_c8_f32_supported(80, 80, 3)
+    # a shape the hand-written kernels decline is declined LOUDLY (once): the layer still runs, on the framework's convolutions
+    big = make_layer(H=40, d=128, T_M=256, k=16, max_pos=64)
+    body40 = list(big.attention.attention_predictor_cnn[1].module.net.children())
+    assert big.attention._c8_cnn_ok(torch.empty(1, dtype=torch.bfloat16), body40)
+    with pytest.warns(UserWarning, match="does not fit the 160 KB LDS"):
+        assert not big.attention._c8_cnn_ok(torch.empty(1, dtype=torch.float32), body40)
 
 
 def test_flat_csr_items_share_storage_and_pending_state():
