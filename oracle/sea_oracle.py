@@ -14,6 +14,16 @@ restate parts of `PerlinAttention.forward` which cannot be imported from the
 reference here (module-level top-k, mix epilogue) say so in their docstring;
 they are pinned only by their equivalence to the pinned pieces.
 
+Not restated here, and how each is pinned instead:
+  * predictor CNN (steps E-F): the reference's own `PA/modules.py` classes, run in place -> tests/golden/estimator.npz;
+  * the callers (`OPTAttention`, `OPTDecoderLayer`, `benchmark_bert.exam`'s surgery): the reference's own
+    `src/models/perlin_opt/perlin_opt.py`, run in place ON THIS PACKAGE -> tests/golden/callers.npz;
+  * the causal Performer (step B, third-party `performer-pytorch==1.1.4`, absent from the tree): HALF pinned.  The prefix
+    sums / eps placement / denominator are pinned to the reference's own restatement of that arithmetic
+    (`StatefulCausalPerformer`, PA/attention_state.py:43-122, run in place -> tests/golden/performer.npz).  The FEATURE MAP
+    `phi(x) = relu(d^-1/4 x W^T) + 1e-3` (`generalized_kernel`) is PARITY UNPINNED: no code under /root/reference evaluates
+    it (the reference's stateful path takes features as given, :84-98), so it follows the package's published formula only.
+
 Citations are `path:line` under the reference root; shorthand
   PA/ = src/models/perlin_attention/      K/ = PA/ops/kernels/
 
