@@ -36,7 +36,7 @@ extern "C" {
  *      state image at that boundary;  round 4: sea_predictor_mlp's w2_packed / vectors pad every decoder half to whole
  *      16-row tiles (identical for Wd % 16 == 0), sea_predictor_tail_select accepts probs = NULL and any T_m % 4 == 0 <= 512
  *   3  round 5: new entry points the binding requires (sea_causal_conv_c8_z, sea_predictor_tail_z, sea_predictor_tail_select_z,
- *      sea_causal_conv_c8_f32);
+ *      sea_causal_conv_c8_f32, sea_decode_cnn_tail_select);
  *      no existing signature changed */
 #define SEA_ABI_VERSION 3
 
@@ -339,6 +339,34 @@ int sea_predictor_tail_select_z(const float* z, int dtype, int64_t N, int64_t H,
                                 void* probs, void* scores, const int32_t* keep, int64_t keep_stride_n, int64_t T_src,
                                 int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz, int32_t* head_off,
                                 sea_stream_t stream);
+
+/* A decoding step's predictor CNN + tail + selection + state advance in ONE launch (round 5; perlin_attention/decode.py).
+ * A graph-replayed position used to run conv1, conv2 (each over the session's whole 25-row window), sea_predictor_tail_select_at
+ * and sea_c8_window_shift: four launches for one new row per sequence, each at its fixed cost.  Here one workgroup per sequence
+ *   - computes conv1's new row from x rows t - 2 dil, t - dil (ring of the MLP's earlier rows) and t (`x_new`, which the MLP
+ *     launch has just written), conv2's new row from the ring of conv1's rows -- bit for bit the rows sea_causal_conv_c8 writes
+ *     (same operand placement and k order; weights read straight from the packed images, w1_packed / w2_packed / bias as for
+ *     sea_causal_conv_c8 with Cin = Cout = C, 3 x 3, `dilation`, pad_w = dilation);
+ *   - runs the tail + selection of sea_predictor_tail_select_at on that row (T_m = 256, W4 = 64, up = 4; keep_table over
+ *     absolute rows; outputs bits (N,1,W), row_nnz (N,1), head_off (N,1,H+1), crow_out (N,2), optional probs (N,H,1,256));
+ *   - files x_new and conv1's new row in their rings (slot = position % ring size: nothing is shifted) and, as the last
+ *     workgroup to finish, advances counters = {rows seen (the new row's position), T_src of the step, T_src of the step JUST
+ *     FINISHED}: counters[2] = counters[1], then counters[0] += 1, counters[1] += 1.  Launches behind this one in the same
+ *     step (sea_csr_emit_at) read their T_src from counters + 2.  `ticket` is one zero-initialised int32 the library owns
+ *     between calls.
+ * `col` (optional, C <= 64): the step's CSR columns (N, col_stride_n) int32, ids = head * T_cap + key as sea_csr_emit_at writes
+ *   them, at most z_cap per item -- the emit of the one new row runs inside this launch too (one launch less per position);
+ *   NULL = the caller runs sea_csr_emit_at.
+ * x_new (N, C/8, 64, 8); x_ring (N, ring_x, C/8, 64, 8); y1_ring (N, ring_y, C/8, 64, 8); y2 (N, C/8, 64, 8) scratch, all `dtype`
+ * (16-bit); ring sizes > 2 * dilation.  C = 2 H <= 80, H % 4 == 0. */
+int sea_decode_cnn_tail_select(const void* x_new, void* x_ring, void* y1_ring, void* y2, int dtype, int64_t N, int64_t C,
+                               int64_t H, int64_t W4, int64_t ring_x, int64_t ring_y, const void* w1_packed,
+                               const float* bias1, const void* w2_packed, const float* bias2, int64_t CinP, int dilation,
+                               int pad_w, const void* conv_b, const void* conv_w16, int64_t Cp, const void* gamma,
+                               const void* beta, float eps, void* probs, const int32_t* keep_table, int32_t* counters,
+                               int32_t* ticket, int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz,
+                               int32_t* head_off, int32_t* crow_out, int32_t* col, int64_t col_stride_n, int64_t z_cap,
+                               int64_t T_cap, sea_stream_t stream);
 
 /* Causal cumulative average out[n,h,t,:] = sum_{s<=t} v[n,h,s,:] / (t+1), fp32 accumulation.
  * Replaces `avg_v.cumsum(-2) / arange(1..T)` (attention.py:1220-1222).  out (N,H,T,D) contiguous. */

@@ -15,6 +15,7 @@ LIB_PATH = os.path.join(PKG_DIR, "libsea_hip.so")
 SOURCES = ["sea_topk.hip", "sea_attn.hip", "sea_attn_tile.hip", "sea_attn_bwd.hip", "sea_csr_ops.hip", "sea_predictor.hip",
            "sea_performer.hip", "sea_conv.hip", "sea_mlp.hip", "sea_decode.hip"]
 HEADERS = [os.path.join(CSRC, "sea_common.hpp"), os.path.join(CSRC, "sea_attn.hpp"), os.path.join(CSRC, "sea_tail.hpp"),
+           os.path.join(CSRC, "sea_convfrag.hpp"),
            os.path.join(os.path.dirname(PKG_DIR), "include", "sea_hip.h")]
 # -fno-slp-vectorize: the SLP pass packs adjacent scalar f32 adds/muls into v_pk_* pairs plus the v_mov traffic
 # to form the register pairs; on gfx950 that is a net loss in these VALU-issue-bound kernels (A/B: -1.5 % step)

@@ -56,6 +56,9 @@ _SIGNATURES = {
                            ctypes.c_float, ptr, i64, ptr, ptr, ptr, ptr], c_int),
     "sea_split_layernorm_c8": ([ptr, c_int, i64, i64, i64, i64, i64, ptr, ptr, ctypes.c_float, ptr, ptr], c_int),
     "sea_causal_conv_c8": ([ptr, c_int, i64, i64, i64, i64, i64, ptr, i64, ptr, c_int, c_int, c_int, c_int, ptr, ptr], c_int),
+    "sea_decode_cnn_tail_select": ([ptr, ptr, ptr, ptr, c_int, i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ptr, i64, c_int, c_int,
+                                    ptr, ptr, i64, ptr, ptr, ctypes.c_float, ptr, ptr, ptr, ptr, c_int, c_int, ptr, ptr, ptr, ptr,
+                                    ptr, i64, i64, i64, ptr], c_int),
     "sea_causal_conv_c8_f32": ([ptr, i64, i64, i64, i64, i64, ptr, i64, ptr, c_int, c_int, c_int, c_int, ptr, ptr], c_int),
     "sea_causal_conv_c8_z": ([ptr, c_int, i64, i64, i64, i64, i64, ptr, i64, ptr, c_int, c_int, c_int, c_int, ptr,
                               ptr, i64, ptr, i64, ptr, ptr], c_int),

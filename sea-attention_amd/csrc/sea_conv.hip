@@ -18,25 +18,9 @@
 // causal_conv_c8_kernel: implicit GEMM, M = C_out, N = pixels, K = taps x C_in, v_mfma_f32_16x16x32.
 //   one wave = 64 consecutive pixels of one (n, t) row  x  all C_out   (NT M-tiles x 4 N-tiles)
 #include "sea_common.hpp"
+#include "sea_convfrag.hpp"
 
 namespace sea {
-
-typedef __attribute__((ext_vector_type(4))) float cf4;
-typedef __attribute__((ext_vector_type(8))) __bf16 bf8;
-typedef __attribute__((ext_vector_type(8))) _Float16 h8;
-typedef __attribute__((ext_vector_type(4))) unsigned int cu4;
-
-template <typename T> struct Mfma16;
-template <> struct Mfma16<__hip_bfloat16> {
-  __device__ static inline cf4 run(const uint4& a, const cu4& b, cf4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf8, a), __builtin_bit_cast(bf8, b), c, 0, 0, 0);
-  }
-};
-template <> struct Mfma16<__half> {
-  __device__ static inline cf4 run(const uint4& a, const cu4& b, cf4 c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), c, 0, 0, 0);
-  }
-};
 
 struct ConvParams {
   const void* x;    // (N, T, Cin/8, W, 8)   C8
@@ -69,9 +53,6 @@ struct ConvParams {
 // channel block is K padding) carries an offset beyond num_records and the hardware returns zeros, so the k-loop
 // is branch-free and the next step's loads are in flight under the current step's MFMAs.
 constexpr int CONV_WAVES = 6;
-template <int NT> __device__ __forceinline__ constexpr int conv_chan(int nt, int g) {
-  return nt < (NT & ~1) ? (nt >> 1) * 32 + g * 8 + (nt & 1) * 4 : (NT - 1) * 16 + g * 4;
-}
 constexpr unsigned CONV_OOB = 0x7FFFFF00u;       // > any valid byte offset (launcher checks the image is < 1 GiB)
 
 // ONESEG: W <= 64, every row is one segment: the tap-validity tests and lane offsets are then kernel invariants.

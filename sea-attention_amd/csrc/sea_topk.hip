@@ -16,6 +16,7 @@
 // Everything here is HBM-bound integer/compare work; LDS holds the score histogram only.
 #include "sea_common.hpp"
 #include "sea_tail.hpp"
+#include "sea_convfrag.hpp"
 
 
 #ifdef SEA_STAMP
@@ -592,6 +593,58 @@ __global__ __launch_bounds__(TK_THREADS) void topk_select_kernel(TopkParams p) {
 // moved into the dead z tile so that six workgroups' LDS fits) 412 us; with two 16-bit keys per register and the ragged form
 // (78 registers uncapped) capped at 72 (4 spills), 7 waves: 399 us.  64 registers: 40 spills, 574 us.  H <= 16: 76 -> 72,
 // 6 -> 7 waves, -5 %.  H = 40: 97-108 -> 90-96, 4 -> 5 waves, -7 %.
+// (the body of predictor_tail_select_kernel below as a device function, for the fused decode kernel.  The prefill kernel keeps
+// its own copy on purpose: routed through this function hipcc allocates it differently -- 9 spilled vector registers
+// instead of 3 at its 72-register cap, H = 32 -- and that kernel is 17 % of the headline step.)
+template <typename T, int EPT, bool FULL>
+__device__ __forceinline__ void tail_select_row(const TailParams& tp, const TopkParams& p, float* s_z, int row) {
+  constexpr int R = EPT / 4, E = 4;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n = row / tp.T, t = row - n * tp.T;
+  constexpr int LDZ = 64 + 3;      // = W4 + 3 (sea_predictor_tail_select checks W4 == 64): z-row offsets become immediates
+#ifdef SEA_STAMP
+  unsigned long long _tprev = __builtin_amdgcn_s_memtime();
+#endif
+  uint32_t* s_tab = reinterpret_cast<uint32_t*>(s_z + ((tp.H + 15) / 16) * 16 * LDZ);   // per-pixel constants [3][64 E]
+  tail_z_tile<T>(tp, s_z, n, t);
+  tail_consts_fill<T>(tp, s_tab, 64 * E);
+  __syncthreads();
+  TailRow<T, E> tr;
+  tr.load(s_tab, lane);
+  STAMP(8);   // z tile (MFMA) + per-pixel constants
+  uint32_t key[EPT / 2];                                           // two 16-bit keys per register (select_body, K16)
+  const int mine = FULL ? R : max(0, (tp.H - wv + 3) / 4);         // heads wv, wv + 4, ... of this wave (wave-uniform)
+  auto batch = [&](auto j0c, auto nbc) {                           // heads 4 (J0 + b) + wv, b < NBC, through one batch
+    constexpr int J0 = decltype(j0c)::value, NBC = decltype(nbc)::value;
+    float a[NBC][E];
+    const int nb = min(NBC, mine - J0);
+    if (nb > 0) {
+      // T_M == 256 == 64 E here (sea_predictor_tail_select checks): the full-row form, without its ragged twin in the kernel
+      tr.template heads_impl<true>(tp, lane, nb, [&](int b) { return s_z + (4 * (J0 + b) + wv) * LDZ; },
+                                   [&](int b) { return (((int64_t)n * tp.H + (4 * (J0 + b) + wv)) * tp.T + t) * (64 * E); }, a);
+    }
+#pragma unroll
+    for (int b = 0; b < NBC; ++b) {  // probabilities are >= +0: the 16-bit pattern the map stores orders like the number
+      key[2 * (J0 + b)] = (b < nb) ? pack2<T>(a[b][0], a[b][1]) : 0u;
+      key[2 * (J0 + b) + 1] = (b < nb) ? pack2<T>(a[b][2], a[b][3]) : 0u;
+    }
+  };
+  static_assert(R <= 16, "two batches of eight heads per wave");
+  if constexpr (R <= 8) {
+    batch(std::integral_constant<int, 0>{}, std::integral_constant<int, R>{});
+  } else {
+    batch(std::integral_constant<int, 0>{}, std::integral_constant<int, 8>{});
+    batch(std::integral_constant<int, 8>{}, std::integral_constant<int, R - 8>{});
+  }
+  STAMP(9);   // 8 heads per wave: resize + LayerNorm + softmax + store
+  // H <= 64: sea_predictor_tail_select checks.  The z tile and the constants table are dead once every wave has left the head
+  // loop, i.e. from select_body's first barrier on: the candidate list lives there (the launcher sizes the dynamic LDS for both).
+  // The packed-key selection never re-reads the map (its slow path works on the registers too): tp.probs may be null.
+  select_body<T, EPT, false, FULL, 64, true, true>(p, key, 0ull, n, t, row, (const T*)nullptr, reinterpret_cast<uint32_t*>(s_z));
+}
+
 template <typename T, int EPT, bool FULL>
 __global__ __launch_bounds__(TK_THREADS, EPT <= 16 ? 7 : EPT == 32 ? 7 : EPT == 40 ? 5 : 1) void predictor_tail_select_kernel(TailParams tp, TopkParams p) {
   constexpr int R = EPT / 4, E = 4;
@@ -746,12 +799,11 @@ constexpr int EM_TABLE = 1024;                        // pixel-bound table (T_m 
 constexpr int EM_WIN = 4096;                          // entries staged per flush
 
 template <typename I>
-__global__ __launch_bounds__(TK_THREADS) void csr_emit_kernel(EmitParams p) {
+__device__ __forceinline__ void csr_emit_row(const EmitParams& p, const int row) {
   __shared__ int s_wave[TK_WAVES];
   __shared__ int s_bound[EM_TABLE + 1];
   __shared__ int s_out[EM_WIN];
   const int tid = threadIdx.x;
-  const int row = blockIdx.x;
   const int n = row / p.T_dst, t = row - n * p.T_dst;
   const I* crow = reinterpret_cast<const I*>(p.crow) + (int64_t)n * (p.T_dst + 1);
   const int64_t row_beg = (int64_t)crow[t];
@@ -889,6 +941,89 @@ __global__ __launch_bounds__(TK_THREADS) void csr_emit_kernel(EmitParams p) {
       __syncthreads();
     }
     carry += total;
+  }
+}
+
+template <typename I>
+__global__ __launch_bounds__(TK_THREADS) void csr_emit_kernel(EmitParams p) {
+  csr_emit_row<I>(p, (int)blockIdx.x);
+}
+
+// ---- a decoding step's predictor CNN + tail + selection in ONE launch (round 5) ------------------------------------------------
+// A position of a graph-replayed DecodeSession ran conv1, conv2 (each over the whole 25-row window: 10 - 12 us, all of it the
+// launch and the 74 KB weight image staged into LDS to convolve rows nobody reads), tail + selection (13 us) and the window
+// shift (4 us) as four launches for ONE new row per sequence.  Here one 4-wave workgroup per sequence
+//   * computes the new row of conv1 from the rows t - 2 dil, t - dil (a ring of the MLP's previous outputs) and t (the row
+//     the MLP launch has just written), and the new row of conv2 from a ring of conv1's previous rows -- conv_row_c8, bit for
+//     bit the rows causal_conv_c8_kernel writes;
+//   * runs tail_select_row on that row, unchanged;
+//   * files the two new rows in their rings (no window to shift) and, as the LAST workgroup to finish (ticket), advances the
+//     session's device counters -- what the shift launch did.
+struct DecodeCnnParams {
+  const void* x_new;      // (N, C/8, W, 8): the MLP's output row of this position
+  void* x_ring;           // (N, RX, C/8, W, 8): rows of earlier positions, row of position p in slot p % RX
+  void* y1_ring;          // (N, RY, C/8, W, 8): conv1's rows, slot p % RY
+  void* y2;               // (N, C/8, W, 8): conv2's new row (the tail's input)
+  const void *w1, *w2;    // packed (C, 9 * CinP)
+  const float *b1, *b2;   // (C)
+  int32_t* counters;      // [seen, tsrc, tsrc of the step just finished]
+  int32_t* ticket;
+  int C, W, RX, RY, dil, pad_w;
+};
+
+// EMIT: the selection's one CSR row is expanded into its column ids here too (csr_emit_row: the sea_csr_emit_at launch that
+// followed); instantiated wherever the emit's 20 KB of LDS fit beside the weight image (all but the 80-channel form).
+template <typename T, int EPT, int NT, int KCH, bool EMIT>
+__global__ __launch_bounds__(TK_THREADS) void decode_cnn_tail_select_kernel(DecodeCnnParams dp, TailParams tp, TopkParams p, EmitParams ep) {
+  extern __shared__ __attribute__((aligned(16))) float s_z[];
+  const int n = (int)blockIdx.x;
+  const int pos = dp.counters[0];                                  // rows the session has seen = index of the new position
+  const int64_t row = (int64_t)dp.C * dp.W;                        // elements per C8 row
+  const T* xn = reinterpret_cast<const T*>(dp.x_new) + n * row;
+  T* xr = reinterpret_cast<T*>(dp.x_ring) + (int64_t)n * dp.RX * row;
+  T* yr = reinterpret_cast<T*>(dp.y1_ring) + (int64_t)n * dp.RY * row;
+  T* y2 = reinterpret_cast<T*>(dp.y2) + n * row;
+  auto slot = [](int p_, int r_) { return ((p_ % r_) + r_) % r_; };
+  T* y1_new = yr + slot(pos, dp.RY) * row;
+  T* sW = reinterpret_cast<T*>(s_z);                               // the weight image lives where the tail's z tile will (dead until then)
+  ConvRowC8<T, NT, KCH> c1, c2;
+  c1.fetch_row(0, xr + slot(pos - 2 * dp.dil, dp.RX) * row, dp.C, dp.W, dp.dil, dp.pad_w);
+  c1.fetch_row(1, xr + slot(pos - dp.dil, dp.RX) * row, dp.C, dp.W, dp.dil, dp.pad_w);
+  c1.fetch_row(2, xn, dp.C, dp.W, dp.dil, dp.pad_w);
+  c1.load_weights(reinterpret_cast<const T*>(dp.w1), dp.C);
+  c2.fetch_row(0, yr + slot(pos - 2 * dp.dil, dp.RY) * row, dp.C, dp.W, dp.dil, dp.pad_w);      // (conv1's rows of earlier positions)
+  c2.fetch_row(1, yr + slot(pos - dp.dil, dp.RY) * row, dp.C, dp.W, dp.dil, dp.pad_w);
+  c1.store_weights(sW);
+  c2.load_weights(reinterpret_cast<const T*>(dp.w2), dp.C);       // in flight while conv1's row is computed
+  c1.run(sW, dp.b1, y1_new, dp.C, dp.W, 1);
+  c2.fetch_row(2, y1_new, dp.C, dp.W, dp.dil, dp.pad_w);           // (stored above, barrier passed)
+  c2.store_weights(sW);
+  c2.run(sW, dp.b2, y2, dp.C, dp.W, 1);
+  {                                                                // the MLP's row joins the ring (read by the next positions)
+    const uint4* src = reinterpret_cast<const uint4*>(xn);
+    uint4* dst = reinterpret_cast<uint4*>(xr + slot(pos, dp.RX) * row);
+    for (int i = threadIdx.x; i < (int)(row / 8); i += TK_THREADS) dst[i] = src[i];
+  }
+  __syncthreads();
+  tail_select_row<T, EPT, false>(tp, p, s_z, n);                   // T = 1: row n of the call is batch item n
+  __syncthreads();
+  if constexpr (EMIT) {
+    if (ep.col != nullptr) {                                        // (grid-uniform)
+      csr_emit_row<int32_t>(ep, n);                                 // reads the bits / crow this workgroup has just written
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == 0) {
+    __threadfence();
+    const int done = atomicAdd(dp.ticket, 1);
+    if (done == (int)gridDim.x - 1) {                              // every workgroup has read the counters and finished
+      const int ts = dp.counters[1];
+      dp.counters[2] = ts;                                         // (the emit launch behind this one reads the step's T_src here)
+      dp.counters[0] = pos + 1;
+      dp.counters[1] = ts + 1;
+      *dp.ticket = 0;
+      __threadfence();
+    }
   }
 }
 
@@ -1158,6 +1293,84 @@ extern "C" int sea_predictor_tail_select_at(const void* y, int dtype, int64_t N,
   return tail_select_common("sea_predictor_tail_select_at", nullptr, y, dtype, N, C, H, T, W4, up, T_m, y_strides, conv_b, conv_w16, Cp,
                             gamma, beta, eps, probs, scores, keep_table, 0, T, t_src_dev, is_causal, max_k, bits, row_nnz,
                             head_off, crow_out, stream);
+}
+
+// One launch for a decoding step's predictor CNN + tail + selection + state advance (DecodeCnnParams above; round 5).
+template <typename T>
+static int launch_decode_cnn(const DecodeCnnParams& dp, const TailParams& tp, const TopkParams& p, const EmitParams& ep, hipStream_t s) {
+  const int ept = ((p.nchunks + TK_THREADS - 1) / TK_THREADS) * 4;
+  size_t lds = (size_t)(((tp.H + 15) / 16) * 16) * (tp.W4 + 3) * sizeof(float) + (size_t)TAIL_TAB_ROWS * 256 * sizeof(uint32_t);
+  if (lds < 2 * TK_CAND_CAP * sizeof(uint32_t)) lds = 2 * TK_CAND_CAP * sizeof(uint32_t);
+  const int nt = (dp.C + 15) / 16, kch = (dp.C + 31) / 32;
+  const size_t wimg = (size_t)(16 * nt) * 9 * kch * 64;                    // the weight image overlays the (later) z tile
+  if (lds < wimg) lds = wimg;
+  dim3 grid((unsigned)tp.N), block(TK_THREADS);
+#define SEA_DCNN(EE, NTV, KV)                                                                                          \
+  do {                                                                                                                 \
+    constexpr bool EM = (NTV) <= 4;                                                                                    \
+    if (!EM && ep.col != nullptr) return SEA_EUNSUPPORTED;                                                             \
+    static DevOnce once;                                                                                               \
+    if (lds > 32 * 1024 && once.first()) SEA_MAX_LDS((decode_cnn_tail_select_kernel<T, EE, NTV, KV, EM>), lds);        \
+    hipLaunchKernelGGL((decode_cnn_tail_select_kernel<T, EE, NTV, KV, EM>), grid, block, lds, s, dp, tp, p, ep);       \
+  } while (0)
+  if (ept <= 8 && nt == 1 && kch == 1) { if (ept <= 4) SEA_DCNN(4, 1, 1); else SEA_DCNN(8, 1, 1); }
+  else if (ept <= 16 && nt == 2 && kch == 1) SEA_DCNN(16, 2, 1);
+  else if (ept <= 32 && nt == 3 && kch == 2) SEA_DCNN(32, 3, 2);
+  else if (ept <= 32 && nt == 4 && kch == 2) SEA_DCNN(32, 4, 2);
+  else if (ept <= 40 && nt == 5 && kch == 3) SEA_DCNN(40, 5, 3);
+  else return SEA_EUNSUPPORTED;
+#undef SEA_DCNN
+  return SEA_OK;
+}
+
+extern "C" int sea_decode_cnn_tail_select(const void* x_new, void* x_ring, void* y1_ring, void* y2, int dtype, int64_t N, int64_t C,
+                                          int64_t H, int64_t W4, int64_t ring_x, int64_t ring_y, const void* w1_packed,
+                                          const float* bias1, const void* w2_packed, const float* bias2, int64_t CinP, int dilation,
+                                          int pad_w, const void* conv_b, const void* conv_w16, int64_t Cp, const void* gamma,
+                                          const void* beta, float eps, void* probs, const int32_t* keep_table, int32_t* counters,
+                                          int32_t* ticket, int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz,
+                                          int32_t* head_off, int32_t* crow_out, int32_t* col, int64_t col_stride_n, int64_t z_cap,
+                                          int64_t T_cap, sea_stream_t stream) {
+  const char* nm = "sea_decode_cnn_tail_select";
+  SEA_REQUIRE(col == nullptr || (C <= 64 && col_stride_n >= z_cap && z_cap > 0 && T_cap > 0 && H * T_cap < (1ll << 31)), SEA_EUNSUPPORTED,
+              "%s: the in-launch emit serves C <= 64 channels (beyond that the weight image leaves no LDS for it: pass col = NULL "
+              "and call sea_csr_emit_at with t_src_dev = counters + 2)", nm);
+  SEA_REQUIRE(x_new && x_ring && y1_ring && y2 && w1_packed && bias1 && w2_packed && bias2 && conv_b && conv_w16 && gamma && beta &&
+                  keep_table && counters && ticket && bits && row_nnz && head_off && crow_out, SEA_EINVAL, "%s: null pointer", nm);
+  SEA_REQUIRE(dtype == SEA_F16 || dtype == SEA_BF16, SEA_EUNSUPPORTED, "%s: 16-bit data only (dtype %d)", nm, dtype);
+  SEA_REQUIRE(N > 0 && N < (1 << 20) && H > 0 && H <= 64 && H % 4 == 0 && C == 2 * H && C % 8 == 0 && W4 == 64 && max_k > 0, SEA_EUNSUPPORTED,
+              "%s: needs T_m = 256 (W4 = 64), H %% 4 == 0, C = 2 H channels in whole blocks of 8", nm);
+  SEA_REQUIRE(CinP == (C + 31) / 32 * 32 && Cp % 32 == 0 && Cp >= C && dilation > 0 && 2 * pad_w == 2 * dilation, SEA_EUNSUPPORTED,
+              "%s: 3 x 3 width-preserving convolutions with CinP = C rounded up to 32", nm);
+  SEA_REQUIRE(ring_x > 2 * dilation && ring_y > 2 * dilation, SEA_EINVAL,
+              "%s: a ring must hold the rows t - 2 dil .. t in distinct slots (more than 2 * dilation of them)", nm);
+  SEA_REQUIRE((((uintptr_t)x_new | (uintptr_t)x_ring | (uintptr_t)y1_ring | (uintptr_t)y2 | (uintptr_t)w1_packed | (uintptr_t)w2_packed |
+                (uintptr_t)conv_w16 | (uintptr_t)probs) & 15) == 0, SEA_EUNSUPPORTED, "%s: 16-byte alignment", nm);
+  DecodeCnnParams dp;
+  dp.x_new = x_new; dp.x_ring = x_ring; dp.y1_ring = y1_ring; dp.y2 = y2; dp.w1 = w1_packed; dp.w2 = w2_packed; dp.b1 = bias1; dp.b2 = bias2;
+  dp.counters = counters; dp.ticket = ticket;
+  dp.C = (int)C; dp.W = (int)W4; dp.RX = (int)ring_x; dp.RY = (int)ring_y; dp.dil = dilation; dp.pad_w = pad_w;
+  TailParams tp;
+  tp.y = y2; tp.w4 = nullptr; tp.b4 = conv_b; tp.gamma = gamma; tp.beta = beta; tp.probs = probs; tp.scores = nullptr; tp.eps = eps;
+  tp.N = (int)N; tp.C = (int)C; tp.H = (int)H; tp.T = 1; tp.W4 = (int)W4; tp.UP = 4; tp.T_M = 256;
+  tp.ys_n = C * W4; tp.ys_c = 1; tp.ys_t = 0; tp.ys_w = 8; tp.ys_c8 = W4 * 8;          // one C8 row per batch item
+  tp.w16 = conv_w16; tp.Cp = (int)Cp; tp.z = nullptr;
+  TopkParams p;
+  p.src = nullptr; p.sn = H * 256; p.sh = 256; p.st = 256;
+  p.H = (int)H; p.T_dst = 1; p.T_m = 256; p.T_src = 1;
+  p.is_causal = is_causal; p.max_k = max_k;
+  p.M = (int)(H * 256); p.nchunks = p.M / 4; p.W = (p.M + 31) / 32; p.G = group_lanes(256);
+  p.keep = keep_table; p.keep_stride_n = 0;
+  p.bits = bits; p.mask_out = nullptr; p.row_nnz = row_nnz; p.head_off = head_off; p.t_src_dev = counters + 1; p.crow1 = crow_out;
+  EmitParams ep;
+  ep.bits = bits; ep.crow = crow_out; ep.H = (int)H; ep.T_dst = 1; ep.T_m = 256; ep.T_src = 1; ep.is_causal = is_causal; ep.max_k = max_k;
+  ep.W = p.W; ep.col = col; ep.col_stride_n = col_stride_n; ep.z_cap = z_cap; ep.values_out = nullptr; ep.T_enc = (int)T_cap;
+  ep.t_src_dev = counters + 1;
+  hipStream_t s = (hipStream_t)stream;
+  const int rc = dtype == SEA_F16 ? launch_decode_cnn<__half>(dp, tp, p, ep, s) : launch_decode_cnn<__hip_bfloat16>(dp, tp, p, ep, s);
+  SEA_REQUIRE(rc == SEA_OK, rc, "%s: this head / channel count has no fused decode instantiation", nm);
+  SEA_CHECK_LAUNCH(nm);
+  return SEA_OK;
 }
 
 extern "C" int sea_csr_row_scan(const int32_t* row_nnz, int64_t N, int64_t T_dst, void* crow, int idx_bytes,

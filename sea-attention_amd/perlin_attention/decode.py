@@ -20,6 +20,14 @@ arguments change: it takes the caller's q row and appends k / v to the caches) a
 also advances the two device counters); the MLP writes the new CNN row straight behind the window and the tail + selection
 launch writes the one-row `crow` itself.  Results are bitwise those of `_forward_cached` called position by position
 (tests/test_decode_session.py).
+
+Round 5: conv1, conv2, tail + selection and the window shift -- four launches, 37 of a position's 95 us at batch 1, all of it
+fixed cost (each convolution staged its 74 KB weight image into LDS to convolve a 25-row window of which one row is new) --
+are ONE launch, `sea_decode_cnn_tail_select`: a workgroup per sequence computes the one new row of each convolution (the
+earlier rows it needs, t - 2 and t - 4, live in two small rings: the MLP's previous outputs and conv1's previous outputs),
+runs the unchanged tail + selection on it and advances the device counters.  Nothing is shifted any more: a ring slot is
+position % ring size.  Still bitwise (`csrc/sea_convfrag.hpp: conv_row_c8` reproduces the convolution kernel's operand
+placement and k order).  Shapes outside that kernel (three-convolution bodies, H > 40) keep the round-4 launches.
 """
 from typing import Optional
 
@@ -61,6 +69,31 @@ class DecodeSession:
         self.xs = torch.zeros((N, LB + 1) + tuple(cs.rows_c8.shape[2:]), dtype=dt, device=dev)
         self.xs[:, :LB] = cs.rows_c8
         self.win = self.xs[:, :LB]
+        self.LB = LB
+        # round 5: the fused CNN + tail + selection launch (module docstring).  x ring: the MLP's rows of the last LB positions,
+        # row of position p in slot p % LB (what `win` holds, by position instead of by age); y1 ring: conv1's rows of the last
+        # positions (8 slots: t - 2 dil and t - 4 dil... t must sit in distinct slots for dilation 2)
+        body = list(at.attention_predictor_cnn[1].module.net.children())
+        convs = [body[i].module for i in range(0, len(body) - 2, 2)]
+        C = cs.rows_c8.shape[2] * 8
+        self.fused_cnn = (len(convs) == 2 and all(c.kernel_size == 3 and c.in_channels == C and c.out_channels == C
+                                                  and isinstance(c.dilation, int) and c.dilation == convs[0].dilation
+                                                  and c.padding[1] == c.dilation for c in convs)
+                          and ops.decode_cnn_supported(C, H, self.T_M, dt) and LB > 2 * convs[0].dilation)
+        if self.fused_cnn:
+            dil, RY = convs[0].dilation, 2 * 2 * convs[0].dilation + 1      # t, t - dil, t - 2 dil in distinct slots: 9 for dil 2
+            row_shape = tuple(cs.rows_c8.shape[2:])
+            pos = torch.arange(L - LB, L, device=dev)
+            self.x_ring = torch.zeros((N, LB) + row_shape, dtype=dt, device=dev)
+            self.x_ring[:, pos % LB] = cs.rows_c8                            # window row i is position L - LB + i
+            y1 = ops.causal_conv_c8(cs.rows_c8.contiguous(), convs[0].weight, convs[0].bias, 3, dil, dil, relu=True)
+            self.y1_ring = torch.zeros((N, RY) + row_shape, dtype=dt, device=dev)
+            keep_rows = min(RY - 1, LB - 2 * dil)                            # rows whose taps lie inside the window: conv1's true values
+            p1 = torch.arange(L - keep_rows, L, device=dev)
+            self.y1_ring[:, p1 % RY] = y1[:, LB - keep_rows:]
+            self.x_new = torch.zeros((N, 1) + row_shape, dtype=dt, device=dev)   # where the MLP writes the new row
+            self.y2 = torch.zeros((N,) + row_shape, dtype=dt, device=dev)
+            self.ticket = torch.zeros((1,), dtype=torch.int32, device=dev)
         # K and V caches are the two halves of ONE tensor and the two position counters two elements of one
         self.kv_cache = torch.zeros((2, N, H, capacity, D), dtype=dt, device=dev)
         self.k_cache, self.v_cache = self.kv_cache[0], self.kv_cache[1]
@@ -68,9 +101,11 @@ class DecodeSession:
         self.v_cache[:, :, :L] = value_prefix
         # device counters: seen = rows the state has seen = cache row of the new token, tsrc = keys the new row sees; the
         # LAST launch of a step (the window shift) advances both
-        self.ctr32 = torch.tensor([L, L + 1], dtype=torch.int32, device=dev)
+        # (third element, fused CNN launch only: T_src of the step that launch has just closed -- what the emit behind it reads)
+        self.ctr32 = torch.tensor([L, L + 1, L + 1], dtype=torch.int32, device=dev)
         self.seen32 = self.ctr32[0:1]
         self.tsrc32 = self.ctr32[1:2]
+        self.tsrc_done32 = self.ctr32[2:3]
         self.crow = torch.zeros((N, 2), dtype=torch.int32, device=dev)        # one-row CSR: [0, row total], written by the selection
         self.length = L                                                      # host mirror (bounds check only)
         # K_t of every reachable position (attention.py:849-866, the same fp32 expression as the stateless path) and
@@ -91,7 +126,7 @@ class DecodeSession:
 
     # the one launch of a position whose arguments change: q -> q_in, k / v -> the caches' new row
     def _stage(self, q, k, v):
-        ops.decode_stage(q, k, v, self.q_in, self.kv_cache, self.ctr32)
+        ops.decode_stage(q, k, v, self.q_in, self.kv_cache, self.ctr32[:2])
 
     # the (captured) launches of one position; everything position-dependent is read from device memory
     def _launch(self):
@@ -103,14 +138,32 @@ class DecodeSession:
         _x, _t, row_scale, avg_scale = ops.predictor_mlp(
             performer_value, at.attention_predictor_enc[0], at.attention_predictor_enc[1],
             at.attention_predictor_dec_row[0], at.attention_predictor_cnn[0].module,
-            at.attention_predictor_dec_scaler[0], want_tpred=False, x_c8_out=self.xs[:, -1:])   # the new row, behind the window
+            at.attention_predictor_dec_scaler[0], want_tpred=False,
+            x_c8_out=self.x_new if self.fused_cnn else self.xs[:, -1:])       # the new row (fused CNN: its own buffer; else behind the window)
         keepres, ln2 = at.attention_predictor_cnn[1].module, at.attention_predictor_cnn[2].module
         body = list(keepres.net.children())
+        conv4 = body[-1].module
+        if self.fused_cnn:
+            # conv1 + conv2 (one new row each) + tail + selection + the counters' advance: one launch
+            emits = ops.decode_cnn_emits(self.x_new.shape[-3] * 8)      # ... and the CSR row's column ids, where the LDS allows
+            col = torch.empty((self.N, self.z_cap), dtype=torch.int32, device=self.q_in.device) if emits else None
+            self.probs, sel = ops.decode_cnn_tail_select(
+                self.x_new, self.x_ring, self.y1_ring, self.y2, body[0].module, body[2].module, conv4.weight[:, :, 0, 0], conv4.bias,
+                ln2.weight, ln2.bias, T_M, self.keep_table, self.k, self.ctr32, self.ticket, self.crow, eps=ln2.eps,
+                col_out=col, T_cap=self.capacity)
+            if emits:
+                csr = ops.FlatCSR(self.crow, col, sel[2], H, self.capacity, bits=sel[0], row_nnz=sel[1])
+            else:
+                csr = ops.csr_from_selection(*sel, H, T_M, self.capacity, self.k, True, self.z_cap, t_src_dev=self.tsrc_done32, crow=self.crow)
+            ops.sparse_attention(self.q_in, self.k_cache, self.v_cache, csr,
+                                 row_scale=row_scale if at.pconfig.partial_attention_scaler else None,
+                                 avg=avg_rows, mix=avg_scale, out=self.ctx.view(self.N, 1, H, D).permute(0, 2, 1, 3),
+                                 path="gather")
+            return
         y = self.xs                                                           # (N, LB + 1, C/8, W, 8)
         for i in range(0, len(body) - 2, 2):
             conv = body[i].module
             y = ops.causal_conv_c8(y, conv.weight, conv.bias, conv.kernel_size, conv.dilation, conv.padding[1], relu=True)
-        conv4 = body[-1].module
         y_new = y[:, -1:]                                                     # (the tail reads the row where it lies)
         self.probs, _, sel = ops.predictor_tail_select(
             y_new, conv4.weight[:, :, 0, 0], conv4.bias, ln2.weight, ln2.bias, up=4, T_m=T_M, keep=self.keep_table,
@@ -120,7 +173,7 @@ class DecodeSession:
                              row_scale=row_scale if at.pconfig.partial_attention_scaler else None,
                              avg=avg_rows, mix=avg_scale, out=self.ctx.view(self.N, 1, H, D).permute(0, 2, 1, 3),
                              path="gather")
-        ops.c8_window_shift(self.xs, counters=self.ctr32)                     # the window of the next position; counters += 1
+        ops.c8_window_shift(self.xs, counters=self.ctr32[:2])                 # the window of the next position; counters += 1
 
     def _capture(self):
         """One eager step on a side stream would advance the state, so the capture runs against SAVED copies of the
@@ -132,7 +185,10 @@ class DecodeSession:
         another layer's `.to()` / `load_state_dict`, or the cache's own size bound -- cannot free memory a replay still
         reads; and it remembers the cache generation: `step()` re-captures when that has moved, because a cleared cache
         means the weights may have been edited and the pinned packs may be stale."""
-        saved = [t.clone() for t in (self.image, self.xs, self.kv_cache, self.ctr32)]
+        mutable = [self.image, self.xs, self.kv_cache, self.ctr32]
+        if self.fused_cnn:
+            mutable += [self.x_ring, self.y1_ring, self.ticket]
+        saved = [t.clone() for t in mutable]
         with ops.pinned_prep() as pins:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -145,7 +201,7 @@ class DecodeSession:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g), torch.no_grad():
                 self._launch()
-        for dst, src in zip((self.image, self.xs, self.kv_cache, self.ctr32), saved):
+        for dst, src in zip(mutable, saved):
             dst.copy_(src)
         self.graph = g
         self._pinned = pins
@@ -159,7 +215,11 @@ class DecodeSession:
         ps = PerformerState()
         ps.image, ps.seq_index = self.image.clone(), self.length
         cs = CnnWindowState(self.win.shape[1])
-        cs.rows_c8 = self.win.clone()
+        if self.fused_cnn:                                          # the ring by age: positions length - LB .. length - 1
+            pos = torch.arange(self.length - self.LB, self.length, device=self.x_ring.device)
+            cs.rows_c8 = self.x_ring[:, pos % self.LB].clone()
+        else:
+            cs.rows_c8 = self.win.clone()
         cav = CumAvgState()
         cav.prev_len, cav.in_image = self.length, True
         st.states = {PerlinAttentionState.PERFORMER: ps, PerlinAttentionState.CNN: cs, PerlinAttentionState.CUMAVG: cav}

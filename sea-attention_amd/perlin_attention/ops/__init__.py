@@ -15,4 +15,4 @@ from .predictor import (split_layernorm, predictor_tail, cumavg, performer_value
                         split_layernorm_c8, causal_conv_c8, causal_conv_c8_z, conv_z_supported, conv_c8_f32_supported, predictor_tail_z, pack_conv_weight, to_c8, from_c8,
                         predictor_mlp, predictor_mlp_supported, predictor_tail_select,
                         predictor_tail_select_supported, clear_prep_cache, prep_generation, pinned_prep, LazyTensor, realize,
-                        decode_stage, c8_window_shift)
+                        decode_stage, c8_window_shift, decode_cnn_tail_select, decode_cnn_supported, decode_cnn_emits)

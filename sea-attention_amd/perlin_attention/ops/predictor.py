@@ -681,6 +681,59 @@ def decode_stage(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_in: torch.
                                     _p(kv_cache), kv_cache.shape[3], _p(counters), _lib.stream_ptr()), "sea_decode_stage")
 
 
+def decode_cnn_supported(C: int, H: int, T_m: int, dtype) -> bool:
+    """Shapes `sea_decode_cnn_tail_select` is instantiated for (csrc/sea_topk.hip: launch_decode_cnn)."""
+    return (dtype in (torch.float16, torch.bfloat16) and T_m == 256 and H % 4 == 0 and 0 < H <= 40 and C == 2 * H and C % 8 == 0)
+
+
+def decode_cnn_emits(C: int) -> bool:
+    """Does `sea_decode_cnn_tail_select` expand the CSR columns itself for this channel count?"""
+    return C <= 64
+
+
+@_lib.device_guarded
+def decode_cnn_tail_select(x_new: torch.Tensor, x_ring: torch.Tensor, y1_ring: torch.Tensor, y2: torch.Tensor, conv1, conv2,
+                           conv_w: torch.Tensor, conv_b: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor, T_m: int,
+                           keep: torch.Tensor, k: int, counters: torch.Tensor, ticket: torch.Tensor, crow_out: torch.Tensor,
+                           is_causal: bool = True, eps: float = 1e-5, want_probs: bool = True,
+                           col_out: Optional[torch.Tensor] = None, T_cap: int = 0):
+    """One launch for a decoding step's predictor CNN (two 3 x 3 dilated causal convolutions, one new row each), tail,
+    selection and the advance of the session's device counters (`sea_decode_cnn_tail_select`).  `conv1` / `conv2` are the
+    `CausalConv2d` modules; rings and counters as include/sea_hip.h describes.  `col_out` (N, z_cap) int32 with `T_cap` (C <=
+    64, `decode_cnn_emits`): the CSR columns of the new row are written by this launch too.  Returns (probs or None, (bits,
+    row_nnz, head_off))."""
+    lib = _lib.load()
+    _lib.require_gpu(x_new, x_ring, y1_ring, y2, conv_w, conv_b, ln_w, ln_b, keep, counters, ticket, crow_out)
+    N, C8, W4, _e = x_new.shape[0], x_new.shape[-3], x_new.shape[-2], x_new.shape[-1]
+    C, H, dt, dev = C8 * 8, conv_w.shape[0], x_new.dtype, x_new.device
+    assert _e == 8 and x_new.is_contiguous() and x_ring.is_contiguous() and y1_ring.is_contiguous() and y2.is_contiguous()
+    assert x_ring.shape[0] == N and tuple(x_ring.shape[2:]) == (C8, W4, 8) and tuple(y1_ring.shape[2:]) == (C8, W4, 8)
+    assert decode_cnn_supported(C, H, T_m, dt) and W4 * 4 == T_m
+    for cv in (conv1, conv2):
+        assert cv.kernel_size == 3 and cv.in_channels == C and cv.out_channels == C and cv.padding[1] == cv.dilation == conv1.dilation
+    assert counters.dtype == torch.int32 and counters.numel() == 3 and ticket.dtype == torch.int32 and ticket.numel() == 1
+    assert keep.dtype == torch.int32 and keep.ndim == 1 and crow_out.dtype == torch.int32 and tuple(crow_out.shape) == (N, 2)
+    packs = []
+    for cv in (conv1, conv2):
+        packs.append(_cached("conv", (cv.weight, cv.bias), dt,
+                             lambda cv=cv: (pack_conv_weight(cv.weight, 3, dt), cv.bias.to(dt).float().contiguous())))
+    (w1p, CinP), b1 = packs[0]
+    (w2p, _c), b2 = packs[1]
+    _cw, cb, g, b, w16, Cp = _tail_pack(conv_w, conv_b, ln_w, ln_b, dt, dev)
+    probs = torch.empty((N, H, 1, T_m), dtype=dt, device=dev) if want_probs else None
+    Wb = (H * T_m + 31) // 32
+    bits = torch.empty((N, 1, Wb), dtype=torch.int32, device=dev)
+    row_nnz = torch.empty((N, 1), dtype=torch.int32, device=dev)
+    head_off = torch.empty((N, 1, H + 1), dtype=torch.int32, device=dev)
+    _lib.check(lib.sea_decode_cnn_tail_select(
+        _p(x_new), _p(x_ring), _p(y1_ring), _p(y2), _lib.dtype_code(dt), N, C, H, W4, x_ring.shape[1], y1_ring.shape[1],
+        _p(w1p), _p(b1), _p(w2p), _p(b2), CinP, int(conv1.dilation), int(conv1.padding[1]), _p(cb), _p(w16), Cp, _p(g), _p(b),
+        float(eps), _p(probs), _p(keep), _p(counters), _p(ticket), int(is_causal), int(k), _p(bits), _p(row_nnz), _p(head_off),
+        _p(crow_out), _p(col_out), col_out.stride(0) if col_out is not None else 0, col_out.shape[1] if col_out is not None else 0,
+        int(T_cap), _lib.stream_ptr()), "sea_decode_cnn_tail_select")
+    return probs, (bits, row_nnz, head_off)
+
+
 @_lib.device_guarded
 def c8_window_shift(xs: torch.Tensor, counters: Optional[torch.Tensor] = None) -> None:
     """`sea_c8_window_shift`: xs (N, rows, ...) dense -> xs[:, r] = xs[:, r + 1] in place (the last row keeps its values);

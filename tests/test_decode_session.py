@@ -69,7 +69,8 @@ def test_session_steps_equal_cached_forward(dtype, N, H, d, T0, steps, use_graph
         # the in-place state is the state the cached forward carries
         from sea_attention_amd.perlin_attention.attention_state import PerlinAttentionState as PS
         assert torch.equal(sess.image, state.states[PS.PERFORMER].image)
-        assert torch.equal(sess.win, state.states[PS.CNN].rows_c8)
+        assert sess.fused_cnn                                  # round 5: conv1 + conv2 + tail + selection + counters in one launch
+        assert torch.equal(sess.export_state().states[PS.CNN].rows_c8, state.states[PS.CNN].rows_c8)   # the ring, by age
         assert torch.equal(sess.k_cache[:, :, :T], x) and torch.equal(sess.v_cache[:, :, :T], x)
 
 
@@ -105,7 +106,7 @@ def test_session_with_the_deeper_predictor_cnn(monkeypatch):
                     attention_mask=_mask(N, T0, T0, dtype))
         state = out.state
         sess = layer.attention.decode_session(state, x[:, :, :T0], x[:, :, :T0], capacity=T0 + steps + 1)
-        assert sess.win.shape[1] == 12
+        assert sess.win.shape[1] == 12 and not sess.fused_cnn       # three convolutions: the round-4 launches
         for i in range(steps):
             hi = T0 + i + 1
             ref = layer(None, None, None, query_layer=q[:, :, hi - 1:hi], key_layer=x[:, :, :hi], value_layer=x[:, :, :hi],
