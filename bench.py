@@ -213,7 +213,16 @@ class LayerBench:
         S.seed(42)
         pc = PerlinAttentionConfig(k=k, attention_predictor_length=T_M, performer_nb_factor=w["nbf"], causal=True,
                                    k_flatten=True, k_flatten_dim='causal_batch', context_output_method='mix')
-        layer = PerlinSelfAttention(_Cfg(H * d, H, T), pc).to(dev).to(self.dtype).eval()
+        # the random-init weights are built on the CPU, and the Performer's projection goes through a QR whose rounding follows
+        # the thread count: built single-threaded, so that every leg of every run (with or without the CPU-baseline leg, which
+        # sets the thread count) times the SAME layer -- a leg's entry count is what matches it to its PMC record
+        nthr = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            layer = PerlinSelfAttention(_Cfg(H * d, H, T), pc)
+        finally:
+            torch.set_num_threads(nthr)
+        layer = layer.to(dev).to(self.dtype).eval()
         for m in layer.modules():
             if hasattr(m, 'benchmarking'):
                 m.benchmarking = True
