@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""A/B builds of the C8 convolution at the one-sequence shapes (BASELINE cfg 4 / cfg 5 per GPU), same box:
+   base | one workgroup per CU when the weight image exceeds 80 KB | 8 waves per workgroup | both.
+Run on the GPU box after `python scripts/ab_conv_small.py --build` here (the variant libraries travel in sea-attention_amd/build/)."""
+import json, os, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+VARIANTS = {"base": [], "one_per_cu": ["-DSEA_CONV_ONE_PER_CU"], "waves8": ["-DSEA_CONV_WAVES=8"],
+            "both": ["-DSEA_CONV_ONE_PER_CU", "-DSEA_CONV_WAVES=8"]}
+def lib(v): return os.path.join(ROOT, "sea-attention_amd", "build", f"libsea_hip_conv_{v}.so")
+if "--build" in sys.argv:
+    from sea_attention_amd import _build
+    for v, fl in VARIANTS.items():
+        print(_build.build_library(extra_flags=tuple(fl) or ("-DSEA_AB_BASE",), out=lib(v)))
+elif "--one" in sys.argv:
+    import torch
+    from sea_attention_amd.perlin_attention import ops
+    res = {}
+    for name, (N, C, T) in {"llama13b_x1": (1, 80, 4096), "opt27b_x1": (1, 64, 8192), "opt13b_x8": (8, 64, 4096), "opt125m_x8": (8, 24, 2048)}.items():
+        torch.manual_seed(0)
+        x = ops.to_c8(torch.relu(torch.randn((N, C, T, 64), device="cuda")).to(torch.bfloat16))
+        wt = (torch.randn((C, C, 5, 3), device="cuda") * 0.04).to(torch.bfloat16); b = torch.zeros(C, device="cuda", dtype=torch.bfloat16)
+        for _ in range(5): y = ops.causal_conv_c8(x, wt, b, 3, 2, 2)
+        torch.cuda.synchronize()
+        best = 1e9
+        for rep in range(5):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20): y = ops.causal_conv_c8(x, wt, b, 3, 2, 2)
+            e1.record(); torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 20 * 1e3)
+        res[name] = {"us": round(best, 1), "checksum": float(y.float().abs().sum())}
+    print(json.dumps(res))
+else:
+    for rnd in range(2):
+        for v in VARIANTS:
+            env = dict(os.environ, SEA_HIP_LIB=lib(v))
+            out = subprocess.run([sys.executable, __file__, "--one"], env=env, capture_output=True, text=True)
+            print(v, out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-300:], flush=True)

@@ -52,7 +52,7 @@ struct ConvParams {
 // lines back to back.  Pixel fragments come through buffer loads: a lane whose tap falls outside the row (or whose
 // channel block is K padding) carries an offset beyond num_records and the hardware returns zeros, so the k-loop
 // is branch-free and the next step's loads are in flight under the current step's MFMAs.
-constexpr int CONV_WAVES = 6;
+constexpr int CONV_WAVES = 6;                     // waves per workgroup of the big launches (NW below: 6 or 8)
 constexpr unsigned CONV_OOB = 0x7FFFFF00u;       // > any valid byte offset (launcher checks the image is < 1 GiB)
 
 // ONESEG: W <= 64, every row is one segment: the tap-validity tests and lane offsets are then kernel invariants.
@@ -60,10 +60,13 @@ constexpr unsigned CONV_OOB = 0x7FFFFF00u;       // > any valid byte offset (lau
 // fp32.  Per 16-pixel tile that is HT x ceil(NT/2) MFMAs on operands that are already in registers (+5.5 % at 64 -> 64
 // channels, 32 heads) and it takes the "z tile" phase -- a third of a row's life -- out of the issue-bound tail + selection
 // kernel.  Same operand placement, k order and rounding point as tail_z_tile (sea_tail.hpp): the same bits.
-template <typename T, int NT, int KS, bool ONESEG, bool ZEPI = false>
-__global__ __launch_bounds__(CONV_WAVES * 64, (NT <= 4 ? 3 : 2)) void causal_conv_c8_kernel(ConvParams p) {
+// NW: waves per workgroup.  6 for the big launches (two workgroups of 6 per CU at 64 -> 64 channels); 8 for launches of few
+// rows and for narrow layers (round 5, same-box A/B `scripts/ab_conv_small.py`: one sequence of LLaMA-13B 62 -> 41 us together
+// with one workgroup per CU, OPT-2.7B 51 -> 48, OPT-125m x 8 33.5 -> 30.4; OPT-1.3B x 8 keeps 6: 180 vs 181 - 187 us).
+template <typename T, int NT, int KS, bool ONESEG, bool ZEPI = false, int NW = CONV_WAVES>
+__global__ __launch_bounds__(NW * 64, (NT <= 4 ? 3 : 2)) void causal_conv_c8_kernel(ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int NTH = CONV_WAVES * 64;
+  constexpr int NTH = NW * 64;
   constexpr int ROWS = 16 * NT;
   const int lane = threadIdx.x & 63;
   const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -150,7 +153,7 @@ __global__ __launch_bounds__(CONV_WAVES * 64, (NT <= 4 ? 3 : 2)) void causal_con
     ++c.grp;
     if (++c.cci == kchunks) {
       c.cci = 0; c.row_soff += p.dil * row_bytes;
-      if (++c.ti == KS) { c.work += CONV_WAVES; open_work(c); }
+      if (++c.ti == KS) { c.work += NW; open_work(c); }
     }
   };
   auto issue = [&](const Cursor& c, int tj, cu4 (&a)[4]) {   // request the 4 pixel fragments of step (c.grp, tj)
@@ -480,18 +483,27 @@ static int launch_conv(const ConvParams& p, hipStream_t s, bool zepi = false) {
   if ((int64_t)p.T * p.W * p.Cin * (int64_t)sizeof(T) >= (int64_t)(1u << 30)) return SEA_EUNSUPPORTED;   // 32-bit buffer offsets
   const int64_t nwork = (int64_t)p.N * p.T * ((p.W + 63) / 64);
   if (nwork >= (int64_t)1 << 30) return SEA_EUNSUPPORTED;
-  int64_t blocks = (nwork + CONV_WAVES - 1) / CONV_WAVES;
+  // 8-wave workgroups for narrow layers and for launches of few rows (measured, see the kernel's comment)
+  const bool w8 = nt <= 3 || nt == 5 || nwork <= 16384;
+  const int nw = w8 ? 8 : CONV_WAVES;
+  int64_t blocks = (nwork + nw - 1) / nw;
   if (blocks > 256 * 2) blocks = 256 * 2;      // persistent: two resident workgroups per CU, weights staged once each
-  dim3 grid((unsigned)blocks), block(CONV_WAVES * 64);
-#define SEA_CONV_K(NTV, KSV, ZV)                                                                                    \
+  if (lds > 80 * 1024 && blocks > 256) blocks = 256;     // an image this large leaves room for ONE workgroup per CU: one staging round
+  dim3 grid((unsigned)blocks), block(nw * 64);
+#define SEA_CONV_L(NTV, KSV, ZV, NWV)                                                                               \
   do {                                                                                                              \
     static DevOnce once;                                                                                            \
     if (lds > 64 * 1024 && once.first()) {                                                                          \
-      SEA_MAX_LDS((causal_conv_c8_kernel<T, NTV, KSV, true, ZV>), 160 * 1024);                                      \
-      SEA_MAX_LDS((causal_conv_c8_kernel<T, NTV, KSV, false, ZV>), 160 * 1024);                                     \
+      SEA_MAX_LDS((causal_conv_c8_kernel<T, NTV, KSV, true, ZV, NWV>), 160 * 1024);                                 \
+      SEA_MAX_LDS((causal_conv_c8_kernel<T, NTV, KSV, false, ZV, NWV>), 160 * 1024);                                \
     }                                                                                                               \
-    if (p.W <= 64) hipLaunchKernelGGL((causal_conv_c8_kernel<T, NTV, KSV, true, ZV>), grid, block, lds, s, p);      \
-    else hipLaunchKernelGGL((causal_conv_c8_kernel<T, NTV, KSV, false, ZV>), grid, block, lds, s, p);               \
+    if (p.W <= 64) hipLaunchKernelGGL((causal_conv_c8_kernel<T, NTV, KSV, true, ZV, NWV>), grid, block, lds, s, p); \
+    else hipLaunchKernelGGL((causal_conv_c8_kernel<T, NTV, KSV, false, ZV, NWV>), grid, block, lds, s, p);          \
+  } while (0)
+#define SEA_CONV_K(NTV, KSV, ZV)                                                                                    \
+  do {                                                                                                              \
+    if (w8) SEA_CONV_L(NTV, KSV, ZV, 8);                                                                            \
+    else SEA_CONV_L(NTV, KSV, ZV, CONV_WAVES);                                                                      \
   } while (0)
 #define SEA_CONV(NTV, KSV) SEA_CONV_K(NTV, KSV, false)
 #define SEA_CONV_NT(KSV)                                                                                            \
@@ -514,6 +526,7 @@ static int launch_conv(const ConvParams& p, hipStream_t s, bool zepi = false) {
 #undef SEA_CONV_NT
 #undef SEA_CONV
 #undef SEA_CONV_K
+#undef SEA_CONV_L
   return SEA_OK;
 }
 
