@@ -119,6 +119,7 @@ CASES = [
     ("big",       1, 4, 128, 128, 32, 8, 32, True),
     ("clamp",     1, 2, 96, 96, 4, 8, 8, True),      # T/T_M = 24 > k = 8 -> max_k clamp fires
     ("noncausal", 1, 2, 40, 40, 8, 4, 8, False),     # F8, completeness only
+    ("large",     1, 4, 512, 512, 64, 16, 32, True), # round 5: the largest case the interpreter finishes in minutes (T / T_M = 8)
 ]
 
 
