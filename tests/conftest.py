@@ -8,7 +8,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
-GOLDEN_CASES = ["tiny", "mid", "ragged", "short", "big", "clamp", "noncausal"]
+GOLDEN_CASES = ["tiny", "mid", "ragged", "short", "big", "clamp", "noncausal", "large"]
 
 
 def pytest_configure(config):
