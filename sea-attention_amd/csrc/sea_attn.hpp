@@ -80,9 +80,22 @@ __device__ inline bool map_block(int NH, int TB, int* pair, int* tb) {
   const int bid = blockIdx.x;
   const int xcd = bid & 7, slot = bid >> 3;
   const int pl = slot / TB;
-  *tb = slot - pl * TB;
-  *pair = pl * 8 + xcd;
-  return *pair < NH;
+  const int full = NH >> 3;                      // groups of 8 pairs: pair 8 pl + x lives on XCD x (its K / V stay in that L2)
+  if (pl < full) {
+    *tb = slot - pl * TB;
+    *pair = pl * 8 + xcd;
+    return true;
+  }
+  // the last, partial group (NH % 8 = r pairs; round 5): its r TB row blocks are dealt round-robin to ALL eight XCDs instead
+  // of TB blocks to each of r XCDs while 8 - r sit idle -- 12 pairs (OPT-125m, one sequence: the long-context and grid legs)
+  // were 2 + 2 + 2 + 2 + 1 + 1 + 1 + 1 pairs per XCD, i.e. the launch lasted as long as 16 pairs
+  const int r = NH - full * 8;
+  const int item = (slot - pl * TB) * 8 + xcd;
+  if (pl > full || item >= r * TB) return false;
+  const int pr = item / TB;
+  *tb = item - pr * TB;
+  *pair = full * 8 + pr;
+  return true;
 }
 
 // true when the plan hands this launch to the OTHER kernel (uniform over the whole grid: every workgroup returns at once)
