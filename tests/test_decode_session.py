@@ -41,7 +41,13 @@ def _layer(H, d, T_M, k, T, dtype):
 @pytest.mark.parametrize("dtype,N,H,d,T0,steps", [(torch.bfloat16, 2, 8, 64, 250, 14),     # crosses T_M = 256: pixel widths 1 -> 2
                                                   (torch.float16, 1, 4, 64, 40, 6),
                                                   (torch.bfloat16, 1, 8, 128, 300, 5),
-                                                  (torch.bfloat16, 1, 4, 80, 63, 4)])       # crosses a Performer chunk boundary
+                                                  (torch.bfloat16, 1, 4, 80, 63, 4),        # crosses a Performer chunk boundary
+                                                  # round 5: every instantiation of the fused CNN + tail + selection launch
+                                                  (torch.bfloat16, 1, 12, 64, 70, 4),       # 24 channels: 2 tiles, 1 k-chunk
+                                                  (torch.float16, 1, 20, 64, 50, 3),        # 40 channels: 3 tiles (odd), 2 k-chunks
+                                                  (torch.bfloat16, 2, 32, 64, 130, 3),      # 64 channels: the OPT-1.3B form
+                                                  (torch.bfloat16, 1, 40, 64, 90, 3),       # 80 channels: 5 tiles, emit as its own launch
+                                                  (torch.bfloat16, 1, 16, 64, 40, 3)])      # 32 channels
 def test_session_steps_equal_cached_forward(dtype, N, H, d, T0, steps, use_graph):
     T_M, k = 256, 16
     T = T0 + steps

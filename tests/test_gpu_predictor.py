@@ -210,6 +210,27 @@ def test_causal_conv_c8(ops, dtype, N, Cin, Cout, T, W, dil):
     torch.testing.assert_close(ops.from_c8(y).float().cpu(), ref1, atol=2e-2, rtol=2e-2)
 
 
+def test_causal_conv_c8_launch_geometries_agree(ops):
+    """Round 5: the convolution picks 8-wave workgroups for narrow layers / launches of few rows and 6-wave ones for big
+    64 -> 64-channel launches (and one workgroup per CU for weight images beyond 80 KB).  Same rows, bit for bit, whichever
+    geometry a launch gets: a 5-sequence batch (20480 rows: the 6-wave form) against its sequences run one by one (8-wave)."""
+    g = torch.Generator().manual_seed(5)
+    N, C, T, W = 5, 64, 4096, 64
+    x = ops.to_c8(torch.randn((N, C, T, W), generator=g).to(torch.bfloat16).to(DEV))
+    wt = (torch.randn((C, C, 5, 3), generator=g) * (C * 9) ** -0.5).to(torch.bfloat16).to(DEV)
+    b = (torch.randn(C, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    y = ops.causal_conv_c8(x, wt, b, 3, 2, 2)
+    for n in range(N):
+        assert torch.equal(y[n:n + 1], ops.causal_conv_c8(x[n:n + 1].contiguous(), wt, b, 3, 2, 2)), n
+    # 80 -> 80 channels (138 KB image: one workgroup per CU), many rows against few
+    C = 80
+    x = ops.to_c8(torch.randn((2, C, 3000, W), generator=g).to(torch.bfloat16).to(DEV))
+    wt = (torch.randn((C, C, 5, 3), generator=g) * (C * 9) ** -0.5).to(torch.bfloat16).to(DEV)
+    b = (torch.randn(C, generator=g) * 0.1).to(torch.bfloat16).to(DEV)
+    y = ops.causal_conv_c8(x, wt, b, 3, 2, 2)
+    assert torch.equal(y[1:, :200], ops.causal_conv_c8(x[1:, :200].contiguous(), wt, b, 3, 2, 2))
+
+
 @pytest.mark.parametrize("dil", [2, 1, 3])
 @pytest.mark.parametrize("N,Cin,Cout,T,W", [(2, 24, 24, 40, 64), (1, 64, 64, 21, 64), (1, 24, 24, 33, 16), (1, 32, 48, 17, 128),
                                             (1, 16, 32, 12, 40), (1, 24, 24, 9, 96), (1, 8, 8, 7, 24), (1, 40, 40, 13, 64)])
