@@ -916,8 +916,12 @@ class PerlinAttention(nn.Module):
                 csr, mask_m = ops.csr_from_selection(*fs[1], H, T_M, T_SRC, int(self.pconfig.k), True, z_cap,
                                                      defer_emit=self._fuses_interpolation(q, T_M)), None
             else:
+                # (the stand-alone selection: fp32 data, padded batches, QUERY_SKIPS, probing.  Its columns, too, are left to
+                # the fused attention launch wherever that form exists -- round 5: fp32 data paid a 73 us emit launch for a
+                # column array the fused launch then did not even read)
                 csr, mask_m = ops.topk_to_csr(probs, keep, int(self.pconfig.k), target_width=T_SRC, is_causal=True,
-                                              z_cap=z_cap, want_mask=probing)
+                                              z_cap=z_cap, want_mask=probing,
+                                              defer_emit=self._fuses_interpolation(q, T_M) and not probing)
             self._fused_selection = None
         if probing:
             bench.register_temp_buffer('partial_attention_mask_before_interp', mask_m)

@@ -167,12 +167,13 @@ def z_capacity(keep_cpu: torch.Tensor, H, T_dst, T_src, T_m, max_k, is_causal=Tr
 # ------------------------------------------------------------------------------------------------
 @_lib.device_guarded
 def topk_to_csr(probs: torch.Tensor, keep: torch.Tensor, k: int, target_width: Optional[int] = None,
-                is_causal: bool = True, z_cap: Optional[int] = None, want_mask: bool = False):
+                is_causal: bool = True, z_cap: Optional[int] = None, want_mask: bool = False, defer_emit: bool = False):
     """Grouped top-k + nearest-neighbour interpolation to a FlatCSR in three launches, no host sync.
 
     probs (N,H,T_dst,T_m) f32/f16/bf16 (pixel stride 1); keep int32 device tensor (T_dst,) or (N,T_dst).
     Returns (FlatCSR, mask or None) where mask is the 0/1 fp32 (N,H,T_dst,T_m) compressed mask
-    (`partial_attention_mask_before_interp`).
+    (`partial_attention_mask_before_interp`).  `defer_emit`: leave the column array pending (see `csr_from_selection`) -- the
+    fused attention launch expands the kept pixels itself; two launches here instead of three.
     Replaces attention.py:774-947 + ops/kernels/causal_resize_m_to_t.py:910-1007.
     """
     lib = _lib.load()
@@ -196,7 +197,7 @@ def topk_to_csr(probs: torch.Tensor, keep: torch.Tensor, k: int, target_width: O
         probs.stride(0), probs.stride(1), probs.stride(2),
         _p(keep), keep_stride_n, T_src, int(is_causal), int(k),
         _p(bits), _p(mask), _p(row_nnz), _p(head_off), st), "sea_topk_select")
-    return csr_from_selection(bits, row_nnz, head_off, H, T_m, T_src, int(k), is_causal, z_cap, keep), mask
+    return csr_from_selection(bits, row_nnz, head_off, H, T_m, T_src, int(k), is_causal, z_cap, keep, defer_emit=defer_emit), mask
 
 
 @_lib.device_guarded
