@@ -382,7 +382,7 @@ int sea_cumavg_sliced(const void* v, int dtype, int64_t N, int64_t H, int64_t T,
  * C8 layout of a logical (N, C, T, W) activation, C % 8 == 0:  memory (N, T, C/8, W, 8) -- 16-byte blocks of 8
  * channels, consecutive pixels of a block adjacent (what an MFMA operand fragment reads contiguously).
  * sea_split_layernorm_c8: as sea_split_layernorm (no activation) but the result is written C8,
- *   out (N, T, C*S/8, W, 8) -- the layout the conv kernel below consumes.
+ *   out (N, T, C*S/8, W, 8) -- the layout the conv kernels below consume (16-bit data, and fp32 since round 5).
  * sea_causal_conv_c8: y = act(conv2d(x) + bias), square kernel `ksize` (1 or 3), dilation `dilation`, zero padding
  *   (ksize-1)*dilation rows on TOP only (causal along T, = CausalConv2d of modules.py:96-192 whose lower kernel
  *   rows are masked) and pad_w columns on both sides (width preserving).  x (N,T,Cin/8,W,8), y (N,T,Cout/8,W,8);

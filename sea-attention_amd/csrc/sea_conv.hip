@@ -415,6 +415,16 @@ __global__ __launch_bounds__(CONVF_WAVES * 64) void causal_conv_c8f_kernel(ConvF
 //   x (N, C, T, S*W) -> out[n, t, (c*S+i)/8, w, (c*S+i)%8] = LN(x[n, c, t, i*W:(i+1)*W])[w] * gamma[w] + beta[w]
 // One workgroup per (n, t): the C*S rows are normalised by 8-lane groups, transposed through LDS and written
 // as one contiguous (C*S/8) x W x 8 block.
+// 8 consecutive elements of a row <-> 8 floats (16-bit: one 16-byte vector; fp32: two)
+template <typename T> __device__ inline void load8(const T* p, float* f) {
+  if constexpr (sizeof(T) == 4) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+  } else {
+    unpack16<T>(*reinterpret_cast<const uint4*>(p), f);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void split_layernorm_c8_kernel(const T* x, T* out, const T* gamma, const T* beta, float eps,
                                                                   int C, int Tn, int S, int W) {
@@ -432,20 +442,19 @@ __global__ __launch_bounds__(256) void split_layernorm_c8_kernel(const T* x, T* 
   const int sub = threadIdx.x % lprp, rloc = threadIdx.x / lprp;
   const bool lact = sub < lpr;
   float g[VEC], b[VEC];
-  unpack16<T>(lact ? *reinterpret_cast<const uint4*>(gamma + sub * VEC) : make_uint4(0, 0, 0, 0), g);
-  unpack16<T>(lact ? *reinterpret_cast<const uint4*>(beta + sub * VEC) : make_uint4(0, 0, 0, 0), b);
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) { g[j] = 0.f; b[j] = 0.f; }
+  if (lact) { load8<T>(gamma + sub * VEC, g); load8<T>(beta + sub * VEC, b); }
   const float invW = 1.0f / (float)W;
   for (int r0 = 0; r0 < CS; r0 += rows_per_pass) {
     const int r = r0 + rloc;                    // output channel c*S + i
     const bool ok = r < CS && lact;
     float f[VEC];
-    {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) {
-        const int c = r / S, i = r - c * S;
-        v = *reinterpret_cast<const uint4*>(x + (((int64_t)n * C + c) * Tn + t) * ((int64_t)S * W) + i * W + sub * VEC);
-      }
-      unpack16<T>(v, f);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) f[j] = 0.f;
+    if (ok) {
+      const int c = r / S, i = r - c * S;
+      load8<T>(x + (((int64_t)n * C + c) * Tn + t) * ((int64_t)S * W) + i * W + sub * VEC, f);
     }
     float s = 0.f;
 #pragma unroll
@@ -464,9 +473,11 @@ __global__ __launch_bounds__(256) void split_layernorm_c8_kernel(const T* x, T* 
   }
   __syncthreads();
   T* on = out + (int64_t)nt * W * CS;
-  for (int ch = threadIdx.x; ch < W * (CS / VEC); ch += 256) {     // ch = block*W + w: the C8 order, coalesced
-    const int blk = ch / W, w = ch - blk * W;
-    *reinterpret_cast<uint4*>(on + (int64_t)ch * VEC) = *reinterpret_cast<const uint4*>(tile + w * ldt + blk * VEC);
+  constexpr int PER = (int)(VEC * sizeof(T) / 16);                 // 16-byte vectors per (block, pixel): 1 (16-bit) or 2 (fp32)
+  for (int ch = threadIdx.x; ch < W * (CS / VEC) * PER; ch += 256) {     // ch / PER = block*W + w: the C8 order, coalesced
+    const int bw = ch / PER, half = ch - bw * PER;
+    const int blk = bw / W, w = bw - blk * W;
+    *(reinterpret_cast<uint4*>(on + (int64_t)bw * VEC) + half) = *(reinterpret_cast<const uint4*>(tile + w * ldt + blk * VEC) + half);
   }
 }
 
@@ -631,18 +642,21 @@ extern "C" int sea_split_layernorm_c8(const void* x, int dtype, int64_t N, int64
                                         const void* gamma, const void* beta, float eps, void* out, sea_stream_t stream) {
   const char* nm = "sea_split_layernorm_c8";
   SEA_REQUIRE(x && gamma && beta && out, SEA_EINVAL, "%s: null pointer", nm);
-  SEA_REQUIRE(dtype == SEA_F16 || dtype == SEA_BF16, SEA_EUNSUPPORTED, "%s: 16-bit data only (dtype %d)", nm, dtype);
+  SEA_REQUIRE(dtype == SEA_F16 || dtype == SEA_BF16 || dtype == SEA_F32, SEA_EINVAL, "%s: bad dtype %d", nm, dtype);
   SEA_REQUIRE(N > 0 && C > 0 && T > 0 && S > 0 && W > 0, SEA_EINVAL, "%s: bad shape", nm);
   const int64_t lpr = W / 8;
   SEA_REQUIRE(W % 8 == 0 && lpr <= 64 && (C * S) % 8 == 0, SEA_EUNSUPPORTED,
               "%s: needs W a multiple of 8 (<= 512) and C*S %% 8 == 0", nm);
-  const size_t lds = (size_t)W * (size_t)(C * S + 8) * 2;
+  const size_t lds = (size_t)W * (size_t)(C * S + 8) * (dtype == SEA_F32 ? 4 : 2);
   SEA_REQUIRE(lds <= 64 * 1024, SEA_EUNSUPPORTED, "%s: tile needs %zu B of LDS", nm, lds);
   SEA_REQUIRE((((uintptr_t)x | (uintptr_t)out | (uintptr_t)gamma | (uintptr_t)beta) & 15) == 0, SEA_EUNSUPPORTED,
               "%s: 16-byte alignment", nm);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)(N * T)), block(256);
-  if (dtype == SEA_BF16)
+  if (dtype == SEA_F32)
+    hipLaunchKernelGGL((split_layernorm_c8_kernel<float>), grid, block, lds, s, (const float*)x, (float*)out, (const float*)gamma,
+                       (const float*)beta, eps, (int)C, (int)T, (int)S, (int)W);
+  else if (dtype == SEA_BF16)
     hipLaunchKernelGGL((split_layernorm_c8_kernel<__hip_bfloat16>), grid, block, lds, s, (const __hip_bfloat16*)x,
                        (__hip_bfloat16*)out, (const __hip_bfloat16*)gamma, (const __hip_bfloat16*)beta, eps, (int)C, (int)T, (int)S, (int)W);
   else

@@ -507,10 +507,8 @@ class PerlinAttention(nn.Module):
                     body = list(keepres.net.children())
                     c8 = self._c8_cnn_ok(dec, body)
                     with timer("cnn.lnorm1"):
-                        if c8 and dec.dtype != torch.float32:   # the CNN runs channel-blocked (C8) on the hand-written MFMA conv kernels
+                        if c8:   # the CNN runs channel-blocked (C8) on the hand-written MFMA conv kernels (16-bit and fp32 data)
                             x = ops.split_layernorm_c8(dec, self.attention_predictor_dec_row_splits, ln1.weight, ln1.bias, ln1.eps)
-                        elif c8:                                # fp32 data: LayerNorm kernel + one re-layout pass
-                            x = ops.to_c8(ops.split_layernorm(dec, self.attention_predictor_dec_row_splits, ln1.weight, ln1.bias, ln1.eps))
                         else:
                             x = ops.split_layernorm(dec, self.attention_predictor_dec_row_splits, ln1.weight, ln1.bias, ln1.eps)
                     if c8:

@@ -568,7 +568,7 @@ def from_c8(y: torch.Tensor) -> torch.Tensor:
 
 @_lib.device_guarded
 def split_layernorm_c8(x: torch.Tensor, splits: int, weight: torch.Tensor, bias: torch.Tensor, eps: float = 1e-5):
-    """ChannelSplit + LayerNorm writing the C8 layout: (N, C, T, splits*W) -> (N, T, C*splits/8, W, 8).  16-bit only."""
+    """ChannelSplit + LayerNorm writing the C8 layout: (N, C, T, splits*W) -> (N, T, C*splits/8, W, 8).  16-bit and fp32 data."""
     lib = _lib.load()
     _lib.require_gpu(x, weight, bias)
     N, C, T, SW = x.shape

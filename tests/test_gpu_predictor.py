@@ -263,7 +263,7 @@ def test_causal_conv_c8_fp32(ops, N, Cin, Cout, T, W, dil):
     torch.testing.assert_close(ops.from_c8(y).cpu(), torch.nn.functional.conv2d(x, w1, b), atol=1e-5, rtol=1e-5)
 
 
-@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16, torch.float32])
 @pytest.mark.parametrize("N,C,T,S,W", [(2, 12, 40, 2, 16), (1, 32, 70, 2, 64), (1, 40, 9, 2, 64), (1, 4, 5, 2, 128),
                                        (1, 12, 21, 2, 24), (1, 12, 13, 2, 96), (1, 4, 7, 2, 40)])    # lanes per row not a power of two
 def test_split_layernorm_c8(ops, dtype, N, C, T, S, W):
@@ -276,6 +276,9 @@ def test_split_layernorm_c8(ops, dtype, N, C, T, S, W):
     assert tuple(c.shape) == (N, T, C * S // 8, W, 8)
     c = ops.from_c8(c)
     # same arithmetic, different layout; the two kernels may contract one FMA differently: <= 1 ulp of the 16-bit type
+    if dtype == torch.float32:                                       # (round 5) fp32 rows: fp32 rounding noise only
+        torch.testing.assert_close(a, c, atol=2e-6, rtol=2e-6)
+        return
     torch.testing.assert_close(a.float(), c.float(), atol=1e-3, rtol=8e-3)
     assert (a != c).float().mean().item() < 1e-3
 
