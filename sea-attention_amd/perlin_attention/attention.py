@@ -507,8 +507,11 @@ class PerlinAttention(nn.Module):
                     body = list(keepres.net.children())
                     c8 = self._c8_cnn_ok(dec, body)
                     with timer("cnn.lnorm1"):
-                        if c8:   # the CNN runs channel-blocked (C8) on the hand-written MFMA conv kernels (16-bit and fp32 data)
+                        if c8 and dec.dtype != torch.float32:   # the CNN runs channel-blocked (C8) on the hand-written MFMA conv kernels
                             x = ops.split_layernorm_c8(dec, self.attention_predictor_dec_row_splits, ln1.weight, ln1.bias, ln1.eps)
+                        elif c8:    # fp32 data: LayerNorm kernel + one re-layout pass (35 + 45 us at config 2; the one-launch
+                            #         split_layernorm_c8 takes fp32 too but its LDS transpose is 8-way bank-conflicted there: 105 us)
+                            x = ops.to_c8(ops.split_layernorm(dec, self.attention_predictor_dec_row_splits, ln1.weight, ln1.bias, ln1.eps))
                         else:
                             x = ops.split_layernorm(dec, self.attention_predictor_dec_row_splits, ln1.weight, ln1.bias, ln1.eps)
                     if c8:

@@ -66,9 +66,6 @@ class DecodeSession:
         self.image = ps.image.clone()                                        # Performer sums, updated in place
         # CNN input rows: the window (last LB rows) and, behind it, the row of the current position -- ONE buffer, so that the
         # MLP writes the new row in place (no cat) and the window moves by an in-place shift at the end of the step
-        self.xs = torch.zeros((N, LB + 1) + tuple(cs.rows_c8.shape[2:]), dtype=dt, device=dev)
-        self.xs[:, :LB] = cs.rows_c8
-        self.win = self.xs[:, :LB]
         self.LB = LB
         # round 5: the fused CNN + tail + selection launch (module docstring).  x ring: the MLP's rows of the last LB positions,
         # row of position p in slot p % LB (what `win` holds, by position instead of by age); y1 ring: conv1's rows of the last
@@ -94,6 +91,10 @@ class DecodeSession:
             self.x_new = torch.zeros((N, 1) + row_shape, dtype=dt, device=dev)   # where the MLP writes the new row
             self.y2 = torch.zeros((N,) + row_shape, dtype=dt, device=dev)
             self.ticket = torch.zeros((1,), dtype=torch.int32, device=dev)
+            self.xs = None
+        else:                                                      # the round-4 launches: a window the step shifts by one row
+            self.xs = torch.zeros((N, LB + 1) + tuple(cs.rows_c8.shape[2:]), dtype=dt, device=dev)
+            self.xs[:, :LB] = cs.rows_c8
         # K and V caches are the two halves of ONE tensor and the two position counters two elements of one
         self.kv_cache = torch.zeros((2, N, H, capacity, D), dtype=dt, device=dev)
         self.k_cache, self.v_cache = self.kv_cache[0], self.kv_cache[1]
@@ -123,6 +124,15 @@ class DecodeSession:
         self._pinned, self._prep_generation = None, ops.prep_generation()
         if use_graph:
             self._capture()
+
+    @property
+    def win(self) -> torch.Tensor:
+        """The predictor CNN's input rows of the last LB positions, oldest first, (N, LB, C/8, W, 8): a view of the shifted
+        window (round-4 launches) or the ring read out by age (fused CNN launch; a copy)."""
+        if self.fused_cnn:
+            pos = torch.arange(self.length - self.LB, self.length, device=self.x_ring.device)
+            return self.x_ring[:, pos % self.LB]
+        return self.xs[:, :self.LB]
 
     # the one launch of a position whose arguments change: q -> q_in, k / v -> the caches' new row
     def _stage(self, q, k, v):
@@ -185,9 +195,8 @@ class DecodeSession:
         another layer's `.to()` / `load_state_dict`, or the cache's own size bound -- cannot free memory a replay still
         reads; and it remembers the cache generation: `step()` re-captures when that has moved, because a cleared cache
         means the weights may have been edited and the pinned packs may be stale."""
-        mutable = [self.image, self.xs, self.kv_cache, self.ctr32]
-        if self.fused_cnn:
-            mutable += [self.x_ring, self.y1_ring, self.ticket]
+        mutable = [self.image, self.kv_cache, self.ctr32]
+        mutable += [self.x_ring, self.y1_ring, self.ticket] if self.fused_cnn else [self.xs]
         saved = [t.clone() for t in mutable]
         with ops.pinned_prep() as pins:
             side = torch.cuda.Stream()
@@ -214,12 +223,8 @@ class DecodeSession:
         st = PerlinAttentionState(self.attention)
         ps = PerformerState()
         ps.image, ps.seq_index = self.image.clone(), self.length
-        cs = CnnWindowState(self.win.shape[1])
-        if self.fused_cnn:                                          # the ring by age: positions length - LB .. length - 1
-            pos = torch.arange(self.length - self.LB, self.length, device=self.x_ring.device)
-            cs.rows_c8 = self.x_ring[:, pos % self.LB].clone()
-        else:
-            cs.rows_c8 = self.win.clone()
+        cs = CnnWindowState(self.LB)
+        cs.rows_c8 = self.win.clone()
         cav = CumAvgState()
         cav.prev_len, cav.in_image = self.length, True
         st.states = {PerlinAttentionState.PERFORMER: ps, PerlinAttentionState.CNN: cs, PerlinAttentionState.CUMAVG: cav}

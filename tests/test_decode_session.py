@@ -76,7 +76,8 @@ def test_session_steps_equal_cached_forward(dtype, N, H, d, T0, steps, use_graph
         from sea_attention_amd.perlin_attention.attention_state import PerlinAttentionState as PS
         assert torch.equal(sess.image, state.states[PS.PERFORMER].image)
         assert sess.fused_cnn                                  # round 5: conv1 + conv2 + tail + selection + counters in one launch
-        assert torch.equal(sess.export_state().states[PS.CNN].rows_c8, state.states[PS.CNN].rows_c8)   # the ring, by age
+        assert torch.equal(sess.win, state.states[PS.CNN].rows_c8)                                    # the ring, read out by age
+        assert torch.equal(sess.export_state().states[PS.CNN].rows_c8, state.states[PS.CNN].rows_c8)
         assert torch.equal(sess.k_cache[:, :, :T], x) and torch.equal(sess.v_cache[:, :, :T], x)
 
 
