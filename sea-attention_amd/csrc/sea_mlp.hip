@@ -65,7 +65,12 @@ struct MlpParams {
 // PADW: the decoder's split width is not a multiple of 16 (T_M = 96: 24; any T_M % 32 == 0 the reference's grid may ask for,
 // src/main/benchmark_opt_ablation.py:160-186): each split owns HT = ceil(Wd / 16) whole tiles, its rows past Wd are zero
 // weights / zero bias (host packing), they stay out of the LayerNorm statistics and are never stored.
-template <typename T, int NT1, int NT2, int MLP_WAVES, bool STAGE, bool W1S = false, bool PADW = false>
+// PACK (round 5): a wave's 16 rows are 16 CONSECUTIVE (token, head) rows of the flattened (n, t, h) order instead of heads
+// 16 j .. 16 j + 15 of one token.  With H % 16 == 0 the two are the same thing (PACK off: that code is untouched); with H = 40
+// a token's third tile was half empty (2.5 of 3 tiles filled), with H = 12 a quarter of the only tile -- packed, every tile
+// but the launch's last is full.  H % 4 == 0 keeps every group of 4 rows inside one token, so the C8 stores (4 heads x 2
+// splits = one 8-channel block) stay whole blocks; each group just has its own (n, t, block).
+template <typename T, int NT1, int NT2, int MLP_WAVES, bool STAGE, bool W1S = false, bool PADW = false, bool PACK = false>
 __global__ __launch_bounds__(MLP_WAVES * 64) __attribute__((amdgpu_waves_per_eu(MLP_WAVES / 4, MLP_WAVES / 4)))
 void predictor_mlp_kernel(MlpParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -98,18 +103,31 @@ void predictor_mlp_kernel(MlpParams p) {
   const T* w2l = sW2 + lane * 8;                                         // + (ks*(NT2+1) + tile)*512
 
   const int htiles = (p.H + 15) / 16;
-  const int nitems = p.N * p.T * htiles;
+  const int total_rows = p.N * p.T * p.H;                                // (launcher: < 2^31)
+  const int nitems = PACK ? (total_rows + 15) / 16 : p.N * p.T * htiles;
   const int C8 = p.H >> 2;                                               // 8-channel blocks: (H*2)/8
   for (int base = blockIdx.x * MLP_WAVES; base < nitems; base += gridDim.x * MLP_WAVES) {
     // (workgroup-uniform trip count: with W1S every wave joins the barriers of the weight ring, item or not)
     const bool active = base + wv < nitems;
     if (!W1S && !active) continue;
     const int item = active ? base + wv : nitems - 1;
-    const int ht = item % htiles;
-    const int nt_ = item / htiles;
-    const int t = nt_ % p.T, n = nt_ / p.T;
-    const int h = ht * 16 + li;
-    const bool hok = active && h < p.H;
+    int ht = 0, t, n, h;
+    bool hok;
+    if constexpr (PACK) {                                                // this lane's row of the flattened (n, t, h) order
+      const int R = item * 16 + li;
+      hok = active && R < total_rows;
+      const int Rc = hok ? R : 0;
+      const int nt_ = Rc / p.H;
+      h = Rc - nt_ * p.H;
+      n = nt_ / p.T;
+      t = nt_ - n * p.T;
+    } else {
+      ht = item % htiles;
+      const int nt_ = item / htiles;
+      t = nt_ % p.T; n = nt_ / p.T;
+      h = ht * 16 + li;
+      hok = active && h < p.H;
+    }
     const T* xr = reinterpret_cast<const T*>(p.x) + n * p.xs_n + (hok ? h : 0) * p.xs_h + t * p.xs_t + 8 * lg;
 
     // ---- product 1: enc^T = W1 . x^T ------------------------------------------------------------------
@@ -275,6 +293,21 @@ void predictor_mlp_kernel(MlpParams p) {
       for (int i = 0; i < HT; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) *reinterpret_cast<uint32_t*>(tl + (i * 16 + lg * 4 + r) * 16) = outp[i][r];
+      if constexpr (PACK) {
+#pragma unroll
+        for (int c0 = 0; c0 < 4 * WdP; c0 += 64) {
+          const int c = c0 + lane, q = c / Wd, w = c - q * Wd;
+          const bool cin = !PADW || c < 4 * Wd;
+          const uint4 v = *reinterpret_cast<const uint4*>(sTile + (cin ? q * QSTR + w * 16 : 0));
+          const int Rq = item * 16 + 4 * q;                              // first row of group q: its token and 4-head block
+          const bool qv = active && cin && Rq < total_rows;
+          const int Rc = qv ? Rq : 0;
+          const int ntq = Rc / p.H, hq = Rc - ntq * p.H;
+          const int nq = ntq / p.T, tq = ntq - nq * p.T;
+          T* ybq = reinterpret_cast<T*>(p.x_c8) + nq * p.xc8_n + ((int64_t)tq * C8 + (hq >> 2)) * (Wd * 8);
+          if (qv) *reinterpret_cast<uint4*>(ybq + (int64_t)w * 8) = v;
+        }
+      } else {
       T* yb = reinterpret_cast<T*>(p.x_c8) + n * p.xc8_n + ((int64_t)t * C8 + ht * 4) * (Wd * 8);
 #pragma unroll
       for (int c0 = 0; c0 < 4 * WdP; c0 += 64) {
@@ -282,6 +315,7 @@ void predictor_mlp_kernel(MlpParams p) {
         const bool cin = !PADW || c < 4 * Wd;
         const uint4 v = *reinterpret_cast<const uint4*>(sTile + (cin ? q * QSTR + w * 16 : 0));
         if (active && cin && ht * 4 + q < C8) *reinterpret_cast<uint4*>(yb + (int64_t)c * 8) = v;
+      }
       }
     } else if (hok) {   // channel = 2h + split: this lane's pair is bytes [4*(h%4), +4) of block h/4, pixel w
       T* yb = reinterpret_cast<T*>(p.x_c8) + n * p.xc8_n + ((int64_t)t * C8 + (h >> 2)) * (Wd * 8) + (h & 3) * 2;
@@ -303,11 +337,13 @@ using namespace sea;
 
 template <typename T>
 static int launch_mlp(const MlpParams& p, int nt1, int nt2, hipStream_t s) {
-  const int64_t nitems = (int64_t)p.N * p.T * ((p.H + 15) / 16);
+  const bool pack = p.H % 16 != 0;                 // rows packed across tokens (the kernel's PACK): every tile full
+  const int64_t nitems = pack ? ((int64_t)p.N * p.T * p.H + 15) / 16 : (int64_t)p.N * p.T * ((p.H + 15) / 16);
   int rc = SEA_EUNSUPPORTED;
   const bool padw = p.Wd != nt2 * 8;
 #define SEA_MLP(A, B) do { if (padw) SEA_MLP_(A, B, true); else SEA_MLP_(A, B, false); } while (0)
-#define SEA_MLP_(A, B, PW)                                                                                          \
+#define SEA_MLP_(A, B, PW) do { if (pack) SEA_MLP__(A, B, PW, true); else SEA_MLP__(A, B, PW, false); } while (0)
+#define SEA_MLP__(A, B, PW, PK)                                                                                          \
   do {                                                                                                              \
     constexpr int NW = (A + B <= 16) ? 16 : 8;                                                                      \
     const size_t wbytes = ((size_t)p.KS1 * A + (size_t)(A / 2) * (B + 1)) * 1024 + (size_t)((3 * A * 16 + 2 * B * 16 + 2 + 3) & ~3) * sizeof(float); \
@@ -319,11 +355,11 @@ static int launch_mlp(const MlpParams& p, int nt1, int nt2, hipStream_t s) {
     if (blocks > 256) blocks = 256;               /* persistent: one workgroup per CU keeps the weights in LDS */   \
     static DevOnce once;                                                                                            \
     if (once.first()) {                                                                                             \
-      SEA_MAX_LDS((predictor_mlp_kernel<T, A, B, NW, true, false, PW>), 160 * 1024);                                \
-      SEA_MAX_LDS((predictor_mlp_kernel<T, A, B, NW, false, false, PW>), 160 * 1024);                               \
+      SEA_MAX_LDS((predictor_mlp_kernel<T, A, B, NW, true, false, PW, PK>), 160 * 1024);                            \
+      SEA_MAX_LDS((predictor_mlp_kernel<T, A, B, NW, false, false, PW, PK>), 160 * 1024);                           \
     }                                                                                                               \
-    if (stage) hipLaunchKernelGGL((predictor_mlp_kernel<T, A, B, NW, true, false, PW>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);  \
-    else hipLaunchKernelGGL((predictor_mlp_kernel<T, A, B, NW, false, false, PW>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);       \
+    if (stage) hipLaunchKernelGGL((predictor_mlp_kernel<T, A, B, NW, true, false, PW, PK>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);  \
+    else hipLaunchKernelGGL((predictor_mlp_kernel<T, A, B, NW, false, false, PW, PK>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);       \
     rc = SEA_OK;                                                                                                    \
   } while (0)
   if (nt1 == 16 && nt2 == 8 && !padw) {                               // d = 128: encoder weights streamed through a two-slot LDS ring
@@ -334,8 +370,12 @@ static int launch_mlp(const MlpParams& p, int nt1, int nt2, hipStream_t s) {
       int64_t blocks = (nitems + NW - 1) / NW;
       if (blocks > 256) blocks = 256;
       static DevOnce once;
-      if (once.first()) SEA_MAX_LDS((predictor_mlp_kernel<T, A, B, NW, true, true>), 160 * 1024);
-      hipLaunchKernelGGL((predictor_mlp_kernel<T, A, B, NW, true, true>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);
+      if (once.first()) {
+        SEA_MAX_LDS((predictor_mlp_kernel<T, A, B, NW, true, true, false, false>), 160 * 1024);
+        SEA_MAX_LDS((predictor_mlp_kernel<T, A, B, NW, true, true, false, true>), 160 * 1024);
+      }
+      if (pack) hipLaunchKernelGGL((predictor_mlp_kernel<T, A, B, NW, true, true, false, true>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);
+      else hipLaunchKernelGGL((predictor_mlp_kernel<T, A, B, NW, true, true, false, false>), dim3((unsigned)blocks), dim3(NW * 64), lds, s, p);
       rc = SEA_OK;
     }
   } else if (nt1 == 8 && nt2 == 8) SEA_MLP(8, 8);
@@ -347,6 +387,7 @@ static int launch_mlp(const MlpParams& p, int nt1, int nt2, hipStream_t s) {
   else if (nt1 == 8 && nt2 == 14) SEA_MLP(8, 14);
   else if (nt1 == 8 && nt2 == 16) SEA_MLP(8, 16);
   else if (nt1 == 10 && nt2 == 8 && !padw) SEA_MLP_(10, 8, false);
+#undef SEA_MLP__
 #undef SEA_MLP_
 #undef SEA_MLP
   return rc;
@@ -365,7 +406,7 @@ extern "C" int sea_predictor_mlp(const void* x, int dtype, int64_t N, int64_t H,
   SEA_REQUIRE(x_strides[0] % 8 == 0 && x_strides[1] % 8 == 0 && x_strides[2] % 8 == 0 &&
                   (((uintptr_t)x | (uintptr_t)w1_packed | (uintptr_t)w2_packed | (uintptr_t)x_c8 | (uintptr_t)tpred) & 15) == 0,
               SEA_EUNSUPPORTED, "%s: 16-byte alignment", nm);
-  SEA_REQUIRE(N * T * ((H + 15) / 16) < (1ll << 31), SEA_EUNSUPPORTED, "%s: too many rows", nm);
+  SEA_REQUIRE(N * T * ((H + 15) / 16) * 16 < (1ll << 31), SEA_EUNSUPPORTED, "%s: too many rows", nm);
   MlpParams p;
   p.x = x; p.xs_n = x_strides[0]; p.xs_h = x_strides[1]; p.xs_t = x_strides[2];
   p.w1p = w1_packed; p.w2p = w2_packed; p.vec = vectors;
