@@ -85,6 +85,9 @@ def parse_args(argv=None):
                     help="positions of the generation leg (batch 1 and the headline batch) after the timed steps; 0 = off (the "
                          "profiling scripts pass 0: its one-row launches share kernel names with the layer's and would dilute a "
                          "profiler's per-kernel averages)")
+    ap.add_argument("--seq-len", type=int, default=0,
+                    help="override the workload's sequence length T (profiling the long-context shape: --workload opt-125m --batch 1 "
+                         "--seq-len 32768); 0 = the workload's own")
     ap.add_argument("--repeats", type=int, default=4,
                     help="after the timed K steps, time K steps this many more times and report min / median / max of ms_per_step "
                          "(`repeats`); `value` stays the first timed region")
@@ -701,11 +704,11 @@ def main(argv=None):
     from sea_attention_amd.perlin_attention import ops
     _lib.load(build_if_missing=True)
 
-    w = WORKLOADS[args.workload]
+    w = dict(WORKLOADS[args.workload], **({"T": args.seq_len} if args.seq_len else {}))
     H, d, T, T_M, k = w["H"], w["d"], w["T"], w["T_M"], w["k"]
     NB = args.batch
     lb = LayerBench(args.workload, NB, args.dtype, dev, ctx_dtype_name="fp32" if args.context_dtype == "fp32" else args.dtype,
-                    inspect_padding=args.inspect_padding, seed_offset=rank)
+                    inspect_padding=args.inspect_padding, seed_offset=rank, override={"T": args.seq_len} if args.seq_len else None)
     dtype = lb.dtype
     layer, q, kk, v, mask = lb.layer, lb.q, lb.k, lb.v, lb.mask
     bench = S.get_bench()

@@ -753,24 +753,40 @@ __global__ __launch_bounds__(TK_THREADS) void predictor_tail_select_gen_kernel(T
 // ---- crow = exclusive scan of row_nnz ------------------------------------------------------------
 template <typename I>
 __global__ __launch_bounds__(1024) void row_scan_kernel(const int32_t* row_nnz, int T_dst, I* crow) {
-  __shared__ int s_w[16];
-  const int n = blockIdx.x;
+  // 1024 rows per pass (coalesced loads and stores).  Round 5: the row totals of the next PER passes are requested together,
+  // so a pass is a wave scan + two barriers instead of a dependent memory round trip + the same (one 32768-token sequence:
+  // 32 round trips, 27 us of a 1.38 ms step at N = 1; a per-thread run of consecutive rows measured worse, 33 us: its
+  // loads and stores touch 64 lines per instruction).
+  constexpr int PER = 16;
+  __shared__ int s_w[2][16];                                   // two sets: a pass needs ONE barrier (pass j + 2 rewrites set j & 1
+  const int n = blockIdx.x;                                    // only after every thread has passed barrier j + 1, i.e. read it)
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int32_t* src = row_nnz + (int64_t)n * T_dst;
   I* dst = crow + (int64_t)n * (T_dst + 1);
   long long carry = 0;
-  for (int t0 = 0; t0 < T_dst; t0 += 1024) {
-    const int t = t0 + tid;
-    const int v = t < T_dst ? src[t] : 0;
-    const int incl = wave_incl_scan(v);
-    if (lane == 63) s_w[w] = incl;
-    __syncthreads();
-    int base = 0, tot = 0;
+  for (int t0 = 0; t0 < T_dst; t0 += 1024 * PER) {
+    int vv[PER];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { const int x = s_w[i]; if (i < w) base += x; tot += x; }
-    __syncthreads();
-    if (t < T_dst) dst[t] = (I)(carry + base + incl - v);
-    carry += tot;
+    for (int j = 0; j < PER; ++j) {
+      const int t = t0 + j * 1024 + tid;
+      vv[j] = t < T_dst ? src[t] : 0;
+    }
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      if (t0 + j * 1024 < T_dst) {                               // block-uniform
+        const int t = t0 + j * 1024 + tid;
+        const int v = vv[j];
+        const int incl = wave_incl_scan(v);
+        if (lane == 63) s_w[j & 1][w] = incl;
+        __syncthreads();
+        int base = 0, tot = 0;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { const int x = s_w[j & 1][i]; if (i < w) base += x; tot += x; }
+        if (t < T_dst) dst[t] = (I)(carry + base + incl - v);
+        carry += tot;
+      }
+    }
+    __syncthreads();                                             // (PER is even: the next span starts on set 0 again)
   }
   if (tid == 0) dst[T_dst] = (I)carry;
 }
