@@ -36,8 +36,9 @@ extern "C" {
  *      state image at that boundary;  round 4: sea_predictor_mlp's w2_packed / vectors pad every decoder half to whole
  *      16-row tiles (identical for Wd % 16 == 0), sea_predictor_tail_select accepts probs = NULL and any T_m % 4 == 0 <= 512
  *   3  round 5: new entry points the binding requires (sea_causal_conv_c8_z, sea_predictor_tail_z, sea_predictor_tail_select_z,
- *      sea_causal_conv_c8_f32, sea_decode_cnn_tail_select);
- *      no existing signature changed */
+ *      sea_causal_conv_c8_f32, sea_decode_cnn_tail_select, sea_predictor_tail_consts); sea_predictor_tail_select / _at take a
+ *      trailing `consts_tab` argument (NULL = the round-4 behaviour)
+ *      */
 #define SEA_ABI_VERSION 3
 
 enum sea_dtype { SEA_F32 = 0, SEA_F16 = 1, SEA_BF16 = 2 };
@@ -328,7 +329,15 @@ int sea_predictor_tail_select(const void* y, int dtype, int64_t N, int64_t C, in
                               const void* conv_w16, int64_t Cp, const void* gamma, const void* beta, float eps,
                               void* probs, void* scores, const int32_t* keep, int64_t keep_stride_n,
                               int64_t T_src, int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz,
-                              int32_t* head_off, sea_stream_t stream);
+                              int32_t* head_off, const uint32_t* consts_tab, sea_stream_t stream);
+
+/* The per-pixel constants of the tail -- for every output pixel the <= 3 taps of the area resize, gamma, beta: (W4, up, T_m,
+ * gamma, beta) only, the same for every row -- computed ONCE into tab (3 * 256 uint32, 16-byte aligned) instead of by every
+ * row's workgroup (round 5; T_m = 256).  The `consts_tab` argument of sea_predictor_tail_select / _at / _z and
+ * sea_decode_cnn_tail_select takes it (NULL = each row computes the table itself, as before): -3.5 % of the launch at
+ * OPT-1.3B x 8, -8 % at H = 12. */
+int sea_predictor_tail_consts(int dtype, int64_t W4, int64_t up, int64_t T_m, const void* gamma, const void* beta,
+                              uint32_t* tab, sea_stream_t stream);
 
 /* The same launch fed with z (N, T, H, W4) fp32 = the 1x1 convolution's output from sea_causal_conv_c8_z (round 5): the "z
  * tile" of a row -- loads of y and of the weights, MFMAs, LDS stores: a third of a row's life in this issue-bound kernel --
@@ -338,7 +347,7 @@ int sea_predictor_tail_select_z(const float* z, int dtype, int64_t N, int64_t H,
                                 int64_t T_m, const float* conv_b, const void* gamma, const void* beta, float eps,
                                 void* probs, void* scores, const int32_t* keep, int64_t keep_stride_n, int64_t T_src,
                                 int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz, int32_t* head_off,
-                                sea_stream_t stream);
+                                const uint32_t* consts_tab, sea_stream_t stream);
 
 /* A decoding step's predictor CNN + tail + selection + state advance in ONE launch (round 5; perlin_attention/decode.py).
  * A graph-replayed position used to run conv1, conv2 (each over the session's whole 25-row window), sea_predictor_tail_select_at
@@ -366,7 +375,7 @@ int sea_decode_cnn_tail_select(const void* x_new, void* x_ring, void* y1_ring, v
                                const void* beta, float eps, void* probs, const int32_t* keep_table, int32_t* counters,
                                int32_t* ticket, int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz,
                                int32_t* head_off, int32_t* crow_out, int32_t* col, int64_t col_stride_n, int64_t z_cap,
-                               int64_t T_cap, sea_stream_t stream);
+                               int64_t T_cap, const uint32_t* consts_tab, sea_stream_t stream);
 
 /* Causal cumulative average out[n,h,t,:] = sum_{s<=t} v[n,h,s,:] / (t+1), fp32 accumulation.
  * Replaces `avg_v.cumsum(-2) / arange(1..T)` (attention.py:1220-1222).  out (N,H,T,D) contiguous. */
@@ -532,7 +541,7 @@ int sea_predictor_tail_select_at(const void* y, int dtype, int64_t N, int64_t C,
                                  const void* conv_w16, int64_t Cp, const void* gamma, const void* beta, float eps,
                                  void* probs, void* scores, const int32_t* keep_table, const int32_t* t_src_dev,
                                  int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz, int32_t* head_off,
-                                 int32_t* crow_out,
+                                 int32_t* crow_out, const uint32_t* consts_tab,
                                  sea_stream_t stream);
 int sea_csr_emit_at(const uint32_t* bits, const void* crow, int64_t N, int64_t H, int64_t T_dst, int64_t T_m,
                     const int32_t* t_src_dev, int64_t T_cap, int is_causal, int max_k, void* col, int idx_bytes,

@@ -51,20 +51,21 @@ _SIGNATURES = {
     "sea_cumavg": ([ptr, c_int, i64, i64, i64, i64, _i64p, ptr, ptr], c_int),
     "sea_cumavg_sliced": ([ptr, c_int, i64, i64, i64, i64, _i64p, ptr, i64, ptr, i64, ptr], c_int),
     "sea_predictor_tail_select": ([ptr, c_int, i64, i64, i64, i64, i64, i64, i64, _i64p, ptr, ptr, i64, ptr, ptr,
-                                   ctypes.c_float, ptr, ptr, ptr, i64, i64, c_int, c_int, ptr, ptr, ptr, ptr], c_int),
+                                   ctypes.c_float, ptr, ptr, ptr, i64, i64, c_int, c_int, ptr, ptr, ptr, ptr, ptr], c_int),
+    "sea_predictor_tail_consts": ([c_int, i64, i64, i64, ptr, ptr, ptr, ptr], c_int),
     "sea_predictor_mlp": ([ptr, c_int, i64, i64, i64, i64, _i64p, i64, i64, ptr, ptr, ptr, ctypes.c_float,
                            ctypes.c_float, ptr, i64, ptr, ptr, ptr, ptr], c_int),
     "sea_split_layernorm_c8": ([ptr, c_int, i64, i64, i64, i64, i64, ptr, ptr, ctypes.c_float, ptr, ptr], c_int),
     "sea_causal_conv_c8": ([ptr, c_int, i64, i64, i64, i64, i64, ptr, i64, ptr, c_int, c_int, c_int, c_int, ptr, ptr], c_int),
     "sea_decode_cnn_tail_select": ([ptr, ptr, ptr, ptr, c_int, i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ptr, i64, c_int, c_int,
                                     ptr, ptr, i64, ptr, ptr, ctypes.c_float, ptr, ptr, ptr, ptr, c_int, c_int, ptr, ptr, ptr, ptr,
-                                    ptr, i64, i64, i64, ptr], c_int),
+                                    ptr, i64, i64, i64, ptr, ptr], c_int),
     "sea_causal_conv_c8_f32": ([ptr, i64, i64, i64, i64, i64, ptr, i64, ptr, c_int, c_int, c_int, c_int, ptr, ptr], c_int),
     "sea_causal_conv_c8_z": ([ptr, c_int, i64, i64, i64, i64, i64, ptr, i64, ptr, c_int, c_int, c_int, c_int, ptr,
                               ptr, i64, ptr, i64, ptr, ptr], c_int),
     "sea_predictor_tail_z": ([ptr, c_int, i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ctypes.c_float, ptr, ptr, ptr], c_int),
     "sea_predictor_tail_select_z": ([ptr, c_int, i64, i64, i64, i64, i64, i64, ptr, ptr, ptr, ctypes.c_float, ptr, ptr,
-                                     ptr, i64, i64, c_int, c_int, ptr, ptr, ptr, ptr], c_int),
+                                     ptr, i64, i64, c_int, c_int, ptr, ptr, ptr, ptr, ptr], c_int),
     "sea_performer_causal": ([ptr, ptr, ptr, ptr, c_int, ptr, i64, i64, i64, i64, i64, _i64p, _i64p, _i64p, i64, ptr, ptr, ptr], c_int),
     "sea_performer_state_bytes": ([i64, i64, i64, i64, c_int], i64),
     "sea_performer_chunk_rows": ([i64, i64, c_int], i64),
@@ -74,7 +75,7 @@ _SIGNATURES = {
     "sea_performer_causal_step_at": ([ptr, ptr, ptr, ptr, c_int, ptr, i64, i64, i64, i64, i64, _i64p, _i64p, _i64p, i64, ptr, ptr,
                                       ptr, ptr, i64, ptr, ptr], c_int),
     "sea_predictor_tail_select_at": ([ptr, c_int, i64, i64, i64, i64, i64, i64, i64, _i64p, ptr, ptr, i64, ptr, ptr,
-                                      ctypes.c_float, ptr, ptr, ptr, ptr, c_int, c_int, ptr, ptr, ptr, ptr, ptr], c_int),
+                                      ctypes.c_float, ptr, ptr, ptr, ptr, c_int, c_int, ptr, ptr, ptr, ptr, ptr, ptr], c_int),
     "sea_decode_stage": ([ptr, ptr, ptr, c_int, i64, i64, i64, _i64p, _i64p, _i64p, ptr, ptr, i64, ptr, ptr], c_int),
     "sea_c8_window_shift": ([ptr, i64, i64, i64, ptr, ptr], c_int),
     "sea_csr_emit_at": ([ptr, ptr, i64, i64, i64, i64, ptr, i64, c_int, c_int, ptr, c_int, i64, i64, ptr], c_int),

@@ -423,6 +423,13 @@ __global__ __launch_bounds__(1024) void cumavg_vec_kernel(const T* v, T* out, in
   }
 }
 
+// the per-pixel constants of the tail (tail_consts_fill: taps of the area resize, gamma, beta) into GLOBAL memory, once per
+// weight set -- the fused tail + selection kernels then read a lane's 12 words with three 16-byte loads instead of computing
+// the table for every row (round 5)
+template <typename T> __global__ __launch_bounds__(256) void tail_consts_kernel(TailParams p, uint32_t* tab, int TMP) {
+  tail_consts_fill<T>(p, tab, TMP);
+}
+
 }  // namespace sea
 
 using namespace sea;
@@ -540,7 +547,7 @@ extern "C" int sea_predictor_tail(const void* y, int dtype, int64_t N, int64_t C
   p.y = y; p.w4 = conv_w; p.b4 = conv_b; p.gamma = gamma; p.beta = beta; p.probs = probs; p.scores = scores; p.eps = eps;
   p.N = (int)N; p.C = (int)C; p.H = (int)H; p.T = (int)T; p.W4 = (int)W4; p.UP = (int)up; p.T_M = (int)T_m;
   p.ys_n = y_strides[0]; p.ys_c = y_strides[1]; p.ys_t = y_strides[2]; p.ys_w = y_strides[3]; p.ys_c8 = y_strides[4];
-  p.w16 = conv_w16; p.Cp = (int)Cp; p.z = nullptr;
+  p.w16 = conv_w16; p.Cp = (int)Cp; p.z = nullptr; p.tab = nullptr;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)(N * T));
   int rc;
@@ -551,6 +558,24 @@ extern "C" int sea_predictor_tail(const void* y, int dtype, int64_t N, int64_t C
   else if (dtype == SEA_F16) rc = launch_tail<__half>(p, lds, grid, s);
   else rc = launch_tail<__hip_bfloat16>(p, lds, grid, s);
   SEA_REQUIRE(rc == SEA_OK, rc, "%s: unsupported T_m", nm);
+  SEA_CHECK_LAUNCH(nm);
+  return SEA_OK;
+}
+
+extern "C" int sea_predictor_tail_consts(int dtype, int64_t W4, int64_t up, int64_t T_m, const void* gamma, const void* beta,
+                                         uint32_t* tab, sea_stream_t stream) {
+  const char* nm = "sea_predictor_tail_consts";
+  SEA_REQUIRE(gamma && beta && tab, SEA_EINVAL, "%s: null pointer", nm);
+  SEA_REQUIRE(dtype == SEA_F16 || dtype == SEA_BF16, SEA_EUNSUPPORTED, "%s: 16-bit maps only (dtype %d)", nm, dtype);
+  SEA_REQUIRE(W4 > 0 && up > 0 && T_m == 256 && W4 * up == T_m && W4 + 1 < 1024, SEA_EUNSUPPORTED,
+              "%s: the table serves the T_m = 256 kernels (3 x 256 words)", nm);
+  TailParams p;
+  p.y = nullptr; p.w4 = nullptr; p.b4 = nullptr; p.gamma = gamma; p.beta = beta; p.probs = nullptr; p.scores = nullptr; p.eps = 0.f;
+  p.N = 1; p.C = 0; p.H = 1; p.T = 1; p.W4 = (int)W4; p.UP = (int)up; p.T_M = (int)T_m;
+  p.ys_n = p.ys_c = p.ys_t = p.ys_w = p.ys_c8 = 0; p.w16 = nullptr; p.Cp = 0; p.z = nullptr; p.tab = nullptr;
+  hipStream_t s = (hipStream_t)stream;
+  if (dtype == SEA_F16) hipLaunchKernelGGL((tail_consts_kernel<__half>), dim3(1), dim3(256), 0, s, p, tab, 256);
+  else hipLaunchKernelGGL((tail_consts_kernel<__hip_bfloat16>), dim3(1), dim3(256), 0, s, p, tab, 256);
   SEA_CHECK_LAUNCH(nm);
   return SEA_OK;
 }
@@ -569,7 +594,7 @@ extern "C" int sea_predictor_tail_z(const float* z, int dtype, int64_t N, int64_
   TailParams p;
   p.y = nullptr; p.w4 = nullptr; p.b4 = conv_b; p.gamma = gamma; p.beta = beta; p.probs = probs; p.scores = scores; p.eps = eps;
   p.N = (int)N; p.C = 0; p.H = (int)H; p.T = (int)T; p.W4 = (int)W4; p.UP = (int)up; p.T_M = (int)T_m;
-  p.ys_n = p.ys_c = p.ys_t = p.ys_w = p.ys_c8 = 0; p.w16 = nullptr; p.Cp = 0; p.z = z;
+  p.ys_n = p.ys_c = p.ys_t = p.ys_w = p.ys_c8 = 0; p.w16 = nullptr; p.Cp = 0; p.z = z; p.tab = nullptr;
   hipStream_t s = (hipStream_t)stream;
   const int rc = dtype == SEA_F16 ? launch_tail_mfma<__half>(p, dim3((unsigned)(N * T)), s) : launch_tail_mfma<__hip_bfloat16>(p, dim3((unsigned)(N * T)), s);
   SEA_REQUIRE(rc == SEA_OK, rc, "%s: unsupported T_m / H for the tail's LDS plan", nm);

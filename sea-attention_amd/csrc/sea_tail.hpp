@@ -20,6 +20,7 @@ struct TailParams {
   int64_t ys_c8;                   // stride between blocks of 8 channels (8*ys_c for plain 4-D layouts; W*8 for C8)
   const void* w16;   // MFMA variant: (HP16, Cp) 16-bit row-major copy of the conv weight, zero padded
   int Cp;            // channels padded to a multiple of 32
+  const uint32_t* tab;  // optional [3][64 E] words in global memory: tail_consts_fill's table, computed once (not per row)
   const float* z;    // optional (N, T, H, W4) fp32: the 1x1 conv's output, already computed (sea_causal_conv_c8_z's epilogue);
                      // y / w16 are then unused and the z tile is a copy into LDS
 };
@@ -193,6 +194,25 @@ template <typename T, int E>
 struct TailRow {
   float g[E], be[E], rcnt[E];
   int src[E][3];   // index into the z row: pixel, W4 (bias: zero-padded border) or W4+1 (unused tap)
+
+  // the same from a table in GLOBAL memory (computed once per weight set): three 16-byte loads per lane, no LDS, no barrier
+  __device__ __forceinline__ void load_global(const uint32_t* tab, int lane) {
+    constexpr int TMP = 64 * E;
+    uint32_t pk[E];
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+      pk[e] = tab[lane * E + e];
+      g[e] = __uint_as_float(tab[TMP + lane * E + e]);
+      be[e] = __uint_as_float(tab[2 * TMP + lane * E + e]);
+    }
+#pragma unroll
+    for (int e = 0; e < E; ++e) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) src[e][k] = (int)__builtin_amdgcn_ubfe(pk[e], 10 * k, 10);
+      const uint32_t cnt = pk[e] >> 30;
+      rcnt[e] = cnt == 1 ? 1.0f : cnt == 2 ? 0.5f : cnt == 3 ? (1.0f / 3.0f) : 0.f;
+    }
+  }
 
   // after the barrier that publishes tail_consts_fill's table
   __device__ __forceinline__ void load(const uint32_t* s_tab, int lane) {

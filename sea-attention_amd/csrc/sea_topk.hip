@@ -608,11 +608,12 @@ __device__ __forceinline__ void tail_select_row(const TailParams& tp, const Topk
   unsigned long long _tprev = __builtin_amdgcn_s_memtime();
 #endif
   uint32_t* s_tab = reinterpret_cast<uint32_t*>(s_z + ((tp.H + 15) / 16) * 16 * LDZ);   // per-pixel constants [3][64 E]
-  tail_z_tile<T>(tp, s_z, n, t);
-  tail_consts_fill<T>(tp, s_tab, 64 * E);
-  __syncthreads();
   TailRow<T, E> tr;
-  tr.load(s_tab, lane);
+  if (tp.tab) tr.load_global(tp.tab, lane);                        // (block-uniform) the table was computed once per weight set
+  tail_z_tile<T>(tp, s_z, n, t);
+  if (!tp.tab) tail_consts_fill<T>(tp, s_tab, 64 * E);
+  __syncthreads();
+  if (!tp.tab) tr.load(s_tab, lane);
   STAMP(8);   // z tile (MFMA) + per-pixel constants
   uint32_t key[EPT / 2];                                           // two 16-bit keys per register (select_body, K16)
   const int mine = FULL ? R : max(0, (tp.H - wv + 3) / 4);         // heads wv, wv + 4, ... of this wave (wave-uniform)
@@ -659,11 +660,12 @@ __global__ __launch_bounds__(TK_THREADS, EPT <= 16 ? 7 : EPT == 32 ? 7 : EPT == 
   unsigned long long _tprev = __builtin_amdgcn_s_memtime();
 #endif
   uint32_t* s_tab = reinterpret_cast<uint32_t*>(s_z + ((tp.H + 15) / 16) * 16 * LDZ);   // per-pixel constants [3][64 E]
-  tail_z_tile<T>(tp, s_z, n, t);
-  tail_consts_fill<T>(tp, s_tab, 64 * E);
-  __syncthreads();
   TailRow<T, E> tr;
-  tr.load(s_tab, lane);
+  if (tp.tab) tr.load_global(tp.tab, lane);                        // (block-uniform) the table was computed once per weight set
+  tail_z_tile<T>(tp, s_z, n, t);
+  if (!tp.tab) tail_consts_fill<T>(tp, s_tab, 64 * E);
+  __syncthreads();
+  if (!tp.tab) tr.load(s_tab, lane);
   STAMP(8);   // z tile (MFMA) + per-pixel constants
   uint32_t key[EPT / 2];                                           // two 16-bit keys per register (select_body, K16)
   const int mine = FULL ? R : max(0, (tp.H - wv + 3) / 4);         // heads wv, wv + 4, ... of this wave (wave-uniform)
@@ -1231,7 +1233,7 @@ static int tail_select_common(const char* nm, const float* z, const void* y, int
                               const void* conv_w16, int64_t Cp, const void* gamma, const void* beta, float eps,
                               void* probs, void* scores, const int32_t* keep, int64_t keep_stride_n,
                               int64_t T_src, const int32_t* t_src_dev, int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz,
-                              int32_t* head_off, int32_t* crow1, sea_stream_t stream) {
+                              int32_t* head_off, int32_t* crow1, const uint32_t* consts_tab, sea_stream_t stream) {
   SEA_REQUIRE(crow1 == nullptr || T == 1, SEA_EINVAL, "%s: crow_out goes with one row per batch item (T = %lld)", nm, (long long)T);
   SEA_REQUIRE((z || (y && y_strides && conv_w16)) && conv_b && gamma && beta && keep && bits && row_nnz && head_off, SEA_EINVAL,
               "%s: null pointer", nm);
@@ -1257,6 +1259,7 @@ static int tail_select_common(const char* nm, const float* z, const void* y, int
   tp.ys_n = tp.ys_c = tp.ys_t = tp.ys_w = tp.ys_c8 = 0;
   if (!z) { tp.ys_n = y_strides[0]; tp.ys_c = y_strides[1]; tp.ys_t = y_strides[2]; tp.ys_w = y_strides[3]; tp.ys_c8 = y_strides[4]; }
   tp.w16 = conv_w16; tp.Cp = (int)Cp; tp.z = z;
+  tp.tab = (consts_tab != nullptr && tm256 && (((uintptr_t)consts_tab) & 15) == 0) ? consts_tab : nullptr;   // (the register-resident form reads it)
   TopkParams p;
   p.src = nullptr; p.sn = H * T * T_m; p.sh = T * T_m; p.st = T_m;        // (the packed-key selection never re-reads the map)
   p.H = (int)H; p.T_dst = (int)T; p.T_m = (int)T_m; p.T_src = (int)T_src;
@@ -1278,10 +1281,10 @@ extern "C" int sea_predictor_tail_select(const void* y, int dtype, int64_t N, in
                                          const void* conv_w16, int64_t Cp, const void* gamma, const void* beta, float eps,
                                          void* probs, void* scores, const int32_t* keep, int64_t keep_stride_n,
                                          int64_t T_src, int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz,
-                                         int32_t* head_off, sea_stream_t stream) {
+                                         int32_t* head_off, const uint32_t* consts_tab, sea_stream_t stream) {
   return tail_select_common("sea_predictor_tail_select", nullptr, y, dtype, N, C, H, T, W4, up, T_m, y_strides, conv_b, conv_w16, Cp, gamma,
                             beta, eps, probs, scores, keep, keep_stride_n, T_src, nullptr, is_causal, max_k, bits, row_nnz,
-                            head_off, nullptr, stream);
+                            head_off, nullptr, consts_tab, stream);
 }
 
 // The same launch fed with z = the 1x1 convolution's output (N, T, H, W4) fp32 as sea_causal_conv_c8_z's epilogue writes it:
@@ -1290,11 +1293,11 @@ extern "C" int sea_predictor_tail_select_z(const float* z, int dtype, int64_t N,
                                            int64_t T_m, const float* conv_b, const void* gamma, const void* beta, float eps,
                                            void* probs, void* scores, const int32_t* keep, int64_t keep_stride_n, int64_t T_src,
                                            int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz, int32_t* head_off,
-                                           sea_stream_t stream) {
+                                           const uint32_t* consts_tab, sea_stream_t stream) {
   SEA_REQUIRE(z, SEA_EINVAL, "sea_predictor_tail_select_z: null pointer");
   return tail_select_common("sea_predictor_tail_select_z", z, nullptr, dtype, N, 0, H, T, W4, up, T_m, nullptr, conv_b, nullptr, 0,
                             gamma, beta, eps, probs, scores, keep, keep_stride_n, T_src, nullptr, is_causal, max_k, bits, row_nnz,
-                            head_off, nullptr, stream);
+                            head_off, nullptr, consts_tab, stream);
 }
 
 // Decode form (a step captured as a HIP graph): the T new rows are the LAST rows of sequences of *t_src_dev tokens (device
@@ -1304,11 +1307,11 @@ extern "C" int sea_predictor_tail_select_at(const void* y, int dtype, int64_t N,
                                             const void* conv_w16, int64_t Cp, const void* gamma, const void* beta, float eps,
                                             void* probs, void* scores, const int32_t* keep_table, const int32_t* t_src_dev,
                                             int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz, int32_t* head_off,
-                                            int32_t* crow_out, sea_stream_t stream) {
+                                            int32_t* crow_out, const uint32_t* consts_tab, sea_stream_t stream) {
   SEA_REQUIRE(t_src_dev, SEA_EINVAL, "sea_predictor_tail_select_at: null pointer");
   return tail_select_common("sea_predictor_tail_select_at", nullptr, y, dtype, N, C, H, T, W4, up, T_m, y_strides, conv_b, conv_w16, Cp,
                             gamma, beta, eps, probs, scores, keep_table, 0, T, t_src_dev, is_causal, max_k, bits, row_nnz,
-                            head_off, crow_out, stream);
+                            head_off, crow_out, consts_tab, stream);
 }
 
 // One launch for a decoding step's predictor CNN + tail + selection + state advance (DecodeCnnParams above; round 5).
@@ -1346,7 +1349,7 @@ extern "C" int sea_decode_cnn_tail_select(const void* x_new, void* x_ring, void*
                                           const void* beta, float eps, void* probs, const int32_t* keep_table, int32_t* counters,
                                           int32_t* ticket, int is_causal, int max_k, uint32_t* bits, int32_t* row_nnz,
                                           int32_t* head_off, int32_t* crow_out, int32_t* col, int64_t col_stride_n, int64_t z_cap,
-                                          int64_t T_cap, sea_stream_t stream) {
+                                          int64_t T_cap, const uint32_t* consts_tab, sea_stream_t stream) {
   const char* nm = "sea_decode_cnn_tail_select";
   SEA_REQUIRE(col == nullptr || (C <= 64 && col_stride_n >= z_cap && z_cap > 0 && T_cap > 0 && H * T_cap < (1ll << 31)), SEA_EUNSUPPORTED,
               "%s: the in-launch emit serves C <= 64 channels (beyond that the weight image leaves no LDS for it: pass col = NULL "
@@ -1371,6 +1374,7 @@ extern "C" int sea_decode_cnn_tail_select(const void* x_new, void* x_ring, void*
   tp.N = (int)N; tp.C = (int)C; tp.H = (int)H; tp.T = 1; tp.W4 = (int)W4; tp.UP = 4; tp.T_M = 256;
   tp.ys_n = C * W4; tp.ys_c = 1; tp.ys_t = 0; tp.ys_w = 8; tp.ys_c8 = W4 * 8;          // one C8 row per batch item
   tp.w16 = conv_w16; tp.Cp = (int)Cp; tp.z = nullptr;
+  tp.tab = (consts_tab != nullptr && (((uintptr_t)consts_tab) & 15) == 0) ? consts_tab : nullptr;
   TopkParams p;
   p.src = nullptr; p.sn = H * 256; p.sh = 256; p.st = 256;
   p.H = (int)H; p.T_dst = 1; p.T_m = 256; p.T_src = 1;

@@ -205,6 +205,22 @@ def _tail_pack(conv_w, conv_b, ln_w, ln_b, dt, device):
     return _cached("tail", (conv_w, conv_b, ln_w, ln_b), dt, build)
 
 
+def _tail_consts(ln_w: torch.Tensor, ln_b: torch.Tensor, up: int, T_m: int, dt, device):
+    """The tail's per-pixel constants (taps of the area resize, gamma, beta: `sea_predictor_tail_consts`) as a device table,
+    cached with the LayerNorm weights; None for shapes the table does not serve (T_m != 256, fp32 maps)."""
+    if T_m != 256 or dt not in (torch.float16, torch.bfloat16) or T_m % up:
+        return None
+
+    def build():
+        g, b = ln_w.to(dt).contiguous(), ln_b.to(dt).contiguous()
+        tab = torch.empty((3 * 256,), dtype=torch.int32, device=device)
+        with torch.cuda.device(device):
+            _lib.check(_lib.load().sea_predictor_tail_consts(_lib.dtype_code(dt), T_m // up, up, T_m, _p(g), _p(b), _p(tab),
+                                                             _lib.stream_ptr()), "sea_predictor_tail_consts")
+        return (tab, g, b)
+    return _cached(f"tailtab{up}x{T_m}", (ln_w, ln_b), dt, build)[0]
+
+
 @_lib.device_guarded
 def predictor_tail_z(z: torch.Tensor, conv_w: torch.Tensor, conv_b: torch.Tensor, ln_w: torch.Tensor, ln_b: torch.Tensor,
                      up: int, T_m: int, dtype: torch.dtype, eps: float = 1e-5, want_scores: bool = False):
@@ -276,6 +292,7 @@ def predictor_tail_select(y: Optional[torch.Tensor], conv_w: torch.Tensor, conv_
         dt, dev = y.dtype, y.device
     assert keep.dtype == torch.int32 and keep.is_contiguous() and (t_src_dev is not None or keep.shape in ((T,), (N, T)))
     _cw, cb, g, b, w16, Cp = _tail_pack(conv_w, conv_b, ln_w, ln_b, dt, dev)
+    tab = _tail_consts(ln_w, ln_b, up, T_m, dt, dev)
     if lazy_probs:
         assert t_src_dev is None
         if z is not None:
@@ -296,18 +313,18 @@ def predictor_tail_select(y: Optional[torch.Tensor], conv_w: torch.Tensor, conv_
         _lib.check(lib.sea_predictor_tail_select_at(
             _p(y), _lib.dtype_code(dt), N, C, H, T, W4, up, T_m, _lib.strides5_blocked(y), _p(cb), _p(w16), Cp, _p(g), _p(b),
             float(eps), _p(probs), _p(scores), _p(keep), _p(t_src_dev), int(is_causal), int(k),
-            _p(bits), _p(row_nnz), _p(head_off), _p(crow_out), _lib.stream_ptr()), "sea_predictor_tail_select_at")
+            _p(bits), _p(row_nnz), _p(head_off), _p(crow_out), _p(tab), _lib.stream_ptr()), "sea_predictor_tail_select_at")
         return probs, scores, (bits, row_nnz, head_off)
     if z is not None:
         _lib.check(lib.sea_predictor_tail_select_z(
             _p(z), _lib.dtype_code(dt), N, H, T, W4, up, T_m, _p(cb), _p(g), _p(b), float(eps),
             _p(None if lazy_probs else probs), _p(scores), _p(keep), T if keep.ndim == 2 else 0, T_src, int(is_causal), int(k),
-            _p(bits), _p(row_nnz), _p(head_off), _lib.stream_ptr()), "sea_predictor_tail_select_z")
+            _p(bits), _p(row_nnz), _p(head_off), _p(tab), _lib.stream_ptr()), "sea_predictor_tail_select_z")
         return probs, scores, (bits, row_nnz, head_off)
     _lib.check(lib.sea_predictor_tail_select(
         _p(y), _lib.dtype_code(dt), N, C, H, T, W4, up, T_m, _lib.strides5_blocked(y), _p(cb), _p(w16), Cp, _p(g), _p(b),
         float(eps), _p(None if lazy_probs else probs), _p(scores), _p(keep), T if keep.ndim == 2 else 0, T_src, int(is_causal), int(k),
-        _p(bits), _p(row_nnz), _p(head_off), _lib.stream_ptr()), "sea_predictor_tail_select")
+        _p(bits), _p(row_nnz), _p(head_off), _p(tab), _lib.stream_ptr()), "sea_predictor_tail_select")
     return probs, scores, (bits, row_nnz, head_off)
 
 
@@ -720,6 +737,7 @@ def decode_cnn_tail_select(x_new: torch.Tensor, x_ring: torch.Tensor, y1_ring: t
     (w1p, CinP), b1 = packs[0]
     (w2p, _c), b2 = packs[1]
     _cw, cb, g, b, w16, Cp = _tail_pack(conv_w, conv_b, ln_w, ln_b, dt, dev)
+    tab = _tail_consts(ln_w, ln_b, 4, T_m, dt, dev)
     probs = torch.empty((N, H, 1, T_m), dtype=dt, device=dev) if want_probs else None
     Wb = (H * T_m + 31) // 32
     bits = torch.empty((N, 1, Wb), dtype=torch.int32, device=dev)
@@ -730,7 +748,7 @@ def decode_cnn_tail_select(x_new: torch.Tensor, x_ring: torch.Tensor, y1_ring: t
         _p(w1p), _p(b1), _p(w2p), _p(b2), CinP, int(conv1.dilation), int(conv1.padding[1]), _p(cb), _p(w16), Cp, _p(g), _p(b),
         float(eps), _p(probs), _p(keep), _p(counters), _p(ticket), int(is_causal), int(k), _p(bits), _p(row_nnz), _p(head_off),
         _p(crow_out), _p(col_out), col_out.stride(0) if col_out is not None else 0, col_out.shape[1] if col_out is not None else 0,
-        int(T_cap), _lib.stream_ptr()), "sea_decode_cnn_tail_select")
+        int(T_cap), _p(tab), _lib.stream_ptr()), "sea_decode_cnn_tail_select")
     return probs, (bits, row_nnz, head_off)
 
 
