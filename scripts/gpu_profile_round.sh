@@ -11,4 +11,7 @@ for WL in llama-13b opt-2.7b; do
   BENCH_EXTRA="--workload $WL --batch 1" BENCH_STEPS=20 bash scripts/gpu_profile.sh ${TAG}_${S}_x1 || exit 1
   BENCH_EXTRA="--workload $WL --batch 1" bash scripts/gpu_pmc.sh ${TAG}_${S}_x1 || exit 1
 done
+BENCH_EXTRA="--workload opt-125m --batch 8" BENCH_STEPS=20 bash scripts/gpu_profile.sh ${TAG}_opt125m_x8 || exit 1
+BENCH_EXTRA="--workload opt-125m --batch 8" bash scripts/gpu_pmc.sh ${TAG}_opt125m_x8 || exit 1
+BENCH_EXTRA="--workload opt-125m --batch 1 --seq-len 32768" BENCH_STEPS=20 bash scripts/gpu_profile.sh ${TAG}_long32k || exit 1
 BENCH_EXTRA="--workload opt-125m --batch 8 --dtype fp32" BENCH_STEPS=20 bash scripts/gpu_profile.sh ${TAG}_fp32_opt125m_x8 || exit 1
