@@ -323,7 +323,11 @@ int sea_predictor_tail_z(const float* z, int dtype, int64_t N, int64_t H, int64_
  * src/main/benchmark_opt_ablation.py:160-186, exp_long_context.py:152; T_m = 256 with H % 4 == 0 keeps the map in
  * registers, every other shape passes it through a flat LDS image of the row).  SEA_EUNSUPPORTED when the row's LDS plan
  * does not fit.  Arguments as in sea_predictor_tail (conv_w16 mandatory, no FP32 weight copy) and sea_topk_select
- * (keep / keep_stride_n / T_src / is_causal / max_k -> bits / row_nnz / head_off). */
+ * (keep / keep_stride_n / T_src / is_causal / max_k -> bits / row_nnz / head_off).
+ * fp32 data (round 5, the reference's measurement protocol): dtype = SEA_F32 with T_m = 256 (W4 = 64, up = 4), H % 4 == 0,
+ * H <= 32; `conv_w16` then carries sea_predictor_tail's conv_wT, the (C, Hpad) FP32 transposed weights (Cp ignored), probs is
+ * mandatory (the fp32 map is always written) and the 1x1 convolution runs on the fp32 MFMA -- bit-identical to
+ * sea_predictor_tail (fp32, channels-last / C8 input: the same device code) followed by sea_topk_select. */
 int sea_predictor_tail_select(const void* y, int dtype, int64_t N, int64_t C, int64_t H, int64_t T, int64_t W4,
                               int64_t up, int64_t T_m, const int64_t* y_strides, const void* conv_b,
                               const void* conv_w16, int64_t Cp, const void* gamma, const void* beta, float eps,

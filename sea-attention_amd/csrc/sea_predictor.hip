@@ -553,7 +553,11 @@ extern "C" int sea_predictor_tail(const void* y, int dtype, int64_t N, int64_t C
   int rc;
   const bool mfma = conv_w16 != nullptr && dtype != SEA_F32 && nhwc && !nchw && Cp % 32 == 0 && Cp >= C &&
                     (((uintptr_t)conv_w16) & 15) == 0;
+  // fp32 channels-last / C8 input (round 5): the MFMA-structured kernel on the fp32 MFMA -- the device code the fused fp32 tail +
+  // selection launch runs, so that the two agree bit for bit (dense mode reads this map, sparse mode selects from that one)
+  const bool mfma32 = dtype == SEA_F32 && nhwc && !nchw && C % 4 == 0 && T_m % 4 == 0;
   if (mfma) rc = dtype == SEA_F16 ? launch_tail_mfma<__half>(p, grid, s) : launch_tail_mfma<__hip_bfloat16>(p, grid, s);
+  else if (mfma32) rc = launch_tail_mfma<float>(p, grid, s);
   else if (dtype == SEA_F32) rc = launch_tail<float>(p, lds, grid, s);
   else if (dtype == SEA_F16) rc = launch_tail<__half>(p, lds, grid, s);
   else rc = launch_tail<__hip_bfloat16>(p, lds, grid, s);
@@ -566,7 +570,7 @@ extern "C" int sea_predictor_tail_consts(int dtype, int64_t W4, int64_t up, int6
                                          uint32_t* tab, sea_stream_t stream) {
   const char* nm = "sea_predictor_tail_consts";
   SEA_REQUIRE(gamma && beta && tab, SEA_EINVAL, "%s: null pointer", nm);
-  SEA_REQUIRE(dtype == SEA_F16 || dtype == SEA_BF16, SEA_EUNSUPPORTED, "%s: 16-bit maps only (dtype %d)", nm, dtype);
+  SEA_REQUIRE(dtype == SEA_F16 || dtype == SEA_BF16 || dtype == SEA_F32, SEA_EINVAL, "%s: bad dtype %d", nm, dtype);
   SEA_REQUIRE(W4 > 0 && up > 0 && T_m == 256 && W4 * up == T_m && W4 + 1 < 1024, SEA_EUNSUPPORTED,
               "%s: the table serves the T_m = 256 kernels (3 x 256 words)", nm);
   TailParams p;
@@ -575,6 +579,7 @@ extern "C" int sea_predictor_tail_consts(int dtype, int64_t W4, int64_t up, int6
   p.ys_n = p.ys_c = p.ys_t = p.ys_w = p.ys_c8 = 0; p.w16 = nullptr; p.Cp = 0; p.z = nullptr; p.tab = nullptr;
   hipStream_t s = (hipStream_t)stream;
   if (dtype == SEA_F16) hipLaunchKernelGGL((tail_consts_kernel<__half>), dim3(1), dim3(256), 0, s, p, tab, 256);
+  else if (dtype == SEA_F32) hipLaunchKernelGGL((tail_consts_kernel<float>), dim3(1), dim3(256), 0, s, p, tab, 256);
   else hipLaunchKernelGGL((tail_consts_kernel<__hip_bfloat16>), dim3(1), dim3(256), 0, s, p, tab, 256);
   SEA_CHECK_LAUNCH(nm);
   return SEA_OK;

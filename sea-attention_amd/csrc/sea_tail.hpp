@@ -75,6 +75,42 @@ __device__ __forceinline__ void tail_z_tile(const TailParams& p, float* s_z, int
     for (int h = threadIdx.x; h < HP; h += 256) { s_z[h * LDZ + p.W4] = h < p.H ? bF[h] : 0.f; s_z[h * LDZ + p.W4 + 1] = 0.f; }
     return;
   }
+  if constexpr (sizeof(T) == 4) {
+    // fp32 data (round 5): the same product on v_mfma_f32_16x16x4_f32, exact fp32.  A = y (row = pixel li, k = channel 4 j + lg:
+    // one 4-byte load per MFMA from the channels-last / C8 row), B = the transposed fp32 weights wT (C, Hpad) (k, col = head li).
+    const float* __restrict__ wT = reinterpret_cast<const float*>(p.w4);
+    const float* yf = reinterpret_cast<const float*>(p.y) + n * p.ys_n + t * p.ys_t;
+    const int Hpad = ((p.H + 7) / 8) * 8;
+    const int MTf = (p.W4 + 15) / 16, NTf = HP / 16, KS = (p.C + 3) / 4;
+    for (int mt = wv; mt < MTf; mt += 4) {
+      const int wpix = mt * 16 + li;
+      for (int nt = 0; nt < NTf; ++nt) {
+        const int h = nt * 16 + li;
+        tf4 acc = tf4{0.f, 0.f, 0.f, 0.f};
+        for (int j0 = 0; j0 < KS; j0 += 8) {                      // eight k-steps' operands requested together
+          float a[8], b[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int c = 4 * (j0 + u) + lg;
+            const bool ck = (j0 + u) < KS && c < p.C;
+            a[u] = (ck && wpix < p.W4) ? yf[(int64_t)wpix * p.ys_w + (c >> 3) * p.ys_c8 + (c & 7) * p.ys_c] : 0.f;
+            b[u] = (ck && h < p.H) ? wT[c * Hpad + h] : 0.f;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u)
+            if (j0 + u < KS) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);   // (block-uniform guard)
+        }
+        const float bias = h < p.H ? bF[h] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int px = mt * 16 + lg * 4 + r;
+          if (px < p.W4) s_z[h * LDZ + px] = acc[r] + bias;
+        }
+      }
+    }
+    for (int h = threadIdx.x; h < HP; h += 256) { s_z[h * LDZ + p.W4] = h < p.H ? bF[h] : 0.f; s_z[h * LDZ + p.W4 + 1] = 0.f; }
+    return;
+  } else {
   const T* __restrict__ w16 = reinterpret_cast<const T*>(p.w16);
   const T* yb = reinterpret_cast<const T*>(p.y) + n * p.ys_n + t * p.ys_t;
   const int MT = (p.W4 + 15) / 16, NT = HP / 16, KC = p.Cp / 32;
@@ -139,6 +175,7 @@ __device__ __forceinline__ void tail_z_tile(const TailParams& p, float* s_z, int
   }
   }
   for (int h = threadIdx.x; h < HP; h += 256) { s_z[h * LDZ + p.W4] = h < p.H ? bF[h] : 0.f; s_z[h * LDZ + p.W4 + 1] = 0.f; }
+  }
 }
 
 // ---- per-pixel constants of the area-resize / LayerNorm stage ----------------------------------------------------

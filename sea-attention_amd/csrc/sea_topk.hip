@@ -698,6 +698,50 @@ __global__ __launch_bounds__(TK_THREADS, EPT <= 16 ? 7 : EPT == 32 ? 7 : EPT == 
   select_body<T, EPT, false, FULL, 64, true, true>(p, key, 0ull, n, t, row, (const T*)nullptr, reinterpret_cast<uint32_t*>(s_z));
 }
 
+// ---- fp32 DATA (round 5): the same fusion for the reference's fp32 measurement protocol (benchmark_bert.py:196-239) ----------
+// Same structure and layouts; the z tile runs on the fp32 MFMA (tail_z_tile<float>), the map is fp32 and IS written (nothing
+// lazy about the fp32 path), the keys are the 32-bit patterns of the probabilities (select_body's unpacked form, whose slow
+// path re-reads the row of the map this launch has just stored).  Bit-identical to predictor_tail_mfma_kernel<float> followed
+// by topk_select_kernel<float>: same device functions, same key layout (chunk 256 j + tid = head 4 j + wave, pixels 4 lane ..).
+template <int EPT>
+__global__ __launch_bounds__(TK_THREADS) void predictor_tail_select_f32_kernel(TailParams tp, TopkParams p) {
+  using T = float;
+  constexpr int R = EPT / 4, E = 4;
+  extern __shared__ __attribute__((aligned(16))) float s_z[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int row = blockIdx.x;
+  const int n = row / tp.T, t = row - n * tp.T;
+  constexpr int LDZ = 64 + 3;
+  uint32_t* s_tab = reinterpret_cast<uint32_t*>(s_z + ((tp.H + 15) / 16) * 16 * LDZ);
+  TailRow<T, E> tr;
+  if (tp.tab) tr.load_global(tp.tab, lane);
+  tail_z_tile<T>(tp, s_z, n, t);
+  if (!tp.tab) tail_consts_fill<T>(tp, s_tab, 64 * E);
+  __syncthreads();
+  if (!tp.tab) tr.load(s_tab, lane);
+  uint32_t key[EPT];
+  const int mine = max(0, (tp.H - wv + 3) / 4);
+  auto batch = [&](auto j0c, auto nbc) {
+    constexpr int J0 = decltype(j0c)::value, NBC = decltype(nbc)::value;
+    float a[NBC][E];
+    const int nb = min(NBC, mine - J0);
+    if (nb > 0) {
+      tr.template heads_impl<true>(tp, lane, nb, [&](int b) { return s_z + (4 * (J0 + b) + wv) * LDZ; },
+                                   [&](int b) { return (((int64_t)n * tp.H + (4 * (J0 + b) + wv)) * tp.T + t) * (64 * E); }, a);
+    }
+#pragma unroll
+    for (int b = 0; b < NBC; ++b)
+#pragma unroll
+      for (int e = 0; e < E; ++e) key[4 * (J0 + b) + e] = (b < nb) ? f2key(a[b][e]) : 0u;
+  };
+  static_assert(R <= 8, "one batch of eight heads per wave (H <= 32)");
+  batch(std::integral_constant<int, 0>{}, std::integral_constant<int, R>{});
+  const T* base = reinterpret_cast<const T*>(tp.probs) + (int64_t)n * p.sn + (int64_t)t * p.st;
+  select_body<T, EPT, false, false, 64, true, false, false>(p, key, 0ull, n, t, row, base, reinterpret_cast<uint32_t*>(s_z));
+}
+
 // ---- the same fusion for ANY predictor length (T_m % 4 == 0, T_m <= 512; the reference's own grid runs 64 / 96 / 128 / 384:
 // src/main/benchmark_opt_ablation.py:160-186, exp_long_context.py:152).  The tail keeps its natural layout (wave <-> heads
 // wv, wv + 4, ..., lane <-> E consecutive pixels); the rounded probabilities go through a flat 16-bit image of the row in
@@ -1197,6 +1241,19 @@ static int launch_tail_select(const TailParams& tp, const TopkParams& p, int64_t
   return SEA_OK;
 }
 
+static int launch_tail_select_f32(const TailParams& tp, const TopkParams& p, int64_t rows, hipStream_t s) {
+  const int ept = ((p.nchunks + TK_THREADS - 1) / TK_THREADS) * 4;
+  size_t lds = (size_t)(((tp.H + 15) / 16) * 16) * (tp.W4 + 3) * sizeof(float) + (size_t)TAIL_TAB_ROWS * 256 * sizeof(uint32_t);
+  if (lds < 2 * TK_CAND_CAP * sizeof(uint32_t)) lds = 2 * TK_CAND_CAP * sizeof(uint32_t);
+  dim3 grid((unsigned)rows), block(TK_THREADS);
+  if (ept <= 4) hipLaunchKernelGGL((predictor_tail_select_f32_kernel<4>), grid, block, lds, s, tp, p);
+  else if (ept <= 8) hipLaunchKernelGGL((predictor_tail_select_f32_kernel<8>), grid, block, lds, s, tp, p);
+  else if (ept <= 16) hipLaunchKernelGGL((predictor_tail_select_f32_kernel<16>), grid, block, lds, s, tp, p);
+  else if (ept <= 32) hipLaunchKernelGGL((predictor_tail_select_f32_kernel<32>), grid, block, lds, s, tp, p);
+  else return SEA_EUNSUPPORTED;
+  return SEA_OK;
+}
+
 template <typename T>
 static int launch_tail_select_gen(const TailParams& tp, const TopkParams& p, int64_t rows, hipStream_t s) {
   const int ept = ((p.nchunks + TK_THREADS - 1) / TK_THREADS) * 4;
@@ -1237,9 +1294,12 @@ static int tail_select_common(const char* nm, const float* z, const void* y, int
   SEA_REQUIRE(crow1 == nullptr || T == 1, SEA_EINVAL, "%s: crow_out goes with one row per batch item (T = %lld)", nm, (long long)T);
   SEA_REQUIRE((z || (y && y_strides && conv_w16)) && conv_b && gamma && beta && keep && bits && row_nnz && head_off, SEA_EINVAL,
               "%s: null pointer", nm);
-  SEA_REQUIRE(dtype == SEA_F16 || dtype == SEA_BF16, SEA_EUNSUPPORTED, "%s: 16-bit data only (dtype %d)", nm, dtype);
+  SEA_REQUIRE(dtype == SEA_F16 || dtype == SEA_BF16 || dtype == SEA_F32, SEA_EINVAL, "%s: bad dtype %d", nm, dtype);
   SEA_REQUIRE(N > 0 && (z || C > 0) && H > 0 && T > 0 && T_src >= T && max_k > 0, SEA_EINVAL, "%s: bad shape", nm);
   const bool tm256 = T_m == 256 && W4 == 64 && up == 4 && H % 4 == 0;       // the register-resident form
+  // fp32 data (round 5): the T_m = 256 form only, H <= 32, map written (probs != NULL), conv_w16 = the (C, Hpad) fp32 transposed weights
+  SEA_REQUIRE(dtype != SEA_F32 || (tm256 && H <= 32 && z == nullptr && t_src_dev == nullptr && probs != nullptr), SEA_EUNSUPPORTED,
+              "%s: fp32 data takes T_m = 256, H <= 32, H %% 4 == 0, a written map, no z / decode form", nm);
   SEA_REQUIRE(W4 * up == T_m && T_m % 4 == 0 && T_m <= 512 && H <= 64 && H * T_m <= 16384 && W4 + 1 < 1024 && W4 * up + 2 <= 2 * T_m,
               SEA_EUNSUPPORTED, "%s: needs W4 * up == T_m, T_m %% 4 == 0, T_m <= 512, H <= 64, H * T_m <= 16384", nm);
   SEA_REQUIRE(tm256 || t_src_dev == nullptr, SEA_EUNSUPPORTED, "%s: the decode form takes T_m = 256 (W4 = 64, up = 4), H %% 4 == 0", nm);
@@ -1248,13 +1308,13 @@ static int tail_select_common(const char* nm, const float* z, const void* y, int
                 "%s: z rows must be whole 16-byte vectors, 16-byte aligned", nm);
   } else {
     SEA_REQUIRE(y_strides[1] == 1 && C % 8 == 0 && y_strides[0] % 8 == 0 && y_strides[2] % 8 == 0 && y_strides[3] % 8 == 0 &&
-                    y_strides[4] % 8 == 0 && Cp % 32 == 0 && Cp >= C &&
+                    y_strides[4] % 8 == 0 && (dtype == SEA_F32 || (Cp % 32 == 0 && Cp >= C)) &&
                     (((uintptr_t)y | (uintptr_t)conv_w16 | (uintptr_t)probs | (uintptr_t)scores) & 15) == 0,
                 SEA_EUNSUPPORTED, "%s: y must be channels-last / C8 with 16-byte aligned vectors", nm);
   }
   SEA_REQUIRE(N * T < (1ll << 31), SEA_EUNSUPPORTED, "%s: too many rows", nm);
   TailParams tp;
-  tp.y = y; tp.w4 = nullptr; tp.b4 = conv_b; tp.gamma = gamma; tp.beta = beta; tp.probs = probs; tp.scores = scores; tp.eps = eps;
+  tp.y = y; tp.w4 = dtype == SEA_F32 ? conv_w16 : nullptr; tp.b4 = conv_b; tp.gamma = gamma; tp.beta = beta; tp.probs = probs; tp.scores = scores; tp.eps = eps;
   tp.N = (int)N; tp.C = (int)C; tp.H = (int)H; tp.T = (int)T; tp.W4 = (int)W4; tp.UP = (int)up; tp.T_M = (int)T_m;
   tp.ys_n = tp.ys_c = tp.ys_t = tp.ys_w = tp.ys_c8 = 0;
   if (!z) { tp.ys_n = y_strides[0]; tp.ys_c = y_strides[1]; tp.ys_t = y_strides[2]; tp.ys_w = y_strides[3]; tp.ys_c8 = y_strides[4]; }
@@ -1269,7 +1329,8 @@ static int tail_select_common(const char* nm, const float* z, const void* y, int
   p.bits = bits; p.mask_out = nullptr; p.row_nnz = row_nnz; p.head_off = head_off; p.t_src_dev = t_src_dev; p.crow1 = crow1;
   hipStream_t s = (hipStream_t)stream;
   int rc;
-  if (tm256) rc = dtype == SEA_F16 ? launch_tail_select<__half>(tp, p, N * T, s) : launch_tail_select<__hip_bfloat16>(tp, p, N * T, s);
+  if (dtype == SEA_F32) rc = launch_tail_select_f32(tp, p, N * T, s);
+  else if (tm256) rc = dtype == SEA_F16 ? launch_tail_select<__half>(tp, p, N * T, s) : launch_tail_select<__hip_bfloat16>(tp, p, N * T, s);
   else rc = dtype == SEA_F16 ? launch_tail_select_gen<__half>(tp, p, N * T, s) : launch_tail_select_gen<__hip_bfloat16>(tp, p, N * T, s);
   SEA_REQUIRE(rc == SEA_OK, rc, "%s: this (H, T_m) does not fit the fused kernel's LDS plan (run sea_predictor_tail + sea_topk_select)", nm);
   SEA_CHECK_LAUNCH(nm);

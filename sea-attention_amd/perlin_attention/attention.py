@@ -361,7 +361,7 @@ class PerlinAttention(nn.Module):
         w1 = conv4.weight[:, :, 0, 0]
         pairs = list(range(0, len(body) - 2, 2))
         last = body[pairs[-1]].module if pairs else None
-        use_z = (self.conv_z_epilogue and last is not None
+        use_z = (self.conv_z_epilogue and last is not None and x.dtype in (torch.float16, torch.bfloat16)
                  and ops.conv_z_supported(last.out_channels, Hh, last.kernel_size, x.shape[3]))
         z = None
         with timer("cnn.keepres"):

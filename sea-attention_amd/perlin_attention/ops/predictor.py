@@ -208,7 +208,7 @@ def _tail_pack(conv_w, conv_b, ln_w, ln_b, dt, device):
 def _tail_consts(ln_w: torch.Tensor, ln_b: torch.Tensor, up: int, T_m: int, dt, device):
     """The tail's per-pixel constants (taps of the area resize, gamma, beta: `sea_predictor_tail_consts`) as a device table,
     cached with the LayerNorm weights; None for shapes the table does not serve (T_m != 256, fp32 maps)."""
-    if T_m != 256 or dt not in (torch.float16, torch.bfloat16) or T_m % up:
+    if T_m != 256 or dt not in (torch.float16, torch.bfloat16, torch.float32) or T_m % up:
         return None
 
     def build():
@@ -243,6 +243,8 @@ def predictor_tail_select_supported(y: torch.Tensor, H: int, T_m: int, decode: b
     """Shapes csrc/sea_topk.hip: predictor_tail_select(_gen)_kernel take (see sea_predictor_tail_select in sea_hip.h):
     any predictor length T_m % 4 == 0 up to 512 whose row fits the kernel's LDS plan; the decode form (`_at`) and the
     register-resident kernel take T_m = 256 with H % 4 == 0."""
+    if y.dtype == torch.float32:      # fp32 data (round 5): the T_m = 256 form on the fp32 MFMA, H <= 32, no decode form
+        return (y.dim() == 5 or y.stride(1) == 1) and T_m == 256 and H % 4 == 0 and H <= 32 and not decode
     if not (y.dtype in (torch.float16, torch.bfloat16) and (y.dim() == 5 or y.stride(1) == 1)):
         return False
     if T_m == 256 and H % 4 == 0 and H <= 64:
@@ -292,6 +294,8 @@ def predictor_tail_select(y: Optional[torch.Tensor], conv_w: torch.Tensor, conv_
         dt, dev = y.dtype, y.device
     assert keep.dtype == torch.int32 and keep.is_contiguous() and (t_src_dev is not None or keep.shape in ((T,), (N, T)))
     _cw, cb, g, b, w16, Cp = _tail_pack(conv_w, conv_b, ln_w, ln_b, dt, dev)
+    if dt == torch.float32:           # fp32 data: the weights go in as the (C, Hpad) fp32 transposed copy, and the map is always written
+        w16, Cp, lazy_probs = _cw, 0, False
     tab = _tail_consts(ln_w, ln_b, up, T_m, dt, dev)
     if lazy_probs:
         assert t_src_dev is None

@@ -448,6 +448,43 @@ def test_predictor_tail_select_bit_identical(ops, dtype, N, H, T, k, T_M):
     assert torch.equal(c4.bits, c5.bits) and torch.equal(c4.crow, c5.crow)
 
 
+@pytest.mark.parametrize("N,H,T,k", [(2, 12, 150, 64), (1, 32, 133, 64), (1, 4, 64, 8), (1, 20, 70, 16), (1, 8, 300, 32)])
+def test_predictor_tail_select_fp32_bit_identical(ops, N, H, T, k):
+    """fp32 data (round 5): the fused tail + selection on the fp32 MFMA == `predictor_tail` (fp32, C8 input: the same device
+    code) followed by `topk_to_csr`, bit for bit; and the map agrees with the torch evaluation of the tail to fp32 noise."""
+    T_M, C, W4 = 256, 2 * H, 64
+    assert ops.predictor_tail_select_supported(torch.empty((1, 1, 1, 1, 8), dtype=torch.float32), H, T_M)
+    assert not ops.predictor_tail_select_supported(torch.empty((1, 1, 1, 1, 8), dtype=torch.float32), 40, T_M)
+    g = torch.Generator().manual_seed(17)
+    yn = torch.relu(torch.randn((N, C, T, W4), generator=g))
+    y = ops.to_c8(yn.to(DEV))
+    cw = (torch.randn((H, C), generator=g) * C ** -0.5).to(DEV)
+    cb = (torch.randn(H, generator=g) * 0.1).to(DEV)
+    lw = (torch.rand(T_M, generator=g) + 0.5).to(DEV)
+    lb = (torch.randn(T_M, generator=g) * 0.1).to(DEV)
+    keep = ops.keep_table_causal(H, T, T_M, k, device=DEV)
+    p0, s0 = ops.predictor_tail(y, cw, cb, lw, lb, up=4, T_m=T_M, want_scores=True)
+    c0, _ = ops.topk_to_csr(p0, keep, k, target_width=T)
+    p1, s1, sel = ops.predictor_tail_select(y, cw, cb, lw, lb, up=4, T_m=T_M, keep=keep, k=k, T_src=T, want_scores=True, lazy_probs=True)
+    assert p1.dtype == torch.float32 and not isinstance(p1, ops.LazyTensor)          # the fp32 map is always written
+    c1 = ops.csr_from_selection(*sel, H, T_M, T, k, True, None, keep)
+    assert torch.equal(p0, p1) and torch.equal(s0, s1)
+    assert torch.equal(c0.bits, c1.bits) and torch.equal(c0.crow, c1.crow) and torch.equal(c0.head_off, c1.head_off)
+    # the map against torch: 1x1 conv (pad 1) on the x4-upsampled rows, area resize to T_M, LayerNorm, softmax
+    z = torch.einsum("hc,nctw->nhtw", cw.cpu().double(), yn.double()) + cb.cpu().double().view(1, H, 1, 1)
+    up = z.repeat_interleave(4, dim=-1)
+    padded = torch.cat([cb.cpu().double().view(1, H, 1, 1).expand(N, H, T, 1), up, cb.cpu().double().view(1, H, 1, 1).expand(N, H, T, 1)], -1)
+    a = torch.nn.functional.adaptive_avg_pool2d(padded, (T, T_M))
+    ref = torch.softmax(torch.nn.functional.layer_norm(a, (T_M,), lw.cpu().double(), lb.cpu().double(), 1e-5), -1)
+    assert (p1.cpu().double() - ref).abs().max().item() < 2e-6
+    # ties: an all-equal map goes through the unpacked selection's slow path, which re-reads the row this launch has stored
+    y0 = torch.zeros_like(y)
+    p2, _, sel2 = ops.predictor_tail_select(y0, cw * 0, cb * 0, lw, lb * 0, up=4, T_m=T_M, keep=keep, k=k, T_src=T)
+    c2 = ops.csr_from_selection(*sel2, H, T_M, T, k, True, None, keep)
+    c3, _ = ops.topk_to_csr(ops.predictor_tail(y0, cw * 0, cb * 0, lw, lb * 0, up=4, T_m=T_M)[0], keep, k, target_width=T)
+    assert torch.equal(c2.bits, c3.bits) and torch.equal(c2.crow, c3.crow)
+
+
 @pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float16])
 @pytest.mark.parametrize("N,H,T,k,T_M", [(2, 32, 150, 64, 256), (1, 12, 133, 16, 256), (1, 40, 100, 64, 256), (1, 4, 40, 8, 256),
                                          (1, 20, 50, 16, 256), (1, 12, 90, 32, 96), (1, 12, 70, 32, 384), (1, 32, 40, 64, 128),
