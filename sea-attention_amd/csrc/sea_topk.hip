@@ -647,7 +647,13 @@ __device__ __forceinline__ void tail_select_row(const TailParams& tp, const Topk
 }
 
 template <typename T, int EPT, bool FULL>
-__global__ __launch_bounds__(TK_THREADS, EPT <= 16 ? 7 : EPT == 32 ? 7 : EPT == 40 ? 5 : 1) void predictor_tail_select_kernel(TailParams tp, TopkParams p) {
+#ifndef SEA_TSEL_OCC32
+#define SEA_TSEL_OCC32 7
+#endif
+#ifndef SEA_TSEL_OCC16
+#define SEA_TSEL_OCC16 7
+#endif
+__global__ __launch_bounds__(TK_THREADS, EPT <= 16 ? SEA_TSEL_OCC16 : EPT == 32 ? SEA_TSEL_OCC32 : EPT == 40 ? 5 : 1) void predictor_tail_select_kernel(TailParams tp, TopkParams p) {
   constexpr int R = EPT / 4, E = 4;
   extern __shared__ __attribute__((aligned(16))) float s_z[];     // HP x (W4 + 3)
   const int tid = threadIdx.x;
