@@ -431,7 +431,11 @@ def test_fused_estimator_predicates_cover_the_reference_grid():
         assert ops.predictor_mlp_supported(128, T_M // 2, 12, 192)
     assert ops.predictor_tail_select_supported(y16, 32, 512) and ops.predictor_tail_select_supported(y16, 40, 256)
     assert not ops.predictor_tail_select_supported(y16, 64, 512)                       # H * T_M > 16384
-    assert not ops.predictor_tail_select_supported(y16.float(), 12, 256)               # 16-bit data only
+    assert ops.predictor_tail_select_supported(y16.float(), 12, 256)                   # round 5: fp32 data, T_M = 256, H <= 32
+    assert not ops.predictor_tail_select_supported(y16.float(), 12, 128)
+    assert not ops.predictor_tail_select_supported(y16.float(), 40, 256)
+    assert not ops.predictor_tail_select_supported(y16.float(), 12, 256, decode=True)
+    assert not ops.predictor_tail_select_supported(y16.double(), 12, 256)
     assert not ops.predictor_tail_select_supported(y16, 12, 128, decode=True)          # the graph-replayed decode form: T_M = 256
     assert ops.predictor_tail_select_supported(y16, 32, 256, decode=True)
     assert not ops.predictor_mlp_supported(128, 24, 12, 192)                            # T_M / 4 must be a multiple of 8
