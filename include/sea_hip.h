@@ -36,7 +36,8 @@ extern "C" {
  *      state image at that boundary;  round 4: sea_predictor_mlp's w2_packed / vectors pad every decoder half to whole
  *      16-row tiles (identical for Wd % 16 == 0), sea_predictor_tail_select accepts probs = NULL and any T_m % 4 == 0 <= 512
  *   3  round 5: new entry points the binding requires (sea_causal_conv_c8_z, sea_predictor_tail_z, sea_predictor_tail_select_z,
- *      sea_causal_conv_c8_f32, sea_decode_cnn_tail_select, sea_predictor_tail_consts); sea_predictor_tail_select / _at take a
+ *      sea_causal_conv_c8_f32, sea_decode_cnn_tail_select, sea_predictor_tail_consts, sea_sparse_attention_fused_at);
+ *      sea_predictor_tail_select / _at take a
  *      trailing `consts_tab` argument (NULL = the round-4 behaviour)
  *      */
 #define SEA_ABI_VERSION 3
@@ -233,6 +234,25 @@ int sea_sparse_attention_fused(const void* q, const void* k, const void* v, int 
                                float* probs_out, int64_t probs_stride_n,
                                const uint32_t* bits, int64_t T_m, int is_causal, int max_k, int write_columns,
                                sea_stream_t stream);
+
+/* The DECODE form of the fused launch (round 5; SURVEY 8f-3, src/main/opt_generate.py:131, PA/attention.py:410-426): a position
+ * of a graph-replayed decoding session has static kernel arguments, so the sequence length the row widths follow is read
+ * from device memory (*t_src_dev, what sea_csr_emit_at reads) while T_cap -- the row count of the K / V caches -- is the
+ * stride the column ids are encoded with (head * T_cap + key) and the T_src the operator is called with.  T_dst <= 8 new
+ * rows per sequence; 16-bit d = 64 / 80 / 128 or fp32 d = 32 / 64 (the fused forms), else SEA_EUNSUPPORTED (run
+ * sea_csr_emit_at + sea_sparse_attention_ex).  The lane groups of a workgroup that have no row touch the K / V rows of the
+ * expanded lists before the one group per row starts its dependent walk (what the unfused kernel does from `col`).  Same
+ * arithmetic in the same order as sea_csr_emit_at + sea_sparse_attention_ex: the step stays bitwise the stateless forward;
+ * the emit launch (or the emit phase of sea_decode_cnn_tail_select: pass col = NULL there) and the crow -> col -> K / V
+ * load chain leave the position's critical path.  `col`: scratch / output as in sea_sparse_attention_fused. */
+int sea_sparse_attention_fused_at(const void* q, const void* k, const void* v, int dtype,
+                                  int64_t N, int64_t H, int64_t T_dst, int64_t T_cap, int64_t D,
+                                  const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                                  const int32_t* crow, int32_t* col, int64_t col_stride_n, const int32_t* head_off,
+                                  const float* row_scale, const void* avg, const int64_t* avg_strides, const float* mix,
+                                  void* out, int out_dtype, const int64_t* out_strides,
+                                  const uint32_t* bits, int64_t T_m, const int32_t* t_src_dev, int is_causal, int max_k,
+                                  int write_columns, sea_stream_t stream);
 
 /* Backward of the fused operator WITHOUT its epilogue (o = sum_e softmax_e(q.k_e) v_e; the caller applies row scale and mix
  * in its autograd framework): dQ, dK, dV from dO.  Reference shape: masked_mm.py:169-267 + the dense branch's autograd

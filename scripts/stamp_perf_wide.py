@@ -21,6 +21,7 @@ chunks = N * H * T / 32
 nseg = ops.performer_plan(N, H, T, D, fa.projection_matrix.shape[0], dt)[0]
 print(json.dumps({"shape": [N, H, T, D], "wave0_cycles_per_chunk": [round(buf[i] / chunks) for i in range(4)],
                   "wave7_cycles_per_chunk": [round(buf[i] / chunks) for i in range(4, 8)],
+                  "state_pass_wave0_cycles_per_chunk": [round(buf[10 + i] / max(N * H * (nseg - 1) * math.ceil(T / nseg / 32), 1)) for i in range(4)],
                   "nseg": nseg, "state_pass_cycles_per_workgroup": round(buf[8] / max(N * H * (nseg - 1), 1)),
                   "output_pass_cycles_per_workgroup": round(buf[9] / (N * H * nseg))}))
 

@@ -38,6 +38,8 @@ _SIGNATURES = {
                                  ptr, ptr, i64, ptr, ptr, ptr, _i64p, ptr, ptr, c_int, _i64p, ptr, i64, ptr, c_int, ptr], c_int),
     "sea_sparse_attention_fused": ([ptr, ptr, ptr, c_int, i64, i64, i64, i64, i64, _i64p, _i64p, _i64p,
                                     ptr, ptr, i64, ptr, ptr, ptr, _i64p, ptr, ptr, c_int, _i64p, ptr, i64, ptr, i64, c_int, c_int, c_int, ptr], c_int),
+    "sea_sparse_attention_fused_at": ([ptr, ptr, ptr, c_int, i64, i64, i64, i64, i64, _i64p, _i64p, _i64p,
+                                       ptr, ptr, i64, ptr, ptr, ptr, _i64p, ptr, ptr, c_int, _i64p, ptr, i64, ptr, c_int, c_int, c_int, ptr], c_int),
     "sea_sparse_attention_bwd": ([ptr, ptr, ptr, c_int, i64, i64, i64, i64, i64, _i64p, _i64p, _i64p, ptr, ptr, i64, ptr,
                                   ptr, i64, ptr, ptr, ptr, ptr, ptr, ptr], c_int),
     "sea_sparse_attention_bwd_workspace_bytes": ([i64, i64, i64, i64], i64),

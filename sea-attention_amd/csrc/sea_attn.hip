@@ -199,7 +199,7 @@ __device__ inline int slot_length(const AttnParams& p, int n, int h, int tn) {
 // Every thread of the block calls (one workgroup barrier inside).
 template <int LPR, int RPB>
 __device__ inline void fused_expand(const AttnParams& p, int n, int h, int tt, bool rowok, int gi, int sub, int beg, int end,
-                                    int hcol, int* s_keys, int* lbase_out, bool* fits_out) {
+                                    int hcol, int t_src, int* s_keys, int* lbase_out, bool* fits_out, int* total_out) {
   __shared__ int s_glen[RPB];
   const int mylen = end - beg;
   if (sub == 0) s_glen[gi] = mylen;
@@ -212,10 +212,11 @@ __device__ inline void fused_expand(const AttnParams& p, int n, int h, int tt, b
     bef += r < gi ? v_ : 0;
   }
   const int lbase = lane_group_sum_i<LPR>(bef);
-  const bool fits = lane_group_sum_i<LPR>(tot) <= p.fuse_cap;      // block-uniform
+  const int total = lane_group_sum_i<LPR>(tot);
+  const bool fits = total <= p.fuse_cap;                           // block-uniform
   int32_t* gcol = p.col_w + n * p.col_stride_n;
   const int WPH = p.T_m >> 5;                              // mask words per head (launcher: T_m % 32 == 0)
-  const int w_t = row_width(tt, p.T_dst, p.T_src, p.is_causal);
+  const int w_t = row_width(tt, p.T_dst, t_src, p.is_causal);      // (t_src: p.T_src, or the decode form's device counter)
   const float scale = interp_scale(w_t, p.T_m);
   const uint32_t* brow = p.bits + ((int64_t)n * p.T_dst + tt) * p.W + h * WPH;
   int carry = 0;
@@ -268,6 +269,28 @@ __device__ inline void fused_expand(const AttnParams& p, int n, int h, int tt, b
   }
   *lbase_out = lbase;
   *fits_out = fits;
+  *total_out = total;
+}
+
+// Decode form (DEC kernels, T_dst of a few rows): the block's key lists are complete in LDS (or, not fitting, in `col`); before
+// the one lane group per row starts its dependent walk, EVERY lane group of the block touches the K / V rows of the lists --
+// what the unfused kernel's warming pass does from `col` (see there).  Every thread of the block calls (two barriers).
+template <int LPR, int NG>
+__device__ inline void fused_warm(const int* s_keys, int total, bool fits, int hcol, const char* kbase, const char* vbase,
+                                  uint32_t kst, uint32_t vst, uint32_t lane_off) {
+  __syncthreads();                                         // the lists of the other waves
+  if (fits) {                                              // (block-uniform)
+    const int g = (int)threadIdx.x / LPR;
+    uint32_t sink = 0;
+    for (int e = g; e < total; e += NG) {
+      const uint32_t key_c = (uint32_t)(s_keys[e] - hcol);
+      const uint4 a = *reinterpret_cast<const uint4*>(kbase + (__umul24(key_c, kst) + lane_off));
+      const uint4 b = *reinterpret_cast<const uint4*>(vbase + (__umul24(key_c, vst) + lane_off));
+      sink ^= a.x ^ b.x;
+    }
+    asm volatile("" ::"v"(sink));                          // the loads must complete; their values are not used
+  }
+  __syncthreads();
 }
 
 // lane `sub`'s column of entry `ec` of its row: from the group's own list (fused, fits), from `col` past the L1 (fused, the
@@ -286,10 +309,12 @@ constexpr int SEA_ATTN_WARM_ROWS = 8;            // T_dst up to which the idle l
 // softmax; nothing is merged across groups.  A wave therefore has 64/LPR independent
 // (offsets -> col -> K/V) load chains in flight instead of one, which is what the wave-per-row mapping lacks.
 // Workgroup = 4 waves = 256/LPR consecutive query rows of one (n, h).
-template <typename T, typename TO, int LPR, int U, bool WP, int NWB = 4, bool FUSE = false>
+// DEC (with FUSE): the decode form -- row widths from *p.t_src_dev, the key lists warmed by the whole block (fused_warm).
+template <typename T, typename TO, int LPR, int U, bool WP, int NWB = 4, bool FUSE = false, bool DEC = false>
 // the fused 16-bit inference forms are held to 64 registers (8 waves per SIMD; 4 - 8 spilled registers): measured 0.307 ms
 // against 0.328 ms at 88 registers for the 16-lane form (LLaMA-13B d = 128), and the same direction for the 8-lane form
-__global__ __launch_bounds__(NWB * 64, (FUSE && sizeof(T) == 2 && !WP) ? 8 : 1) void sparse_attn_rows_kernel(AttnParams p) {
+__global__ __launch_bounds__(NWB * 64, (FUSE && !DEC && sizeof(T) == 2 && !WP) ? 8 : 1) void sparse_attn_rows_kernel(AttnParams p) {
+  static_assert(!DEC || FUSE, "the decode form is a fused form");
   constexpr int VEC = Elem<T>::VEC;
   constexpr int RPW = 64 / LPR;       // rows per wave
   constexpr int RPB = NWB * RPW;      // rows per workgroup
@@ -328,7 +353,9 @@ __global__ __launch_bounds__(NWB * 64, (FUSE && sizeof(T) == 2 && !WP) ? 8 : 1) 
   extern __shared__ int s_keys[];
   int lbase = 0;
   bool fits = false;
-  if constexpr (FUSE) fused_expand<LPR, RPB>(p, n, h, tt, rowok, gi, sub, beg, end, hcol, s_keys, &lbase, &fits);
+  int ltotal = 0;
+  if constexpr (FUSE) fused_expand<LPR, RPB>(p, n, h, tt, rowok, gi, sub, beg, end, hcol, DEC ? *p.t_src_dev : p.T_src, s_keys, &lbase, &fits, &ltotal);
+  if constexpr (DEC) fused_warm<LPR, NWB * RPW>(s_keys, ltotal, fits, hcol, kbase, vbase, kst, vst, lane_off);
 
   // ---- a decoding step: T_dst of one or a few rows, so all but a few of the block's lane groups have no row -- and the one
   // that has walks its ~k entries down ONE dependent chain (column indices -> four K / V rows -> the next four ...: three
@@ -467,10 +494,11 @@ template <> __device__ inline void unpack2<__half>(uint32_t r, float* f) {
 template <typename TO> __device__ inline void store2(TO* dst, float a, float b) { *reinterpret_cast<uint32_t*>(dst) = pack2<TO>(a, b); }
 template <> __device__ inline void store2<float>(float* dst, float a, float b) { *reinterpret_cast<float2*>(dst) = make_float2(a, b); }
 
-template <typename T, typename TO, int U, bool WP, int NWB = 4, bool FUSE = false>
+template <typename T, typename TO, int U, bool WP, int NWB = 4, bool FUSE = false, bool DEC = false>
 // (no wave floor here: capping this kernel at 80 / 64 registers for 6 / 8 waves per SIMD measured 0.427 / 0.489 ms against
 // 0.418 ms as compiled, OPT-2.7B T = 8192 -- DESIGN.md section 9)
 __global__ __launch_bounds__(NWB * 64) void sparse_attn_rows80_kernel(AttnParams p) {
+  static_assert(!DEC || FUSE, "the decode form is a fused form");
   constexpr int LPR = 8, VEC = 8, XT = 2, DM = LPR * VEC;     // DM = 64 elements in the 16-byte fragments
   constexpr int RPW = 64 / LPR, RPB = NWB * RPW;
   int pair, tb;
@@ -502,7 +530,10 @@ __global__ __launch_bounds__(NWB * 64) void sparse_attn_rows80_kernel(AttnParams
   extern __shared__ int s_keys[];                          // fused interpolation: see fused_expand
   int lbase = 0;
   bool fits = false;
-  if constexpr (FUSE) fused_expand<LPR, RPB>(p, n, h, tt, rowok, gi, sub, beg, end, hcol, s_keys, &lbase, &fits);
+  int ltotal = 0;
+  if constexpr (FUSE) fused_expand<LPR, RPB>(p, n, h, tt, rowok, gi, sub, beg, end, hcol, DEC ? *p.t_src_dev : p.T_src, s_keys, &lbase, &fits, &ltotal);
+  // (the 16-byte fragments of the lists' K / V rows: 128 of a row's 160 bytes, i.e. both of its cache lines)
+  if constexpr (DEC) fused_warm<LPR, NWB * RPW>(s_keys, ltotal, fits, hcol, kbase, vbase, kst, vst, off_m);
 
   float m = -INFINITY, l = 0.f;
   float acc[VEC + XT];
@@ -731,7 +762,10 @@ static int launch_attn_wp(AttnParams p, hipStream_t s) {
       const int rpb = 8 * 8;                               // 8 waves x 8 rows, sorted by length
       p.TB = (p.T_dst + rpb - 1) / rpb;
       const int64_t blocks = (int64_t)8 * ((NH + 7) / 8) * p.TB;
-      if (p.bits) hipLaunchKernelGGL((sparse_attn_rows80_kernel<T, TO, 4, WP, 8, true>), dim3((unsigned)blocks), dim3(512), p.fuse_cap * (int)sizeof(int), s, p);
+      if (p.bits && p.t_src_dev) {
+        if constexpr (WP) return SEA_EUNSUPPORTED;
+        else hipLaunchKernelGGL((sparse_attn_rows80_kernel<T, TO, 4, false, 8, true, true>), dim3((unsigned)blocks), dim3(512), p.fuse_cap * (int)sizeof(int), s, p);
+      } else if (p.bits) hipLaunchKernelGGL((sparse_attn_rows80_kernel<T, TO, 4, WP, 8, true>), dim3((unsigned)blocks), dim3(512), p.fuse_cap * (int)sizeof(int), s, p);
       else hipLaunchKernelGGL((sparse_attn_rows80_kernel<T, TO, 4, WP, 8>), dim3((unsigned)blocks), dim3(512), 0, s, p);
       return SEA_OK;
     }
@@ -747,6 +781,14 @@ static int launch_attn_wp(AttnParams p, hipStream_t s) {
     if (p.bits) {                                          // fused interpolation: group-private key lists in LDS
       if (lpr == 4) return SEA_EUNSUPPORTED;
       const int lds = p.fuse_cap * (int)sizeof(int);
+      if (p.t_src_dev) {                                   // decode form
+        if constexpr (WP) return SEA_EUNSUPPORTED;
+        else {
+          if (lpr == 8) hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 8, 4, false, 8, true, true>), grid, block, lds, s, p);
+          else hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 16, 4, false, 8, true, true>), grid, block, lds, s, p);
+          return SEA_OK;
+        }
+      }
       if (lpr == 8) hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 8, 4, WP, 8, true>), grid, block, lds, s, p);
       else hipLaunchKernelGGL((sparse_attn_rows_kernel<T, TO, 16, 4, WP, 8, true>), grid, block, lds, s, p);
       return SEA_OK;
@@ -829,7 +871,8 @@ static int attention_entry(const char* nm, const void* q, const void* k, const v
                            const float* row_scale, const void* avg, const int64_t* avg_strides,
                            const float* mix, void* out, int out_dtype, const int64_t* out_strides,
                            float* probs_out, int64_t probs_stride_n, const uint8_t* block_path, int flags,
-                           const uint32_t* bits, int64_t T_m, int is_causal, int max_k, int write_cols, sea_stream_t stream) {
+                           const uint32_t* bits, int64_t T_m, int is_causal, int max_k, int write_cols, const int32_t* t_src_dev,
+                           sea_stream_t stream) {
   SEA_REQUIRE(q && k && v && crow && col && head_off && out && q_strides && k_strides && v_strides && out_strides,
               SEA_EINVAL, "%s: null pointer", nm);
   if (int e = check_dtype(nm, dtype)) return e;
@@ -868,6 +911,11 @@ static int attention_entry(const char* nm, const void* q, const void* k, const v
   p.max_k = max_k; p.is_causal = is_causal;
   p.fuse_cap = 8192;                                        // entries of a block's key lists held in LDS (32 KB)
   p.write_cols = write_cols;
+  p.t_src_dev = t_src_dev;
+  if (t_src_dev) {
+    SEA_REQUIRE(bits != nullptr && probs_out == nullptr && T_dst <= SEA_ATTN_WARM_ROWS, SEA_EUNSUPPORTED,
+                "%s: the decode form takes T_dst <= %d rows per sequence, no probs_out", nm, SEA_ATTN_WARM_ROWS);
+  }
   if (bits) {
     SEA_REQUIRE(path != SEA_ATTN_TILE && block_path == nullptr, SEA_EUNSUPPORTED, "%s: the fused interpolation runs on the gather kernels", nm);
     SEA_REQUIRE(T_m > 0 && T_m % 32 == 0 && max_k > 0, SEA_EUNSUPPORTED, "%s: fused interpolation needs T_m %% 32 == 0", nm);
@@ -912,7 +960,7 @@ extern "C" int sea_sparse_attention_ex(const void* q, const void* k, const void*
                                        sea_stream_t stream) {
   return attention_entry("sea_sparse_attention", q, k, v, dtype, N, H, T_dst, T_src, D, q_strides, k_strides, v_strides, crow, col,
                          col_stride_n, head_off, row_scale, avg, avg_strides, mix, out, out_dtype, out_strides, probs_out,
-                         probs_stride_n, block_path, flags, nullptr, 0, 0, 0, 1, stream);
+                         probs_stride_n, block_path, flags, nullptr, 0, 0, 0, 1, nullptr, stream);
 }
 
 // Steps I + J in ONE launch: the gather kernel expands the selection's kept pixels to key columns itself (the emit's
@@ -931,7 +979,26 @@ extern "C" int sea_sparse_attention_fused(const void* q, const void* k, const vo
   SEA_REQUIRE(bits != nullptr, SEA_EINVAL, "sea_sparse_attention_fused: null pointer");
   return attention_entry("sea_sparse_attention_fused", q, k, v, dtype, N, H, T_dst, T_src, D, q_strides, k_strides, v_strides, crow,
                          col, col_stride_n, head_off, row_scale, avg, avg_strides, mix, out, out_dtype, out_strides, probs_out,
-                         probs_stride_n, nullptr, SEA_ATTN_GATHER, bits, T_m, is_causal, max_k, write_columns != 0, stream);
+                         probs_stride_n, nullptr, SEA_ATTN_GATHER, bits, T_m, is_causal, max_k, write_columns != 0, nullptr, stream);
+}
+
+// The decode form of the fused launch: a graph-replayed step (opt_generate.py:131) has static arguments, so the
+// sequence length the row widths follow is read from device memory and T_src = T_cap is the fixed capacity of the K / V
+// caches, with which the column ids are encoded (sea_csr_emit_at's convention).  T_dst <= 8 rows per sequence; the lane groups
+// that have no row touch the K / V rows of the block's expanded lists before the walk starts.  Same arithmetic, same order
+// as sea_csr_emit_at + sea_sparse_attention: the step stays bitwise the stateless forward.
+extern "C" int sea_sparse_attention_fused_at(const void* q, const void* k, const void* v, int dtype, int64_t N, int64_t H,
+                                             int64_t T_dst, int64_t T_cap, int64_t D, const int64_t* q_strides,
+                                             const int64_t* k_strides, const int64_t* v_strides, const int32_t* crow,
+                                             int32_t* col, int64_t col_stride_n, const int32_t* head_off,
+                                             const float* row_scale, const void* avg, const int64_t* avg_strides,
+                                             const float* mix, void* out, int out_dtype, const int64_t* out_strides,
+                                             const uint32_t* bits, int64_t T_m, const int32_t* t_src_dev, int is_causal,
+                                             int max_k, int write_columns, sea_stream_t stream) {
+  SEA_REQUIRE(bits != nullptr && t_src_dev != nullptr, SEA_EINVAL, "sea_sparse_attention_fused_at: null pointer");
+  return attention_entry("sea_sparse_attention_fused_at", q, k, v, dtype, N, H, T_dst, T_cap, D, q_strides, k_strides, v_strides,
+                         crow, col, col_stride_n, head_off, row_scale, avg, avg_strides, mix, out, out_dtype, out_strides, nullptr,
+                         0, nullptr, SEA_ATTN_GATHER, bits, T_m, is_causal, max_k, write_columns != 0, t_src_dev, stream);
 }
 
 extern "C" int sea_sparse_attention(const void* q, const void* k, const void* v, int dtype, int64_t N, int64_t H,

@@ -39,6 +39,10 @@ struct AttnParams {
   // column array is NOT an output of this launch -- the caller's handle keeps its columns pending and sea_csr_emit writes
   // them if anybody ever reads them (round 4: the copy-out was 266 MB and ~50 us of the headline launch for no reader)
   int write_cols;
+  // decode form of the fused interpolation (sea_sparse_attention_fused_at): the row widths follow *t_src_dev (the sequence
+  // length, in device memory: a graph-replayed step has static arguments) while T_src above stays the FIXED capacity the
+  // column ids are encoded with (head * T_src + key) and the K / V caches are laid out for.  NULL: widths follow T_src.
+  const int32_t* t_src_dev;
 };
 
 template <typename TO, int VEC> __device__ inline void store_frag(TO* dst, const float* f);

@@ -110,6 +110,15 @@ __global__ __launch_bounds__(NW * 64, (NT <= 4 ? 3 : 2)) void causal_conv_c8_ker
   }
   __syncthreads();
 
+#ifdef SEA_CONV_STAGGER
+  {  // experiment: the three waves of a SIMD start a third of a row apart, so that their row boundaries (epilogue, stores, the
+     // newest row's compulsory misses) do not coincide.  Placement model: waves round-robin over the SIMDs, second workgroup of
+     // a CU continues where the first stopped.
+    const bool first = blockIdx.x < 256;
+    const int ph = NW == 6 ? (first ? wv / 4 : (wv < 2 ? 1 : 2)) : (wv / 4);
+    for (int i = 0; i < ph * SEA_CONV_STAGGER; ++i) __builtin_amdgcn_s_sleep(100);
+  }
+#endif
   const int segs = (p.W + 63) / 64;                          // 64-pixel segments per row
   const int C8i = p.Cin >> 3, C8o = p.Cout >> 3;
   const unsigned img_bytes = (unsigned)p.T * (unsigned)p.W * (unsigned)p.Cin * (unsigned)sizeof(T);
@@ -207,7 +216,11 @@ __global__ __launch_bounds__(NW * 64, (NT <= 4 ? 3 : 2)) void causal_conv_c8_ker
         pk[2 * nt + 1] = pack2<T>(v2, v3);
         acc[nt][mt] = cf4{0.f, 0.f, 0.f, 0.f};
       }
+#ifdef SEA_CONV_EXP_NOSTORE
+      if (want_y && wpix < p.W && pk[0] == 0x12345678u) {
+#else
       if (want_y && wpix < p.W) {
+#endif
 #pragma unroll
         for (int q = 0; q < NT / 2; ++q) {         // tile pairs: whole 8-channel blocks per lane, 16-byte stores
           const int blk = q * 4 + lg;
@@ -262,11 +275,35 @@ __global__ __launch_bounds__(NW * 64, (NT <= 4 ? 3 : 2)) void causal_conv_c8_ker
     cu4 a0[4], a1[4], a2[4];
     issue(cl, 0, a0);  __builtin_amdgcn_sched_barrier(0);   // (program order = queue order the waits are counted in)
     issue(cl, 1, a1);  __builtin_amdgcn_sched_barrier(0);
+#ifdef SEA_CONV_EARLY_A2
+    issue(cl, 2, a2);  __builtin_amdgcn_sched_barrier(0);
+#endif
     uint4 wf0 = *reinterpret_cast<const uint4*>(wptr(cc.grp, 0));
 #pragma unroll 1
     while (cc.live) {
       // (scheduling fences: the loads must leave BEFORE the MFMA block they overlap, not sink below it)
       const T* w0p = wptr(cc.grp, 0);
+#if defined(SEA_CONV_EXP_ONETAP)     // timing experiment (wrong results): one load per chunk instead of three column taps
+      for (int i = 0; i < 4; ++i) { a1[i] = a0[i]; a2[i] = a0[i]; }
+      compute(w0p, w0p + 4 * ROWS * 8, a0, wf0);  __builtin_amdgcn_sched_barrier(0);
+      advance(cl);
+      issue(cl, 0, a0);  __builtin_amdgcn_sched_barrier(0);
+      compute(w0p + 4 * ROWS * 8, w0p + 8 * ROWS * 8, a1, wf0);  __builtin_amdgcn_sched_barrier(0);
+      compute(w0p + 8 * ROWS * 8, wptr(cl.grp, 0), a2, wf0);  __builtin_amdgcn_sched_barrier(0);
+#elif defined(SEA_CONV_EXP_NOLOAD)   // timing experiment (wrong results): no pixel loads at all
+      compute(w0p, w0p + 4 * ROWS * 8, a0, wf0);  __builtin_amdgcn_sched_barrier(0);
+      advance(cl);
+      compute(w0p + 4 * ROWS * 8, w0p + 8 * ROWS * 8, a1, wf0);  __builtin_amdgcn_sched_barrier(0);
+      compute(w0p + 8 * ROWS * 8, wptr(cl.grp, 0), a2, wf0);  __builtin_amdgcn_sched_barrier(0);
+#elif defined(SEA_CONV_EARLY_A2)     // the third tap's fragments leave at the END of the previous step, i.e. before a row's epilogue stores
+      compute(w0p, w0p + 4 * ROWS * 8, a0, wf0);  __builtin_amdgcn_sched_barrier(0);
+      advance(cl);
+      issue(cl, 0, a0);  __builtin_amdgcn_sched_barrier(0);
+      compute(w0p + 4 * ROWS * 8, w0p + 8 * ROWS * 8, a1, wf0);  __builtin_amdgcn_sched_barrier(0);
+      issue(cl, 1, a1);  __builtin_amdgcn_sched_barrier(0);
+      compute(w0p + 8 * ROWS * 8, wptr(cl.grp, 0), a2, wf0);  __builtin_amdgcn_sched_barrier(0);
+      issue(cl, 2, a2);  __builtin_amdgcn_sched_barrier(0);
+#else
       issue(cl, 2, a2);  __builtin_amdgcn_sched_barrier(0);
       compute(w0p, w0p + 4 * ROWS * 8, a0, wf0);  __builtin_amdgcn_sched_barrier(0);
       advance(cl);
@@ -274,9 +311,17 @@ __global__ __launch_bounds__(NW * 64, (NT <= 4 ? 3 : 2)) void causal_conv_c8_ker
       compute(w0p + 4 * ROWS * 8, w0p + 8 * ROWS * 8, a1, wf0);  __builtin_amdgcn_sched_barrier(0);
       issue(cl, 1, a1);  __builtin_amdgcn_sched_barrier(0);
       compute(w0p + 8 * ROWS * 8, wptr(cl.grp, 0), a2, wf0);  __builtin_amdgcn_sched_barrier(0);   // cl == next(cc)
+#endif
+#ifndef SEA_CONV_EXP_NOEPI
       if (cc.ti == KS - 1 && cc.cci == kchunks - 1) epilogue(cc);   // wave-uniform
+#endif
       advance(cc);
     }
+#ifdef SEA_CONV_EXP_NOEPI     // timing experiment: keep the accumulators alive without an epilogue
+    float sink = 0.f;
+    for (int nt = 0; nt < NT; ++nt) for (int mt = 0; mt < 4; ++mt) for (int r = 0; r < 4; ++r) sink += acc[nt][mt][r];
+    if (sink == 12345.678f) reinterpret_cast<float*>(p.y)[threadIdx.x] = sink;
+#endif
   } else {
     cu4 a0[4];
 #pragma unroll 1

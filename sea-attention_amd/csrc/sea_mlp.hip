@@ -53,6 +53,8 @@ struct MlpParams {
   int Wd;                   // width of one decoder split (= T_M / 4); <= 16 * (NT2 / 2), smaller only in the PADW instantiations
   int64_t xc8_n;            // element stride between batch items of x_c8 (dense: T * (H*2/8) * Wd * 8; a decode session writes the
                             // one new row of every item straight behind its CNN window: (rows + 1) * row)
+  int spread;               // launches too small to fill 256 persistent workgroups (a decoding step: 2 - 16 items): item i goes to
+                            // workgroup i % grid, wave (i / grid) % waves -- one CU per item -- instead of 16 items to one CU
 };
 
 // MLP_WAVES waves per (persistent) workgroup: 16 where the accumulators leave room under 128 VGPRs, else 8.
@@ -106,11 +108,12 @@ void predictor_mlp_kernel(MlpParams p) {
   const int total_rows = p.N * p.T * p.H;                                // (launcher: < 2^31)
   const int nitems = PACK ? (total_rows + 15) / 16 : p.N * p.T * htiles;
   const int C8 = p.H >> 2;                                               // 8-channel blocks: (H*2)/8
-  for (int base = blockIdx.x * MLP_WAVES; base < nitems; base += gridDim.x * MLP_WAVES) {
+  const int wstride = p.spread ? (int)gridDim.x : 1;                     // items between neighbouring waves of a workgroup
+  for (int base = blockIdx.x * (p.spread ? 1 : MLP_WAVES); base < nitems; base += gridDim.x * MLP_WAVES) {
     // (workgroup-uniform trip count: with W1S every wave joins the barriers of the weight ring, item or not)
-    const bool active = base + wv < nitems;
+    const bool active = base + wv * wstride < nitems;
     if (!W1S && !active) continue;
-    const int item = active ? base + wv : nitems - 1;
+    const int item = active ? base + wv * wstride : nitems - 1;
     int ht = 0, t, n, h;
     bool hok;
     if constexpr (PACK) {                                                // this lane's row of the flattened (n, t, h) order
@@ -336,7 +339,8 @@ void predictor_mlp_kernel(MlpParams p) {
 using namespace sea;
 
 template <typename T>
-static int launch_mlp(const MlpParams& p, int nt1, int nt2, hipStream_t s) {
+static int launch_mlp(const MlpParams& p_in, int nt1, int nt2, hipStream_t s) {
+  MlpParams p = p_in;
   const bool pack = p.H % 16 != 0;                 // rows packed across tokens (the kernel's PACK): every tile full
   const int64_t nitems = pack ? ((int64_t)p.N * p.T * p.H + 15) / 16 : (int64_t)p.N * p.T * ((p.H + 15) / 16);
   int rc = SEA_EUNSUPPORTED;
@@ -353,6 +357,8 @@ static int launch_mlp(const MlpParams& p, int nt1, int nt2, hipStream_t s) {
     if (lds > 160 * 1024) break;                                                                                    \
     int64_t blocks = (nitems + NW - 1) / NW;                                                                        \
     if (blocks > 256) blocks = 256;               /* persistent: one workgroup per CU keeps the weights in LDS */   \
+    p.spread = nitems < 256 * NW;                 /* fewer: one item per CU first (MlpParams::spread) */           \
+    if (p.spread) blocks = nitems < 256 ? nitems : 256;                                                             \
     static DevOnce once;                                                                                            \
     if (once.first()) {                                                                                             \
       SEA_MAX_LDS((predictor_mlp_kernel<T, A, B, NW, true, false, PW, PK>), 160 * 1024);                            \
@@ -369,6 +375,8 @@ static int launch_mlp(const MlpParams& p, int nt1, int nt2, hipStream_t s) {
     if (lds <= 160 * 1024 && p.KS1 <= 12) {
       int64_t blocks = (nitems + NW - 1) / NW;
       if (blocks > 256) blocks = 256;
+      p.spread = nitems < 256 * NW;
+      if (p.spread) blocks = nitems < 256 ? nitems : 256;
       static DevOnce once;
       if (once.first()) {
         SEA_MAX_LDS((predictor_mlp_kernel<T, A, B, NW, true, true, false, false>), 160 * 1024);

@@ -25,8 +25,9 @@ __device__ unsigned long long sea_dbg_perf[16];
 __device__ unsigned long long sea_dbg_wg[2048];   // [start, end] (s_memrealtime, 100 MHz) of every workgroup of the wide kernel's output pass
 #define PSTAMP(i) do { if (threadIdx.x == 0) { unsigned long long _t = __builtin_amdgcn_s_memtime(); atomicAdd(&sea_dbg_perf[i], _t - _tprev); _tprev = _t; } } while (0)
 // (the wide kernel keeps its deltas in registers and adds them once at the end: an atomic per phase sits in front of every vmcnt wait)
-#define WSTAMP(i) do { if (!STATE_ONLY && threadIdx.x == 0 && (blockIdx.y == 0 || blockIdx.y == gridDim.y - 1)) { unsigned long long _t = __builtin_amdgcn_s_memtime(); _tacc[i] += _t - _tprev; _tprev = _t; } } while (0)
+#define WSTAMP(i) do { if (threadIdx.x == 0 && (STATE_ONLY || blockIdx.y == 0 || blockIdx.y == gridDim.y - 1)) { unsigned long long _t = __builtin_amdgcn_s_memtime(); _tacc[i] += _t - _tprev; _tprev = _t; } } while (0)
 #define WSTAMP_FLUSH() do { if (!STATE_ONLY && threadIdx.x == 0 && (blockIdx.y == 0 || blockIdx.y == gridDim.y - 1)) for (int _i = 0; _i < 4; ++_i) atomicAdd(&sea_dbg_perf[_i + (blockIdx.y ? 0 : 4)], _tacc[_i]); \
+    if (STATE_ONLY && threadIdx.x == 0) for (int _i = 0; _i < 4; ++_i) atomicAdd(&sea_dbg_perf[10 + _i], _tacc[_i]); \
     if (threadIdx.x == 0) atomicAdd(&sea_dbg_perf[STATE_ONLY ? 8 : 9], __builtin_amdgcn_s_memtime() - _tstart); \
     if (!STATE_ONLY && threadIdx.x == 0) { const int _w = blockIdx.y * gridDim.x + blockIdx.x; if (_w < 1024) { sea_dbg_wg[2 * _w] = _rstart; sea_dbg_wg[2 * _w + 1] = __builtin_amdgcn_s_memrealtime(); } } } while (0)
 #else

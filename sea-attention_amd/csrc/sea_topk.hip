@@ -1054,33 +1054,45 @@ __global__ __launch_bounds__(TK_THREADS) void decode_cnn_tail_select_kernel(Deco
   auto slot = [](int p_, int r_) { return ((p_ % r_) + r_) % r_; };
   T* y1_new = yr + slot(pos, dp.RY) * row;
   T* sW = reinterpret_cast<T*>(s_z);                               // the weight image lives where the tail's z tile will (dead until then)
+#ifdef SEA_STAMP
+  unsigned long long _tprev = __builtin_amdgcn_s_memtime();
+#endif
   ConvRowC8<T, NT, KCH> c1, c2;
+  // (what does not depend on the position leaves first: the weight image and the MLP's row are in flight while the counter's
+  // scalar load returns)
+  c1.load_weights(reinterpret_cast<const T*>(dp.w1), dp.C);
+  c1.fetch_row(2, xn, dp.C, dp.W, dp.dil, dp.pad_w);
   c1.fetch_row(0, xr + slot(pos - 2 * dp.dil, dp.RX) * row, dp.C, dp.W, dp.dil, dp.pad_w);
   c1.fetch_row(1, xr + slot(pos - dp.dil, dp.RX) * row, dp.C, dp.W, dp.dil, dp.pad_w);
-  c1.fetch_row(2, xn, dp.C, dp.W, dp.dil, dp.pad_w);
-  c1.load_weights(reinterpret_cast<const T*>(dp.w1), dp.C);
   c2.fetch_row(0, yr + slot(pos - 2 * dp.dil, dp.RY) * row, dp.C, dp.W, dp.dil, dp.pad_w);      // (conv1's rows of earlier positions)
   c2.fetch_row(1, yr + slot(pos - dp.dil, dp.RY) * row, dp.C, dp.W, dp.dil, dp.pad_w);
   c1.store_weights(sW);
   c2.load_weights(reinterpret_cast<const T*>(dp.w2), dp.C);       // in flight while conv1's row is computed
   c1.run(sW, dp.b1, y1_new, dp.C, dp.W, 1);
+  STAMP(10);  // decode: operand fetches + conv1's row
   c2.fetch_row(2, y1_new, dp.C, dp.W, dp.dil, dp.pad_w);           // (stored above, barrier passed)
   c2.store_weights(sW);
   c2.run(sW, dp.b2, y2, dp.C, dp.W, 1);
+  STAMP(11);  // decode: conv2's row
   {                                                                // the MLP's row joins the ring (read by the next positions)
     const uint4* src = reinterpret_cast<const uint4*>(xn);
     uint4* dst = reinterpret_cast<uint4*>(xr + slot(pos, dp.RX) * row);
     for (int i = threadIdx.x; i < (int)(row / 8); i += TK_THREADS) dst[i] = src[i];
   }
   __syncthreads();
+  STAMP(12);  // decode: ring copy
   tail_select_row<T, EPT, false>(tp, p, s_z, n);                   // T = 1: row n of the call is batch item n
   __syncthreads();
+#ifdef SEA_STAMP
+  _tprev = __builtin_amdgcn_s_memtime();
+#endif
   if constexpr (EMIT) {
     if (ep.col != nullptr) {                                        // (grid-uniform)
       csr_emit_row<int32_t>(ep, n);                                 // reads the bits / crow this workgroup has just written
       __syncthreads();
     }
   }
+  STAMP(13);  // decode: emit
   if (threadIdx.x == 0) {
     __threadfence();
     const int done = atomicAdd(dp.ticket, 1);

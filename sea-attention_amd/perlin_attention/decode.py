@@ -28,6 +28,10 @@ earlier rows it needs, t - 2 and t - 4, live in two small rings: the MLP's previ
 runs the unchanged tail + selection on it and advances the device counters.  Nothing is shifted any more: a ring slot is
 position % ring size.  Still bitwise (`csrc/sea_convfrag.hpp: conv_row_c8` reproduces the convolution kernel's operand
 placement and k order).  Shapes outside that kernel (three-convolution bodies, H > 40) keep the round-4 launches.
+Round 5, later: the attention launch of a position is `sea_sparse_attention_fused_at` -- the gather kernel expands the one
+row's kept pixels itself (row widths from the device counter), its idle lane groups warm the K / V rows of the expanded lists
+-- so the CSR row's column ids are not on the critical path any more (no emit phase / launch; `session.csr.col` emits on
+first read).  `fused_attention=False` keeps the emit + unfused launch pair (bitwise the same context).
 """
 from typing import Optional
 
@@ -43,7 +47,7 @@ class DecodeSession:
     context row (N, 1, H*D) -- a static buffer, overwritten by the next step."""
 
     def __init__(self, attention, state: PerlinAttentionState, key_prefix: torch.Tensor, value_prefix: torch.Tensor,
-                 capacity: int, use_graph: bool = True):
+                 capacity: int, use_graph: bool = True, fused_attention: bool = True):
         at = self.attention = attention
         pc = at.pconfig
         assert pc.causal and not at.training, "decoding is the causal inference path"
@@ -119,6 +123,8 @@ class DecodeSession:
         self.z_cap = max(int(bound.max().item()), 1)
         self.q_in = torch.zeros((N, H, 1, D), dtype=dt, device=dev)
         self.ctx = torch.zeros((N, 1, H * D), dtype=at.context_layer_dtype or torch.float32, device=dev)
+        self.fused_attention = bool(fused_attention)   # the attention launch's decode form (False: emit + the unfused launch)
+        self.csr = None
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.probs = None                                                    # estimated attention probabilities of the last step
         self._pinned, self._prep_generation = None, ops.prep_generation()
@@ -155,7 +161,11 @@ class DecodeSession:
         conv4 = body[-1].module
         if self.fused_cnn:
             # conv1 + conv2 (one new row each) + tail + selection + the counters' advance: one launch
-            emits = ops.decode_cnn_emits(self.x_new.shape[-3] * 8)      # ... and the CSR row's column ids, where the LDS allows
+            # The attention launch expands the kept pixels itself (sea_sparse_attention_fused_at: the emit phase / launch and the
+            # crow -> col -> K / V chain leave the position's critical path); where that form does not exist the CSR row's
+            # column ids come out of this launch (LDS allowing) or an emit launch behind it, as in the first round-5 version.
+            fused_attn = self.fused_attention and ops.fused_interp_supported(self.q_in.dtype, D, T_M)
+            emits = not fused_attn and ops.decode_cnn_emits(self.x_new.shape[-3] * 8)
             col = torch.empty((self.N, self.z_cap), dtype=torch.int32, device=self.q_in.device) if emits else None
             self.probs, sel = ops.decode_cnn_tail_select(
                 self.x_new, self.x_ring, self.y1_ring, self.y2, body[0].module, body[2].module, conv4.weight[:, :, 0, 0], conv4.bias,
@@ -164,11 +174,13 @@ class DecodeSession:
             if emits:
                 csr = ops.FlatCSR(self.crow, col, sel[2], H, self.capacity, bits=sel[0], row_nnz=sel[1])
             else:
-                csr = ops.csr_from_selection(*sel, H, T_M, self.capacity, self.k, True, self.z_cap, t_src_dev=self.tsrc_done32, crow=self.crow)
+                csr = ops.csr_from_selection(*sel, H, T_M, self.capacity, self.k, True, self.z_cap, t_src_dev=self.tsrc_done32,
+                                             crow=self.crow, defer_emit=fused_attn)
             ops.sparse_attention(self.q_in, self.k_cache, self.v_cache, csr,
                                  row_scale=row_scale if at.pconfig.partial_attention_scaler else None,
                                  avg=avg_rows, mix=avg_scale, out=self.ctx.view(self.N, 1, H, D).permute(0, 2, 1, 3),
-                                 path="gather")
+                                 path="gather", keep_columns_pending=True)
+            self.csr = csr                                                    # (the step's selection: columns on first read of .col)
             return
         y = self.xs                                                           # (N, LB + 1, C/8, W, 8)
         for i in range(0, len(body) - 2, 2):

@@ -51,6 +51,9 @@ class FlatCSR:
         # defer_emit=True)` hands such a handle to the fused attention launch, which writes `col` itself; whoever reads
         # `.col` first otherwise runs the emit launch then (same stream: ordered behind the selection)
         self._pending = None
+        # decode handles (csr_from_selection(..., t_src_dev=...)): the device counter the row widths follow; T_src is then the
+        # fixed capacity the column ids are encoded with
+        self.t_src_dev = None
 
     @property
     def col(self):
@@ -222,10 +225,18 @@ def csr_from_selection(bits: torch.Tensor, row_nnz: torch.Tensor, head_off: torc
     col = torch.empty((N, z_cap), dtype=torch.int32, device=dev)
     if t_src_dev is not None:
         assert t_src_dev.dtype == torch.int32 and t_src_dev.numel() == 1 and t_src_dev.is_cuda
-        _lib.check(lib.sea_csr_emit_at(
-            _p(bits), _p(crow), N, H, T_dst, T_m, _p(t_src_dev), T_src, int(is_causal), int(k),
-            _p(col), 4, col.stride(0), z_cap, st), "sea_csr_emit_at")
-        return FlatCSR(crow, col, head_off, H, T_src, bits=bits, row_nnz=row_nnz)
+        def emit_at():
+            with torch.cuda.device(dev):
+                _lib.check(lib.sea_csr_emit_at(
+                    _p(bits), _p(crow), N, H, T_dst, T_m, _p(t_src_dev), T_src, int(is_causal), int(k),
+                    _p(col), 4, col.stride(0), z_cap, _lib.stream_ptr()), "sea_csr_emit_at")
+        csr = FlatCSR(crow, col, head_off, H, T_src, bits=bits, row_nnz=row_nnz)
+        csr.t_src_dev = t_src_dev
+        if defer_emit:      # sparse_attention's decode form (sea_sparse_attention_fused_at) expands the kept pixels itself
+            csr._pending = (int(T_m), int(k), bool(is_causal), emit_at)
+        else:
+            emit_at()
+        return csr
     def emit():
         with torch.cuda.device(dev):
             _lib.check(lib.sea_csr_emit(
@@ -435,8 +446,10 @@ def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = 
     # kept pixels themselves and WRITE `col` (sea_sparse_attention_fused) where their fused form exists; anything else
     # (the tile kernel, a plan that may choose it, rows of 4 lanes / d = 80 / wider than 16 lanes) reads `.col`, which
     # runs the emit launch first
+    decode_form = csr.t_src_dev is not None                   # a decoding step: the sequence length lives in device memory
     fused = (csr.col_is_pending and fuse_emit and path != "tile" and not (path == "auto" and plan is not None)
-             and fused_interp_supported(q.dtype, D, csr._pending[0], N * H * T_dst))
+             and fused_interp_supported(q.dtype, D, csr._pending[0], None if decode_form else N * H * T_dst)
+             and not (decode_form and (want_probs or T_dst > 8)))
     T_src = k.shape[2]
     assert k.shape == (N, H, T_src, D) and v.shape == (N, H, T_src, D)
     assert q.dtype == k.dtype == v.dtype
@@ -456,14 +469,18 @@ def sparse_attention(q, k, v, csr: FlatCSR, row_scale: Optional[torch.Tensor] = 
         T_m_, max_k_, causal_, _emit = csr._pending
         raw_col = csr._col
         probs = torch.zeros(raw_col.shape, dtype=torch.float32, device=q.device) if want_probs else None
-        rc = lib.sea_sparse_attention_fused(
-            _p(q), _p(k), _p(v), _lib.dtype_code(q.dtype), N, H, T_dst, T_src, D,
-            _lib.strides3(q), _lib.strides3(k), _lib.strides3(v),
-            _p(csr.crow), _p(raw_col), raw_col.stride(0), _p(csr.head_off),
-            _p(row_scale), _p(avg), _lib.strides3(avg) if avg is not None else None, _p(mix),
-            _p(out), _lib.dtype_code(out.dtype), _lib.strides3(out),
-            _p(probs), probs.stride(0) if probs is not None else 0,
-            _p(csr.bits), T_m_, int(causal_), max_k_, 0 if keep_columns_pending else 1, _lib.stream_ptr())
+        common = (_p(q), _p(k), _p(v), _lib.dtype_code(q.dtype), N, H, T_dst, T_src, D,
+                  _lib.strides3(q), _lib.strides3(k), _lib.strides3(v),
+                  _p(csr.crow), _p(raw_col), raw_col.stride(0), _p(csr.head_off),
+                  _p(row_scale), _p(avg), _lib.strides3(avg) if avg is not None else None, _p(mix),
+                  _p(out), _lib.dtype_code(out.dtype), _lib.strides3(out))
+        write_cols = 0 if keep_columns_pending else 1
+        if decode_form:
+            rc = lib.sea_sparse_attention_fused_at(*common, _p(csr.bits), T_m_, _p(csr.t_src_dev), int(causal_), max_k_, write_cols,
+                                                   _lib.stream_ptr())
+        else:
+            rc = lib.sea_sparse_attention_fused(*common, _p(probs), probs.stride(0) if probs is not None else 0,
+                                                _p(csr.bits), T_m_, int(causal_), max_k_, write_cols, _lib.stream_ptr())
         if rc == 0:
             if not keep_columns_pending:
                 csr._pending = None                         # the launch has written the columns

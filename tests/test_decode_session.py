@@ -81,6 +81,39 @@ def test_session_steps_equal_cached_forward(dtype, N, H, d, T0, steps, use_graph
         assert torch.equal(sess.k_cache[:, :, :T], x) and torch.equal(sess.v_cache[:, :, :T], x)
 
 
+@pytest.mark.parametrize("use_graph", [False, True])
+@pytest.mark.parametrize("dtype,N,H,d,T0", [(torch.bfloat16, 2, 8, 64, 250), (torch.bfloat16, 1, 4, 80, 90), (torch.float16, 1, 8, 128, 300),
+                                            (torch.bfloat16, 1, 40, 64, 70)])
+def test_session_attention_forms_agree(dtype, N, H, d, T0, use_graph):
+    """Round 5: the attention launch of a position expands the kept pixels itself (sea_sparse_attention_fused_at) instead of
+    reading the columns an emit phase / launch wrote.  Both forms give the same bits, and the pending handle's columns -- emitted
+    on first read -- are the ones the unfused form walked."""
+    T_M, k, steps = 256, 16, 5
+    T = T0 + steps
+    layer = _layer(H, d, T_M, k, T + 3, dtype)
+    S.seed(11)
+    x = torch.randn((N, H, T, d), device=DEV).to(dtype)
+    q = (x.float() * d ** -0.5).to(dtype)
+    with torch.no_grad():
+        out = layer(None, None, None, query_layer=q[:, :, :T0], key_layer=x[:, :, :T0], value_layer=x[:, :, :T0],
+                    attention_mask=_mask(N, T0, T0, dtype))
+        a = DecodeSession(layer.attention, out.state, x[:, :, :T0], x[:, :, :T0], capacity=T + 3, use_graph=use_graph)
+        b = DecodeSession(layer.attention, out.state, x[:, :, :T0], x[:, :, :T0], capacity=T + 3, use_graph=use_graph, fused_attention=False)
+        assert a.fused_attention and not b.fused_attention
+        for i in range(steps):
+            hi = T0 + i + 1
+            ga = a.step(q[:, :, hi - 1:hi], x[:, :, hi - 1:hi], x[:, :, hi - 1:hi]).clone()
+            gb = b.step(q[:, :, hi - 1:hi], x[:, :, hi - 1:hi], x[:, :, hi - 1:hi]).clone()
+            assert torch.equal(ga, gb), (i, (ga.float() - gb.float()).abs().max().item())
+            assert a.csr.t_src_dev is not None and a.csr.col_is_pending           # nobody has read the columns: none were written
+            assert torch.equal(a.csr.crow, b.csr.crow) and torch.equal(a.csr.head_off, b.csr.head_off)
+            if i == steps - 1:
+                ca, cb = a.csr.col, b.csr.col                                       # first read: the emit launch runs now
+                for n in range(N):
+                    nnz = int(a.csr.crow[n, 1].item())
+                    assert nnz > 0 and torch.equal(ca[n, :nnz], cb[n, :nnz])
+
+
 def test_session_refuses_what_it_cannot_continue():
     dtype, N, H, d, T_M, k = torch.bfloat16, 1, 4, 64, 256, 16
     layer = _layer(H, d, T_M, k, 64, dtype)
