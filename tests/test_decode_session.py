@@ -114,6 +114,57 @@ def test_session_attention_forms_agree(dtype, N, H, d, T0, use_graph):
                     assert nnz > 0 and torch.equal(ca[n, :nnz], cb[n, :nnz])
 
 
+@pytest.mark.parametrize("dtype,H,d,T_src,k,heavy", [(torch.bfloat16, 4, 64, 3000, 64, True),    # one head takes ~3000 entries: 12 chunks of 256
+                                                     (torch.float16, 4, 128, 3000, 64, True),    # 16-lane rows: chunks of 128
+                                                     (torch.bfloat16, 4, 64, 3000, 4, True),     # every pixel thinned to max_k = 4
+                                                     (torch.bfloat16, 8, 64, 517, 16, False),    # ragged step boundary (entries % 4 != 0)
+                                                     (torch.bfloat16, 4, 80, 3000, 64, True),    # d = 80: the lane-group decode form
+                                                     (torch.bfloat16, 4, 64, 1, 64, False)])     # the very first position: one key
+def test_decode_attention_operator_forms_agree(dtype, H, d, T_src, k, heavy):
+    """`sea_sparse_attention_fused_at` (one new row per sequence: sparse_attn_decode1_kernel -- the whole workgroup serves the
+    row) against `sea_csr_emit_at` + the unfused launch on one selection: bitwise, for rows far longer than a chunk, thinned
+    pixels, ragged ends and empty heads."""
+    from sea_attention_amd.perlin_attention import ops
+    N, T_m, T_cap = 2, 256, T_src + 40
+    S.seed(5)
+    probs = torch.rand((N, H, 1, T_m), device=DEV) * 0.1
+    if heavy:
+        probs[:, 0] += 1.0                                                  # head 0 wins the pooled top-k
+        probs[1, 1] = 0.0                                                   # ... and item 1's head 1 keeps nothing
+    probs = probs.to(dtype)
+    keep = torch.full((1,), (H * T_m) // 3 if heavy else 37, dtype=torch.int32, device=DEV)
+    lib_bits = ops.topk_to_csr(probs, keep, k, target_width=T_src, is_causal=True)[0]
+    bits, row_nnz, head_off = lib_bits.bits, lib_bits.row_nnz, lib_bits.head_off
+    crow = torch.stack([torch.zeros_like(row_nnz[:, 0]), row_nnz[:, 0]], 1).contiguous()
+    z_cap = max(int(row_nnz.max().item()), 1)
+    ts = torch.tensor([T_src], dtype=torch.int32, device=DEV)
+    q = torch.randn((N, H, 1, d), device=DEV).to(dtype)
+    kk = torch.randn((N, H, T_cap, d), device=DEV).to(dtype)
+    vv = torch.randn((N, H, T_cap, d), device=DEV).to(dtype)
+    rs = torch.rand((N, H, 1), device=DEV)
+    avg = torch.randn((N, H, 1, d), device=DEV).to(dtype)
+    mix = torch.rand((N, H, 1), device=DEV)
+    outs = []
+    for defer in (True, False):
+        csr = ops.csr_from_selection(bits, row_nnz, head_off, H, T_m, T_cap, k, True, z_cap, t_src_dev=ts, crow=crow, defer_emit=defer)
+        assert csr.col_is_pending == defer
+        o = ops.sparse_attention(q, kk, vv, csr, row_scale=rs, avg=avg, mix=mix, path="gather", keep_columns_pending=True,
+                                 out_dtype=dtype if defer else None, out=None)
+        outs.append((o, csr))
+    (oa, ca), (ob, cb) = outs
+    assert ca.col_is_pending                                                 # the decode form wrote no columns
+    ob16 = ops.sparse_attention(q, kk, vv, cb, row_scale=rs, avg=avg, mix=mix, path="gather", out_dtype=dtype)
+    assert torch.isfinite(oa.float()).all() and torch.equal(oa, ob16), (oa.float() - ob16.float()).abs().max().item()
+    o32 = ops.sparse_attention(q, kk, vv, ca, row_scale=rs, avg=avg, mix=mix, path="gather", keep_columns_pending=True)   # fp32 context
+    assert torch.equal(o32, ob)
+    if heavy:
+        assert int((head_off[0, 0, 1] - head_off[0, 0, 0]).item()) > (1000 if k > 4 else 300)
+        assert int((head_off[1, 0, 2] - head_off[1, 0, 1]).item()) == 0
+        assert torch.equal(oa[1, 1].float(), ((1.0 - mix[1, 1]).view(1, 1) * avg[1, 1].float()).to(dtype).float())     # empty head: the average alone
+    for n in range(N):                                                      # the pending handle's columns, emitted on first read
+        assert torch.equal(ca.col[n, :int(row_nnz[n, 0])], cb.col[n, :int(row_nnz[n, 0])])
+
+
 def test_session_refuses_what_it_cannot_continue():
     dtype, N, H, d, T_M, k = torch.bfloat16, 1, 4, 64, 256, 16
     layer = _layer(H, d, T_M, k, 64, dtype)
