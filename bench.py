@@ -521,21 +521,26 @@ def decode_leg(layer, q, kk, v, mask, NB, T, positions):
     lc_.pconfig = copy.copy(layer.pconfig); lc_.pconfig.use_cache = True
     lc_.attention.pconfig = lc_.pconfig
     nd = max(1, min(positions, T // 2))
-    T0 = T - nd - 8
+    passes = 3 if 3 * nd + 8 <= T // 2 else 1               # the median pass is reported: one host hiccup (allocator, GC) inside a
+    T0 = T - passes * nd - 8                                 # 32-position pass once read 2.2 ms per position instead of 0.075
     with torch.no_grad():
         pre = lc_(None, None, None, query_layer=q[:NB, :, :T0], key_layer=kk[:NB, :, :T0], value_layer=v[:NB, :, :T0],
                   attention_mask=mask[:NB, :, :T0, :T0].contiguous())
         sess = DecodeSession(lc_.attention, pre.state, kk[:NB, :, :T0], v[:NB, :, :T0], capacity=T, use_graph=True)
         for i in range(4):
             sess.step(q[:NB, :, T0 + i:T0 + i + 1], kk[:NB, :, T0 + i:T0 + i + 1], v[:NB, :, T0 + i:T0 + i + 1])
-        torch.cuda.synchronize(); t0_ = time.perf_counter()
-        for i in range(4, 4 + nd):
-            sess.step(q[:NB, :, T0 + i:T0 + i + 1], kk[:NB, :, T0 + i:T0 + i + 1], v[:NB, :, T0 + i:T0 + i + 1])
-        torch.cuda.synchronize()
-        t_pos = (time.perf_counter() - t0_) / nd
+        per_pass = []
+        for ps in range(passes):
+            torch.cuda.synchronize(); t0_ = time.perf_counter()
+            for i in range(4 + ps * nd, 4 + (ps + 1) * nd):
+                sess.step(q[:NB, :, T0 + i:T0 + i + 1], kk[:NB, :, T0 + i:T0 + i + 1], v[:NB, :, T0 + i:T0 + i + 1])
+            torch.cuda.synchronize()
+            per_pass.append((time.perf_counter() - t0_) / nd)
+        t_pos = sorted(per_pass)[len(per_pass) // 2]
+        captures = getattr(sess, "captures", None)
     del sess, lc_, pre
     return {"ms_per_position": round(t_pos * 1e3, 4), "tokens_per_s": round(NB / t_pos, 1), "batch": NB, "prefix_tokens": T0,
-            "positions_timed": nd}
+            "positions_timed": nd, "passes_ms_per_position": [round(t * 1e3, 4) for t in per_pass], "graph_captures": captures}
 
 
 def train_step_leg(wname, args, dev):

@@ -1040,6 +1040,8 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
   float* sKsum = reinterpret_cast<float*>(sAl + C * LDA);           // [FP]
   float* sDenP = sKsum + FP;                                        // [C][DSL]
   float* sKsP = sDenP + C * DSL;                                    // [NW][FP]   per-wave k-sum increments
+  float* sKsP2 = sKsP + NW * FP;                                    // [NW][FP]   (state pass: the second chunk of an iteration)
+  unsigned short* sV2 = reinterpret_cast<unsigned short*>(sKsP2 + NW * FP);   // [C][EL] (state pass: the second chunk's [pos | v])
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -1493,6 +1495,184 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
       }
     }
   };
+  // ---- pass 1 (STATE_ONLY) walks TWO chunks per iteration on three barriers (round 5, late) --------------------------------------
+  // The state pass needs phi(K) and S += phi(K)^T [pos | v] only: no causal structure, nothing to store per row.  Walked like
+  // the output pass it spent its time between barriers with half the waves idle ((b): the four "K" waves; stamps: 1.65 us per
+  // 32-row chunk at d = 80 on four barriers, 2.7 us at d = 128 on two).  Here the four "Q" waves of (b) take the NEXT chunk's k
+  // rows (staged where q goes, phi images into the second image set), the k-sum partials are produced beside the state
+  // update and folded in one barrier later, and (e) runs for both chunks back to back.  Same operand placement and k order per
+  // chunk as before: the state tiles S are bit for bit the output pass's; the k-sum's partials are summed per chunk in the
+  // same fixed order.
+  if constexpr (STATE_ONLY) {
+    auto stage_k_to = [&](unsigned short* dst, const bu4& r) {
+      if (stager) *reinterpret_cast<bu4*>(dst + (sc * C + (sr ^ sc)) * 8) = r;
+    };
+    auto stage_v_to = [&](unsigned short* dst, const bu4& rp_, const bu4& rv_) {
+      if (stager) {
+        *reinterpret_cast<bu4*>(dst + sr * EL + vchunk(sr, sc) * 8) = rp_;
+        *reinterpret_cast<bu4*>(dst + sr * EL + vchunk(sr, CPR + sc) * 8) = rv_;
+      }
+    };
+    auto load_k = [&](int t0n) {
+      const int t = t0n + sr;
+      return __builtin_amdgcn_raw_buffer_load_b128(rk, (t < t_end && stager) ? (int)((t * p.ks[2] + sc * 8) * 2) : (int)OOB, 0, 0);
+    };
+    // phi(K) of one chunk by HALF the workgroup (the waves whose `which` selects it): src = staged k rows, dh = hi image
+    auto phase_bk = [&](int rows, const unsigned short* src, unsigned short* dh) {
+      const int rb = wv & (RB - 1), part = (BW - 1) - ((wv % (NW / 2)) / RB);
+      f4 acc[FBP];
+#pragma unroll
+      for (int fb = 0; fb < FBP; ++fb) acc[fb] = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < DP / 32; ++ks) {
+        const uint4 bx = *reinterpret_cast<const uint4*>(src + ((4 * ks + lg) * C + ((rb * 16 + li) ^ ((4 * ks + lg) & 15))) * 8);
+#pragma unroll
+        for (int fb = 0; fb < FBP; ++fb) {
+          const int fbg = part * FBP + fb;                   // (wave-uniform)
+          if (fbg < NBT) {
+            const uint4 aw = *reinterpret_cast<const uint4*>(sW + ((4 * ks + lg) * NBP + fbg * 16 + li) * 8);
+            acc[fb] = S16<T>::mfma(aw, bx, acc[fb]);
+          }
+        }
+      }
+      unsigned short* dl = dh + C * LDK2;
+      const int row = rb * 16 + li;
+#pragma unroll
+      for (int fb = 0; fb < FBP; ++fb) {
+        const int fbg = part * FBP + fb;
+        if (fbg < NBT) {
+          unsigned short hh[4], ll[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int f = fbg * 16 + lg * 4 + r;
+            float val = fmaxf(cnorm * acc[fb][r], 0.f) + 1e-3f;
+            if (f >= p.nb || row >= rows) val = 0.f;
+            split16<T>(val, hh[r], ll[r]);
+          }
+          const int pos = (fbg >> 1) * 32 + lg * 8 + (fbg & 1) * 4;
+          *reinterpret_cast<uint2*>(dh + row * LDK2 + pos) = pack4(hh);
+          *reinterpret_cast<uint2*>(dl + row * LDK2 + pos) = pack4(ll);
+        }
+      }
+    };
+    // per-wave k-sum increments of one chunk (phase (c)'s code) into `dst` [NW][FP]
+    auto ksum_partial = [&](const unsigned short* sKh, float* dst) {
+      const unsigned short* sKl = sKh + C * LDK2;
+      constexpr int FG = FP / 4, RRN = 64 / FG, RPL = (C / NW) / RRN;
+      const int fc = lane % FG, rr = lane / FG;
+      float k4[4] = {0.f, 0.f, 0.f, 0.f};
+      if (rr < RRN) {
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+          const int r2 = wv * (C / NW) + rr * RPL + j;
+          const uint2 kh = *reinterpret_cast<const uint2*>(sKh + r2 * LDK2 + fc * 4);
+          const uint2 kl = *reinterpret_cast<const uint2*>(sKl + r2 * LDK2 + fc * 4);
+          k4[0] += S16<T>::val((unsigned short)(kh.x & 0xffff)) + S16<T>::val((unsigned short)(kl.x & 0xffff));
+          k4[1] += S16<T>::val((unsigned short)(kh.x >> 16)) + S16<T>::val((unsigned short)(kl.x >> 16));
+          k4[2] += S16<T>::val((unsigned short)(kh.y & 0xffff)) + S16<T>::val((unsigned short)(kl.y & 0xffff));
+          k4[3] += S16<T>::val((unsigned short)(kh.y >> 16)) + S16<T>::val((unsigned short)(kl.y >> 16));
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (FG == 16) {
+          k4[j] = xor16_sum(xor32_sum(k4[j]));
+        } else {
+#pragma unroll
+          for (int o = FG * (RRN / 2); o >= FG; o >>= 1) k4[j] += __shfl_down(k4[j], o);
+        }
+      }
+      if (lane < FG) *reinterpret_cast<float4*>(dst + wv * FP + fc * 4) = make_float4(k4[0], k4[1], k4[2], k4[3]);
+    };
+    auto ksum_fold = [&](const float* src) {                 // fixed order: bitwise reproducible
+      if (tid < FP) {
+        float s_ = sKsum[tid];
+#pragma unroll
+        for (int i = 0; i < NW; ++i) s_ += src[i * FP + tid];
+        sKsum[tid] = s_;
+      }
+    };
+    // column totals of v and S += phi(K)^T [pos | v] for one chunk: phase (d)(e)'s STATE_ONLY code
+    auto phase_e = [&](const unsigned short* sVi, const unsigned short* sKh) {
+      const unsigned short* sKl = sKh + C * LDK2;
+      const int q = li >> 2, pp_ = li & 3;
+      // V fragments of BOTH column blocks of the wave first: a phi(K) fragment, which depends on (feature block, k-step) only, is
+      // then read ONCE and feeds both blocks' state tiles (the output pass's loop reads it per block: 40 transposing reads per
+      // chunk and wave at d = 128, all eight waves reading the same 12 KB of images -- the phase is bound by the LDS array)
+      uint4 vf[JB][C / 32];
+      bool has[JB];
+#pragma unroll
+      for (int jq = 0; jq < JB; ++jq) {
+        const int jb = wv + jq * NW;
+        has[jq] = !(EB % NW != 0 && jb >= EB);               // (wave-uniform) no such column block
+        const int jbc = has[jq] ? jb : wv;
+#pragma unroll
+        for (int ks = 0; ks < C / 32; ++ks) {
+          const int r0 = ks * 32 + lg * 8;
+          const uint2 a = lds_tr(sVi + (r0 + q) * EL + vchunk(r0 + q, 2 * jbc + (pp_ >> 1)) * 8 + 4 * (pp_ & 1));
+          const uint2 b = lds_tr(sVi + (r0 + 4 + q) * EL + vchunk(r0 + 4 + q, 2 * jbc + (pp_ >> 1)) * 8 + 4 * (pp_ & 1));
+          vf[jq][ks] = cat8(a, b);
+        }
+        if (has[jq] && want_avg && jb >= EB / 2) {
+          f4 cum = f4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks <= (RB - 1) / 2; ++ks) cum = S16<T>::mfma(vf[jq][ks], tril[RB - 1][ks], cum);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) csum[jq][r] += __shfl(cum[r], (lane & 48) | 15);
+        }
+      }
+#pragma unroll
+      for (int rb = 0; rb < NBT; ++rb) {
+#pragma unroll
+        for (int ks = 0; ks < C / 32; ++ks) {
+          const int r0 = ks * 32 + lg * 8;
+          const int co = (rb >> 1) * 32 + 8 * pp_ + (rb & 1) * 4;
+          const uint4 kh = cat8(lds_tr(sKh + (r0 + q) * LDK2 + co), lds_tr(sKh + (r0 + 4 + q) * LDK2 + co));
+          const uint4 kl = cat8(lds_tr(sKl + (r0 + q) * LDK2 + co), lds_tr(sKl + (r0 + 4 + q) * LDK2 + co));
+#pragma unroll
+          for (int jq = 0; jq < JB; ++jq) {
+            if (has[jq]) {                                   // per tile: hi then lo, k-steps ascending -- the output pass's order
+              S[jq][rb] = S16<T>::mfma(kh, vf[jq][ks], S[jq][rb]);
+              S[jq][rb] = S16<T>::mfma(kl, vf[jq][ks], S[jq][rb]);
+            }
+          }
+        }
+      }
+    };
+    unsigned short* kA = sPhi + 2 * C * LDQ2;                // K images of the two sets
+    unsigned short* kB = sPhi + PHI + 2 * C * LDQ2;
+    // prefetch registers: pa = chunk A (k in .k, [pos | v] in .p / .v), pn = chunk B; the loads of the next iteration leave
+    // right after this iteration's registers went to LDS
+    pa.k = load_k(t_begin);  issue_v(t_begin, pa);            // (issue_qk / issue_v of the prologue above already asked for
+    pn.k = load_k(t_begin + C);  issue_v(t_begin + C, pn);    //  chunk A: the duplicates are dropped by the compiler or hit L1)
+    bool pending = false;                                    // k-sum partials of the previous iteration not folded yet
+    for (int t0 = t_begin; t0 < t_end; t0 += 2 * C) {
+      const bool two = t0 + C < t_end;                       // (block-uniform) the last iteration may hold one chunk
+      stage_k_to(sK, pa.k);  stage_v_to(sV, pa.p, pa.v);
+      stage_k_to(sQ, pn.k);  stage_v_to(sV2, pn.p, pn.v);
+      pa.k = load_k(t0 + 2 * C);  issue_v(t0 + 2 * C, pa);
+      pn.k = load_k(t0 + 3 * C);  issue_v(t0 + 3 * C, pn);
+      if (pending) { ksum_fold(sKsP); }
+      __syncthreads();                                       // staged rows visible; the fold above has read sKsP
+      if (pending) { ksum_fold(sKsP2); }                     // (second chunk of the previous iteration: after the first, same order)
+      if (wv >= NW / 2) phase_bk(rows_of(t0), sK, kA);
+      else if (two) phase_bk(rows_of(t0 + C), sQ, kB);
+      __syncthreads();                                       // phi(K) images visible
+      ksum_partial(kA, sKsP);
+      if (two) ksum_partial(kB, sKsP2);
+      else if (lane < FP / 4) *reinterpret_cast<float4*>(sKsP2 + wv * FP + lane * 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+      phase_e(sV, kA);
+      if (two) phase_e(sV2, kB);
+      pending = true;
+      __syncthreads();                                       // images, staging buffers and partials are free / complete
+    }
+    if (pending) { ksum_fold(sKsP); }
+    __syncthreads();
+    if (pending) { ksum_fold(sKsP2); }
+    __syncthreads();
+    write_image(p.carry + ((int64_t)nh * (p.nseg - 1) + seg) * CARRY);
+    return;
+  }
   // D = 80 keeps the phases one after the other (four barriers): pipelined, the median workgroup is 7 % faster (105 vs 113.6 us on
   // 1 x 32 x 8192) but the workgroups of the LAST segment run 10 us behind (every chunk's P2 is longer; not a cold-cache effect: a
   // warming walk changes nothing), and the launch ends later (128.5 vs 121.9 us; two-chunk prefetch: 5 us behind) -- DESIGN.md section 9
@@ -1629,7 +1809,8 @@ static int launch_perf_bf16w(const PerfParams& p, hipStream_t s) {
   constexpr int NTH = 512, NBP = NBT * 16, FP = ((NBT + 1) / 2) * 32, LDQ2 = FP + 16, LDK2 = (FP == 64) ? 96 : FP + 8, LDA = C + 16;
   constexpr int KC = (D + 31) / 32 * 4, EL = 256;
   constexpr size_t lds = 2 * (KC * NBP * 8 + 2 * KC * C * 8 + C * EL + 2 * (2 * C * LDQ2 + 2 * C * LDK2) + 2 * C * LDA) +
-                         sizeof(float) * (FP + C * (C / 16 + 8) + 8 * FP);
+                         sizeof(float) * (FP + C * (C / 16 + 8) + 8 * FP) +
+                         sizeof(float) * 8 * FP + 2 * C * EL;     // the state pass's second k-sum partials and second [pos | v] image
   static_assert(lds <= 160 * 1024, "LDS budget");
   static DevOnce once;
   if (once.first()) {

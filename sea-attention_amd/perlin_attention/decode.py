@@ -225,6 +225,7 @@ class DecodeSession:
         for dst, src in zip(mutable, saved):
             dst.copy_(src)
         self.graph = g
+        self.captures = getattr(self, "captures", 0) + 1
         self._pinned = pins
         self._prep_generation = ops.prep_generation()
 
