@@ -487,172 +487,6 @@ __global__ __launch_bounds__(NWB * 64, (FUSE && !DEC && sizeof(T) == 2 && !WP) ?
 //      the row's end included (probability exp(-inf) = 0 times the last entry's V row) -- the step stays bitwise the stateless
 //      forward (tests/test_decode_session.py, test_kv_cache.py).
 // Rows longer than CH entries pass through in chunks (state carried).  16-bit data, rows of 8 or 16 lanes, T_m <= 256.
-template <typename T, typename TO, int LPR>
-__global__ __launch_bounds__(256) void sparse_attn_decode1_kernel(AttnParams p) {
-  constexpr int VEC = Elem<T>::VEC, NT = 256, NG = NT / LPR, DL = LPR * VEC;
-  constexpr int CH = LPR == 8 ? 256 : 128;                 // entries per chunk: CH / 4 steps fit one wave, CH / NG = 8 per lane group
-  constexpr int EPG = CH / NG;
-  static_assert(VEC == 8 && CH / 4 <= 64 && CH % NG == 0, "16-bit rows; one lane per step in phase D");
-  extern __shared__ __attribute__((aligned(16))) char dsm[];
-  int* s_keys = reinterpret_cast<int*>(dsm);               // [CH]     key index (without the head offset)
-  float* s_sc = reinterpret_cast<float*>(s_keys + CH);     // [CH]     scores, then probabilities
-  float* s_al = s_sc + CH;                                 // [CH / 4] alpha per step
-  T* s_v = reinterpret_cast<T*>(s_al + CH / 4);            // [CH][DL] V rows
-  __shared__ int s_wsum[4];
-  __shared__ float s_mcarry;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  const int grp = tid / LPR, sub = tid - grp * LPR;
-  const int n = (int)blockIdx.x / p.H, h = (int)blockIdx.x - n * p.H;
-  const bool dact = sub * VEC < p.D;
-  const int sube = dact ? sub : 0;
-  const char* kbase = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.k) + n * p.ks[0] + h * p.ks[1]);
-  const char* vbase = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.v) + n * p.vs[0] + h * p.vs[1]);
-  const uint32_t kst = (uint32_t)p.ks[2] * (uint32_t)sizeof(T), vst = (uint32_t)p.vs[2] * (uint32_t)sizeof(T);
-  const uint32_t lane_off = (uint32_t)(sube * VEC) * (uint32_t)sizeof(T);
-  uint4 qraw = make_uint4(0, 0, 0, 0);
-  if (dact) qraw = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.q) + n * p.qs[0] + h * p.qs[1] + sub * VEC);
-  const int beg = p.crow[(int64_t)n * 2] + p.head_off[(int64_t)n * (p.H + 1) + h];
-  const int hcol = h * p.T_src;
-
-  // ---- B: one thread per pixel of the head --------------------------------------------------------------------------
-  const int w_t = row_width(0, 1, *p.t_src_dev, p.is_causal);
-  const float scale = interp_scale(w_t, p.T_m);
-  const uint32_t* brow = p.bits + (int64_t)n * p.W + h * (p.T_m >> 5);
-  const bool kept = tid < p.T_m && ((brow[tid >> 5] >> (tid & 31)) & 1u);
-  const int lo = (int)interp_bound(tid, scale), hi = (int)interp_bound(tid + 1, scale);
-  const int wd = hi - lo;
-  const int cnt = kept ? (wd < p.max_k ? wd : p.max_k) : 0;
-  const int incl = wave_incl_scan(cnt);
-  if (lane == 63) s_wsum[wv] = incl;
-  if (tid == 0) s_mcarry = -INFINITY;
-  __syncthreads();
-  int off = incl - cnt, total = 0;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) { off += w < wv ? s_wsum[w] : 0; total += s_wsum[w]; }
-  const int padded = (total + 3) & ~3;                     // the walk's steps of four: entries past the end re-read the last one
-  const bool owns_last = cnt > 0 && off + cnt == total;
-  int32_t* gcol = p.col_w + n * p.col_stride_n;
-
-  float l = 0.f;
-  float acc[VEC];
-#pragma unroll
-  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
-
-  for (int c0 = 0; c0 < padded; c0 += CH) {                // (block-uniform)
-    // this thread's pixel: its entries that fall into the chunk
-    if (cnt > 0 && off < c0 + CH && off + cnt > c0) {
-      const int j0 = max(0, c0 - off), j1 = min(cnt, c0 + CH - off);
-      if (wd <= p.max_k) {
-        for (int j = j0; j < j1; ++j) s_keys[off + j - c0] = hi - 1 - j;
-      } else {                                             // thinned pixel: the reference's fp32 stepping (csr_emit_kernel)
-        const float rs = (float)lo + (float)hcol, re = (float)hi + (float)hcol;
-        const float step = __fdiv_rn(re - rs, (float)p.max_k);
-        for (int j = j0; j < j1; ++j) s_keys[off + j - c0] = (int)((re - (float)(int)__fmul_rn((float)j, step)) - 1.0f) - hcol;
-      }
-      if (owns_last && j1 == cnt) {                        // the last entry's key again in the slots up to the step boundary
-        const int lastkey = s_keys[total - 1 - c0];
-        for (int e = total; e < padded; ++e) s_keys[e - c0] = lastkey;
-      }
-    }
-    __syncthreads();
-    const int nent = min(CH, padded - c0);                 // entries of the chunk, padding included (a multiple of 4)
-    if (p.write_cols)
-      for (int e = tid; e < min(nent, total - c0); e += NT) gcol[beg + c0 + e] = hcol + s_keys[e];
-
-    // ---- C: one lane group per entry, EPG entries each, every load in flight at once ------------------------------------
-    {
-      uint4 kr[EPG], vr[EPG];
-#pragma unroll
-      for (int i = 0; i < EPG; ++i) {
-        const int e = grp + i * NG;
-        const uint32_t key_c = (uint32_t)s_keys[e < nent ? e : 0];
-        kr[i] = *reinterpret_cast<const uint4*>(kbase + (__umul24(key_c, kst) + lane_off));
-        vr[i] = *reinterpret_cast<const uint4*>(vbase + (__umul24(key_c, vst) + lane_off));
-      }
-#pragma unroll
-      for (int i = 0; i < EPG; ++i) {
-        const int e = grp + i * NG;
-        float d = frag_dot<T>(qraw, kr[i]);
-        d = group_sum<LPR>(d);
-        if (e < nent) {
-          if (sub == 0) s_sc[e] = c0 + e < total ? d : -INFINITY;
-          *reinterpret_cast<uint4*>(s_v + (size_t)e * DL + sub * VEC) = vr[i];
-        }
-      }
-    }
-    __syncthreads();
-
-    // ---- D: per step of four entries (lane = step): running maximum, alpha, probabilities --------------------------------
-    if (wv == 0) {
-      const int nsteps = nent >> 2;
-      const bool on = lane < nsteps;
-      float4 sc = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-      if (on) sc = *reinterpret_cast<const float4*>(s_sc + 4 * lane);
-      float mx = fmaxf(fmaxf(sc.x, sc.y), fmaxf(sc.z, sc.w));
-#pragma unroll
-      for (int o = 1; o < 64; o <<= 1) {                   // inclusive prefix maximum over the steps
-        const float t = __shfl_up(mx, o);
-        if (lane >= o) mx = fmaxf(mx, t);
-      }
-      const float m_in = s_mcarry;
-      const float m_after = fmaxf(m_in, mx);
-      float m_before = __shfl_up(m_after, 1);
-      if (lane == 0) m_before = m_in;
-      const float msafe = (m_after == -INFINITY) ? 0.f : m_after;     // rows that have seen nothing yet: exp(-inf - 0) = 0
-      if (on) {
-        s_al[lane] = __expf(m_before - msafe);
-        *reinterpret_cast<float4*>(s_sc + 4 * lane) = make_float4(__expf(sc.x - msafe), __expf(sc.y - msafe), __expf(sc.z - msafe), __expf(sc.w - msafe));
-      }
-      if (lane == nsteps - 1) s_mcarry = m_after;
-    }
-    __syncthreads();
-
-    // ---- E: the accumulation chain, in the walk's order ------------------------------------------------------------------
-    if (grp == 0) {
-      const int nsteps = nent >> 2;
-      for (int st = 0; st < nsteps; ++st) {
-        const float alpha = s_al[st];
-        const float4 pu4 = *reinterpret_cast<const float4*>(s_sc + 4 * st);
-        const float pu[4] = {pu4.x, pu4.y, pu4.z, pu4.w};
-        uint4 vr[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) vr[u] = *reinterpret_cast<const uint4*>(s_v + (size_t)(4 * st + u) * DL + sub * VEC);
-        l *= alpha;
-#pragma unroll
-        for (int j = 0; j < VEC; ++j) acc[j] *= alpha;
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          float vf[VEC];
-          unpack16<T>(vr[u], vf);
-          l += pu[u];
-#pragma unroll
-          for (int j = 0; j < VEC; ++j) acc[j] = fmaf(pu[u], vf[j], acc[j]);
-        }
-      }
-    }
-    __syncthreads();                                       // the chunk's LDS is free again
-  }
-
-  if (grp == 0 && dact) {                                  // sparse_attn_rows_kernel's epilogue (t = 0, T_dst = 1)
-    const int64_t ridx = (int64_t)n * p.H + h;
-    float sc_ = (l > 0.f) ? (1.0f / l) : 0.f;
-    if (p.row_scale) sc_ *= p.row_scale[ridx];
-    float o[VEC];
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) o[j] = (l > 0.f) ? acc[j] * sc_ : 0.f;
-    if (p.mix) {
-      const float a = p.mix[ridx];
-      const T* ap = reinterpret_cast<const T*>(p.avg) + n * p.as[0] + h * p.as[1] + sub * VEC;
-      float af[VEC];
-      unpack16<T>(*reinterpret_cast<const uint4*>(ap), af);
-#pragma unroll
-      for (int j = 0; j < VEC; ++j) o[j] = o[j] * a + (1.0f - a) * af[j];
-    }
-    TO* op = reinterpret_cast<TO*>(p.out) + n * p.os[0] + h * p.os[1] + sub * VEC;
-    store_frag<TO, VEC>(op, o);
-  }
-}
-
 // ---- d = 80 (OPT-2.7B heads), 16-bit data: 8 lanes per row, each with 8 + 2 elements -------------------------
 // The power-of-two mapping above gives a d = 80 row 16 lanes of which 10 carry data (4 rows per wave).  Here a row
 // takes 8 lanes: lane j holds elements 8j..8j+7 (one 16-byte load) plus the pair 64+2j, 65+2j (one 4-byte load), so a
@@ -808,6 +642,193 @@ __global__ __launch_bounds__(NWB * 64) void sparse_attn_rows80_kernel(AttnParams
   }
 }
 
+// X80: d = 80 on 8 lanes per row -- lane j holds elements 8j .. 8j+7 plus the pair 64+2j, 65+2j (sparse_attn_rows80_kernel's map)
+template <typename T, typename TO, int LPR, bool X80 = false>
+__global__ __launch_bounds__(256) void sparse_attn_decode1_kernel(AttnParams p) {
+  constexpr int VEC = Elem<T>::VEC, NT = 256, NG = NT / LPR, XT = X80 ? 2 : 0, DL = LPR * (VEC + XT);
+  static_assert(!X80 || LPR == 8, "d = 80: eight lanes per row");
+  constexpr int CH = LPR == 8 ? 256 : 128;                 // entries per chunk: CH / 4 steps fit one wave, CH / NG = 8 per lane group
+  constexpr int EPG = CH / NG;
+  static_assert(VEC == 8 && CH / 4 <= 64 && CH % NG == 0, "16-bit rows; one lane per step in phase D");
+  extern __shared__ __attribute__((aligned(16))) char dsm[];
+  int* s_keys = reinterpret_cast<int*>(dsm);               // [CH]     key index (without the head offset)
+  float* s_sc = reinterpret_cast<float*>(s_keys + CH);     // [CH]     scores, then probabilities
+  float* s_al = s_sc + CH;                                 // [CH / 4] alpha per step
+  T* s_v = reinterpret_cast<T*>(s_al + CH / 4);            // [CH][DL] V rows
+  __shared__ int s_wsum[4];
+  __shared__ float s_mcarry;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int grp = tid / LPR, sub = tid - grp * LPR;
+  const int n = (int)blockIdx.x / p.H, h = (int)blockIdx.x - n * p.H;
+  const bool dact = X80 || sub * VEC < p.D;
+  const int sube = dact ? sub : 0;
+  const char* kbase = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.k) + n * p.ks[0] + h * p.ks[1]);
+  const char* vbase = reinterpret_cast<const char*>(reinterpret_cast<const T*>(p.v) + n * p.vs[0] + h * p.vs[1]);
+  const uint32_t kst = (uint32_t)p.ks[2] * (uint32_t)sizeof(T), vst = (uint32_t)p.vs[2] * (uint32_t)sizeof(T);
+  const uint32_t lane_off = (uint32_t)(sube * VEC) * (uint32_t)sizeof(T);
+  uint4 qraw = make_uint4(0, 0, 0, 0);
+  if (dact) qraw = *reinterpret_cast<const uint4*>(reinterpret_cast<const T*>(p.q) + n * p.qs[0] + h * p.qs[1] + sub * VEC);
+  constexpr int DM = LPR * VEC;                            // X80: elements in the 16-byte fragments; the pairs sit behind them
+  const uint32_t off_x = (uint32_t)(DM + sub * 2) * (uint32_t)sizeof(T);
+  uint32_t qx = 0;
+  if constexpr (X80) qx = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const T*>(p.q) + n * p.qs[0] + h * p.qs[1] + DM + sub * 2);
+  const int beg = p.crow[(int64_t)n * 2] + p.head_off[(int64_t)n * (p.H + 1) + h];
+  const int hcol = h * p.T_src;
+
+  // ---- B: one thread per pixel of the head --------------------------------------------------------------------------
+  const int w_t = row_width(0, 1, *p.t_src_dev, p.is_causal);
+  const float scale = interp_scale(w_t, p.T_m);
+  const uint32_t* brow = p.bits + (int64_t)n * p.W + h * (p.T_m >> 5);
+  const bool kept = tid < p.T_m && ((brow[tid >> 5] >> (tid & 31)) & 1u);
+  const int lo = (int)interp_bound(tid, scale), hi = (int)interp_bound(tid + 1, scale);
+  const int wd = hi - lo;
+  const int cnt = kept ? (wd < p.max_k ? wd : p.max_k) : 0;
+  const int incl = wave_incl_scan(cnt);
+  if (lane == 63) s_wsum[wv] = incl;
+  if (tid == 0) s_mcarry = -INFINITY;
+  __syncthreads();
+  int off = incl - cnt, total = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) { off += w < wv ? s_wsum[w] : 0; total += s_wsum[w]; }
+  const int padded = (total + 3) & ~3;                     // the walk's steps of four: entries past the end re-read the last one
+  const bool owns_last = cnt > 0 && off + cnt == total;
+  int32_t* gcol = p.col_w + n * p.col_stride_n;
+
+  float l = 0.f;
+  float acc[VEC + XT];
+#pragma unroll
+  for (int j = 0; j < VEC + XT; ++j) acc[j] = 0.f;
+
+  for (int c0 = 0; c0 < padded; c0 += CH) {                // (block-uniform)
+    // this thread's pixel: its entries that fall into the chunk
+    if (cnt > 0 && off < c0 + CH && off + cnt > c0) {
+      const int j0 = max(0, c0 - off), j1 = min(cnt, c0 + CH - off);
+      if (wd <= p.max_k) {
+        for (int j = j0; j < j1; ++j) s_keys[off + j - c0] = hi - 1 - j;
+      } else {                                             // thinned pixel: the reference's fp32 stepping (csr_emit_kernel)
+        const float rs = (float)lo + (float)hcol, re = (float)hi + (float)hcol;
+        const float step = __fdiv_rn(re - rs, (float)p.max_k);
+        for (int j = j0; j < j1; ++j) s_keys[off + j - c0] = (int)((re - (float)(int)__fmul_rn((float)j, step)) - 1.0f) - hcol;
+      }
+      if (owns_last && j1 == cnt) {                        // the last entry's key again in the slots up to the step boundary
+        const int lastkey = s_keys[total - 1 - c0];
+        for (int e = total; e < padded; ++e) s_keys[e - c0] = lastkey;
+      }
+    }
+    __syncthreads();
+    const int nent = min(CH, padded - c0);                 // entries of the chunk, padding included (a multiple of 4)
+    if (p.write_cols)
+      for (int e = tid; e < min(nent, total - c0); e += NT) gcol[beg + c0 + e] = hcol + s_keys[e];
+
+    // ---- C: one lane group per entry, EPG entries each, every load in flight at once ------------------------------------
+    {
+      uint4 kr[EPG], vr[EPG];
+      uint32_t kx[EPG], vx[EPG];
+#pragma unroll
+      for (int i = 0; i < EPG; ++i) {
+        const int e = grp + i * NG;
+        const uint32_t key_c = (uint32_t)s_keys[e < nent ? e : 0];
+        const uint32_t ko = __umul24(key_c, kst), vo = __umul24(key_c, vst);
+        kr[i] = *reinterpret_cast<const uint4*>(kbase + (ko + lane_off));
+        vr[i] = *reinterpret_cast<const uint4*>(vbase + (vo + lane_off));
+        if constexpr (X80) {
+          kx[i] = *reinterpret_cast<const uint32_t*>(kbase + (ko + off_x));
+          vx[i] = *reinterpret_cast<const uint32_t*>(vbase + (vo + off_x));
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < EPG; ++i) {
+        const int e = grp + i * NG;
+        float d = frag_dot<T>(qraw, kr[i]);
+        if constexpr (X80) d = tail_dot<T>(qx, kx[i], d);
+        d = group_sum<LPR>(d);
+        if (e < nent) {
+          if (sub == 0) s_sc[e] = c0 + e < total ? d : -INFINITY;
+          *reinterpret_cast<uint4*>(s_v + (size_t)e * DL + sub * VEC) = vr[i];
+          if constexpr (X80) *reinterpret_cast<uint32_t*>(s_v + (size_t)e * DL + DM + sub * 2) = vx[i];
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- D: per step of four entries (lane = step): running maximum, alpha, probabilities --------------------------------
+    if (wv == 0) {
+      const int nsteps = nent >> 2;
+      const bool on = lane < nsteps;
+      float4 sc = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      if (on) sc = *reinterpret_cast<const float4*>(s_sc + 4 * lane);
+      float mx = fmaxf(fmaxf(sc.x, sc.y), fmaxf(sc.z, sc.w));
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {                   // inclusive prefix maximum over the steps
+        const float t = __shfl_up(mx, o);
+        if (lane >= o) mx = fmaxf(mx, t);
+      }
+      const float m_in = s_mcarry;
+      const float m_after = fmaxf(m_in, mx);
+      float m_before = __shfl_up(m_after, 1);
+      if (lane == 0) m_before = m_in;
+      const float msafe = (m_after == -INFINITY) ? 0.f : m_after;     // rows that have seen nothing yet: exp(-inf - 0) = 0
+      if (on) {
+        s_al[lane] = __expf(m_before - msafe);
+        *reinterpret_cast<float4*>(s_sc + 4 * lane) = make_float4(__expf(sc.x - msafe), __expf(sc.y - msafe), __expf(sc.z - msafe), __expf(sc.w - msafe));
+      }
+      if (lane == nsteps - 1) s_mcarry = m_after;
+    }
+    __syncthreads();
+
+    // ---- E: the accumulation chain, in the walk's order ------------------------------------------------------------------
+    if (grp == 0) {
+      const int nsteps = nent >> 2;
+      for (int st = 0; st < nsteps; ++st) {
+        const float alpha = s_al[st];
+        const float4 pu4 = *reinterpret_cast<const float4*>(s_sc + 4 * st);
+        const float pu[4] = {pu4.x, pu4.y, pu4.z, pu4.w};
+        uint4 vr[4];
+        uint32_t vx[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          vr[u] = *reinterpret_cast<const uint4*>(s_v + (size_t)(4 * st + u) * DL + sub * VEC);
+          if constexpr (X80) vx[u] = *reinterpret_cast<const uint32_t*>(s_v + (size_t)(4 * st + u) * DL + DM + sub * 2);
+        }
+        l *= alpha;
+#pragma unroll
+        for (int j = 0; j < VEC + XT; ++j) acc[j] *= alpha;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          float vf[VEC + 2];
+          unpack16<T>(vr[u], vf);
+          if constexpr (X80) unpack2<T>(vx[u], vf + VEC);
+          l += pu[u];
+#pragma unroll
+          for (int j = 0; j < VEC + XT; ++j) acc[j] = fmaf(pu[u], vf[j], acc[j]);
+        }
+      }
+    }
+    __syncthreads();                                       // the chunk's LDS is free again
+  }
+
+  if (grp == 0 && dact) {                                  // sparse_attn_rows_kernel's epilogue (t = 0, T_dst = 1)
+    const int64_t ridx = (int64_t)n * p.H + h;
+    float sc_ = (l > 0.f) ? (1.0f / l) : 0.f;
+    if (p.row_scale) sc_ *= p.row_scale[ridx];
+    float o[VEC + 2];
+#pragma unroll
+    for (int j = 0; j < VEC + XT; ++j) o[j] = (l > 0.f) ? acc[j] * sc_ : 0.f;
+    if (p.mix) {
+      const float a = p.mix[ridx];
+      const T* ap = reinterpret_cast<const T*>(p.avg) + n * p.as[0] + h * p.as[1];
+      float af[VEC + 2];
+      unpack16<T>(*reinterpret_cast<const uint4*>(ap + sub * VEC), af);
+      if constexpr (X80) unpack2<T>(*reinterpret_cast<const uint32_t*>(ap + DM + sub * 2), af + VEC);
+#pragma unroll
+      for (int j = 0; j < VEC + XT; ++j) o[j] = o[j] * a + (1.0f - a) * af[j];
+    }
+    TO* op = reinterpret_cast<TO*>(p.out) + n * p.os[0] + h * p.os[1];
+    store_frag<TO, VEC>(op + sub * VEC, o);
+    if constexpr (X80) store2<TO>(op + DM + sub * 2, o[VEC], o[VEC + 1]);
+  }
+}
+
 // ---- unfused SDDMM: one wave per (n, t) row, all heads -----------------------------------------------
 struct SddmmParams {
   const void *q, *k;
@@ -940,8 +961,11 @@ static int launch_attn_wp(AttnParams p, hipStream_t s) {
                      (int64_t)p.T_src * p.ks[2] * esz < (1ll << 31) && (int64_t)p.T_src * p.vs[2] * esz < (1ll << 31);
   if constexpr (sizeof(T) == 2 && !WP) {
     // one new row per sequence (a DecodeSession position): the whole workgroup serves the row (sparse_attn_decode1_kernel)
-    if (p.bits && p.t_src_dev && p.T_dst == 1 && p.T_m <= 256 && small && (lpr == 8 || lpr == 16) && p.D != 80) {
-      if (lpr == 8) {
+    if (p.bits && p.t_src_dev && p.T_dst == 1 && p.T_m <= 256 && small && (lpr == 8 || lpr == 16 || p.D == 80)) {
+      if (p.D == 80) {
+        constexpr int CH = 256, DL = 80;
+        hipLaunchKernelGGL((sparse_attn_decode1_kernel<T, TO, 8, true>), dim3((unsigned)NH), dim3(256), CH * 8 + CH + CH * DL * 2, s, p);
+      } else if (lpr == 8) {
         constexpr int CH = 256, DL = 64;
         hipLaunchKernelGGL((sparse_attn_decode1_kernel<T, TO, 8>), dim3((unsigned)NH), dim3(256), CH * 8 + CH + CH * DL * 2, s, p);
       } else {

@@ -118,7 +118,7 @@ def test_session_attention_forms_agree(dtype, N, H, d, T0, use_graph):
                                                      (torch.float16, 4, 128, 3000, 64, True),    # 16-lane rows: chunks of 128
                                                      (torch.bfloat16, 4, 64, 3000, 4, True),     # every pixel thinned to max_k = 4
                                                      (torch.bfloat16, 8, 64, 517, 16, False),    # ragged step boundary (entries % 4 != 0)
-                                                     (torch.bfloat16, 4, 80, 3000, 64, True),    # d = 80: the lane-group decode form
+                                                     (torch.bfloat16, 4, 80, 3000, 64, True),    # d = 80: 8 lanes x (8 + 2) elements per row
                                                      (torch.bfloat16, 4, 64, 1, 64, False)])     # the very first position: one key
 def test_decode_attention_operator_forms_agree(dtype, H, d, T_src, k, heavy):
     """`sea_sparse_attention_fused_at` (one new row per sequence: sparse_attn_decode1_kernel -- the whole workgroup serves the
