@@ -43,7 +43,7 @@ with torch.no_grad():
         hi = T0 + i + 1
         sess.step(q[:, :, hi - 1:hi], x[:, :, hi - 1:hi], x[:, :, hi - 1:hi])
     torch.cuda.synchronize(); lib.sea_debug_stamps(buf)
-names = {10: "fetch + conv1 row", 11: "conv2 row", 12: "ring copy", 8: "z tile", 9: "head loop", 1: "minmax", 2: "hist+bin",
+names = {5: "start -> conv1 operands + weights in LDS", 10: "conv1 row (MFMA + store)", 11: "conv2 row", 12: "ring copy", 8: "z tile", 9: "head loop", 1: "minmax", 2: "hist+bin",
          3: "select flags", 4: "bits+widths", 13: "emit"}
 per = (steps - 4) * N                                       # workgroup runs in the stamped window
 print(json.dumps({"batch": N, "us_per_workgroup (100 MHz ticks / 100)": {names[i]: round(buf[i] / per / 100, 2) for i in names},

@@ -84,9 +84,22 @@ struct ConvRowC8 {
     __syncthreads();
   }
 
+  // this lane's biases (channels conv_chan<NT>(nt, lg) .. +3 per tile), requested with the first loads of the kernel: read in the
+  // epilogue they were one more exposed round trip per row (a row has nothing to hide it behind)
+  float bs[NT][4];
+  __device__ __forceinline__ void load_bias(const float* __restrict__ bias, int C) {
+    const int lg = (threadIdx.x & 63) >> 4;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int c0 = conv_chan<NT>(nt, lg);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) bs[nt][r] = c0 + r < C ? bias[c0 + r] : 0.f;
+    }
+  }
+
   // the row: MFMAs in the convolution kernel's order, its epilogue, the C8 store.  Ends with a barrier (the stored row is
-  // visible to the workgroup, and sW may be overwritten).
-  __device__ __forceinline__ void run(const T* sW, const float* __restrict__ bias, T* __restrict__ out, int C, int W, int relu) {
+  // visible to the workgroup, and sW may be overwritten).  load_bias() first.
+  __device__ __forceinline__ void run(const T* sW, T* __restrict__ out, int C, int W, int relu) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int li = lane & 15, lg = lane >> 4;
@@ -111,9 +124,8 @@ struct ConvRowC8 {
     unsigned pk[2 * NT];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const int c0 = conv_chan<NT>(nt, lg);
-      float v0 = acc[nt][0] + (c0 < C ? bias[c0] : 0.f), v1 = acc[nt][1] + (c0 + 1 < C ? bias[c0 + 1] : 0.f);
-      float v2 = acc[nt][2] + (c0 + 2 < C ? bias[c0 + 2] : 0.f), v3 = acc[nt][3] + (c0 + 3 < C ? bias[c0 + 3] : 0.f);
+      float v0 = acc[nt][0] + bs[nt][0], v1 = acc[nt][1] + bs[nt][1];
+      float v2 = acc[nt][2] + bs[nt][2], v3 = acc[nt][3] + bs[nt][3];
       if (relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
       pk[2 * nt] = pack2<T>(v0, v1);
       pk[2 * nt + 1] = pack2<T>(v2, v3);

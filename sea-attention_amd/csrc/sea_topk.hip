@@ -1061,18 +1061,21 @@ __global__ __launch_bounds__(TK_THREADS) void decode_cnn_tail_select_kernel(Deco
   // (what does not depend on the position leaves first: the weight image and the MLP's row are in flight while the counter's
   // scalar load returns)
   c1.load_weights(reinterpret_cast<const T*>(dp.w1), dp.C);
+  c1.load_bias(dp.b1, dp.C);
+  c2.load_bias(dp.b2, dp.C);
   c1.fetch_row(2, xn, dp.C, dp.W, dp.dil, dp.pad_w);
   c1.fetch_row(0, xr + slot(pos - 2 * dp.dil, dp.RX) * row, dp.C, dp.W, dp.dil, dp.pad_w);
   c1.fetch_row(1, xr + slot(pos - dp.dil, dp.RX) * row, dp.C, dp.W, dp.dil, dp.pad_w);
   c2.fetch_row(0, yr + slot(pos - 2 * dp.dil, dp.RY) * row, dp.C, dp.W, dp.dil, dp.pad_w);      // (conv1's rows of earlier positions)
   c2.fetch_row(1, yr + slot(pos - dp.dil, dp.RY) * row, dp.C, dp.W, dp.dil, dp.pad_w);
   c1.store_weights(sW);
+  STAMP(5);   // decode: kernel start -> conv1's operands and weight image in place (all of it memory latency)
   c2.load_weights(reinterpret_cast<const T*>(dp.w2), dp.C);       // in flight while conv1's row is computed
-  c1.run(sW, dp.b1, y1_new, dp.C, dp.W, 1);
+  c1.run(sW, y1_new, dp.C, dp.W, 1);
   STAMP(10);  // decode: operand fetches + conv1's row
   c2.fetch_row(2, y1_new, dp.C, dp.W, dp.dil, dp.pad_w);           // (stored above, barrier passed)
   c2.store_weights(sW);
-  c2.run(sW, dp.b2, y2, dp.C, dp.W, 1);
+  c2.run(sW, y2, dp.C, dp.W, 1);
   STAMP(11);  // decode: conv2's row
   {                                                                // the MLP's row joins the ring (read by the next positions)
     const uint4* src = reinterpret_cast<const uint4*>(xn);
