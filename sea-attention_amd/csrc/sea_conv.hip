@@ -52,6 +52,9 @@ struct ConvParams {
 // lines back to back.  Pixel fragments come through buffer loads: a lane whose tap falls outside the row (or whose
 // channel block is K padding) carries an offset beyond num_records and the hardware returns zeros, so the k-loop
 // is branch-free and the next step's loads are in flight under the current step's MFMAs.
+#ifndef SEA_CONV_FIXED_OFFSETS
+#define SEA_CONV_FIXED_OFFSETS 1
+#endif
 constexpr int CONV_WAVES = 6;                     // waves per workgroup of the big launches (NW below: 6 or 8)
 constexpr unsigned CONV_OOB = 0x7FFFFF00u;       // > any valid byte offset (launcher checks the image is < 1 GiB)
 
@@ -165,8 +168,35 @@ __global__ __launch_bounds__(NW * 64, (NT <= 4 ? 3 : 2)) void causal_conv_c8_ker
       if (++c.ti == KS) { c.work += NW; open_work(c); }
     }
   };
+#if SEA_CONV_FIXED_OFFSETS
+  // ONESEG, 3 x 3: the per-lane byte offsets of the 12 (tap column, pixel tile) fragments are kernel invariants -- a tap that
+  // leaves the row carries an offset beyond num_records -- and so is the K-padding mask of the last channel chunk.  (Computed
+  // per request they were ~10 vector instructions in front of every 4 loads: 23 % of the waves' cycles were vector issue in a
+  // kernel whose vector work is its epilogue.)  A cursor past the end re-reads work item 0 (valid memory, never used).
+  unsigned voff[3][4];
+  const unsigned lastdead = ((kchunks - 1) * 4 + lg < C8i) ? 0u : CONV_OOB;
+  if constexpr (ONESEG && KS == 3) {
+#pragma unroll
+    for (int tj = 0; tj < 3; ++tj)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) {
+        const int dw = p.dil * tj - p.pad_w;
+        const bool in_row = (unsigned)(li + mt * 16 + dw) < (unsigned)p.W;
+        voff[tj][mt] = in_row ? (unsigned)((lg * p.W + li + mt * 16 + dw) * 16) : CONV_OOB;
+      }
+  }
+#endif
   auto issue = [&](const Cursor& c, int tj, cu4 (&a)[4]) {   // request the 4 pixel fragments of step (c.grp, tj)
     const int soff = c.row_soff + c.cci * 4 * p.W * 16;      // byte offset of the (row, 4-block chunk) slab
+#if SEA_CONV_FIXED_OFFSETS
+    if constexpr (ONESEG && KS == 3) {
+      const unsigned m = (c.cci == kchunks - 1) ? lastdead : 0u;       // (the compare is scalar: one v_or per request)
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt)
+        a[mt] = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc, (int)(voff[tj][mt] | m), soff, 0);
+      return;
+    }
+#endif
     // dead cursor / K-padding blocks: an all-ones-ish mask OR-ed into the offset keeps it beyond num_records
     // (pure arithmetic on purpose: a boolean here gets jump-threaded into divergent load paths)
     const unsigned dead = (c.live && (c.cci * 4 + lg < C8i)) ? 0u : CONV_OOB;
