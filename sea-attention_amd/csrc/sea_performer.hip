@@ -992,8 +992,11 @@ __global__ __launch_bounds__(512) void performer_bf16_kernel(PerfParams p) {
     if (tid < FP) cw[NBT * 4 * NTH + tid] = sKsum[tid];
     cw[NBT * 4 * NTH + FP + tid] = li == 0 ? csum[0] : li == 1 ? csum[1] : li == 2 ? csum[2] : li == 3 ? csum[3] : 0.f;
   } else {
-    // the block that walked the last rows holds the final state (aligned step: the state at the last chunk boundary)
-    if (p.state_out && seg == p.nseg - 1) write_state();
+    // the block that walked the last rows holds the final state (aligned step: the state at the last chunk boundary).  A step
+    // that closed no chunk leaves the image as it found it: updated in place (a DecodeSession) there is nothing to write --
+    // 25 KB of stores per (n, h) whose drain was the end of the launch on 63 of 64 positions
+    const bool unchanged = p.aligned && p.state_in == p.state_out && t_end - t_begin <= C && !upd_of(t_begin);
+    if (p.state_out && seg == p.nseg - 1 && !unchanged) write_state();
 #ifdef SEA_STAMP
     if (threadIdx.x == 0) { const int _w = blockIdx.y * gridDim.x + blockIdx.x; if (_w < 1024) { sea_dbg_wg[2 * _w] = _rstart64; sea_dbg_wg[2 * _w + 1] = __builtin_amdgcn_s_memrealtime(); } }
 #endif
@@ -1745,8 +1748,10 @@ __global__ __launch_bounds__(512) void performer_bf16w_kernel(PerfParams p) {
   if constexpr (STATE_ONLY) {
     write_image(p.carry + ((int64_t)nh * (p.nseg - 1) + seg) * CARRY);
   } else {
-    // the block that walked the last rows holds the final state (aligned step: the state at the last chunk boundary)
-    if (p.state_out && seg == p.nseg - 1) write_image(p.state_out + (int64_t)nh * CARRY);
+    // the block that walked the last rows holds the final state (aligned step: the state at the last chunk boundary); a step that
+    // closed no chunk and updates the image in place has nothing to write (see the D = 64 kernel)
+    const bool unchanged = p.aligned && p.state_in == p.state_out && t_end - t_begin <= C && !upd_of(t_begin);
+    if (p.state_out && seg == p.nseg - 1 && !unchanged) write_image(p.state_out + (int64_t)nh * CARRY);
   }
 }
 
