@@ -511,6 +511,44 @@ def grid_leg(args, dev):
             "points": pts}
 
 
+def reference_fixture_check(dev):
+    """The hot path (steps H..K) against the REFERENCE's own outputs, inside the bench process: `tests/golden/*.npz` hold seeded
+    inputs and what the reference's Triton / torch operators returned for them (`tests/golden/make_golden.py`, run once in the
+    build container; data only).  Selection + interpolation: CSR row pointers and column ids bit-exact; fused sparse attention
+    (one launch instead of the reference's four operators): fp32 result within 2e-5 abs / 1e-4 rel.  The same comparisons as
+    `tests/test_gpu_golden.py`, on the cases that fit a second."""
+    import numpy as np
+    import torch
+    from sea_attention_amd.perlin_attention import ops
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden")
+    res = {"cases": [], "csr_bit_exact": True, "attention_max_abs_err": 0.0, "attention_within_tolerance": True}
+    for case in ("large", "big", "ragged", "clamp"):
+        f = os.path.join(gdir, case + ".npz")
+        if not os.path.exists(f):
+            continue
+        g = np.load(f)
+        N, H, T_DST, T_SRC, T_M, k, d, causal = [int(x) for x in g["meta"]]
+        if not causal:
+            continue
+        keep = ops.keep_table_kernel_test(H, T_DST, T_M, k, device=dev)
+        probs = torch.from_numpy(g["probs"]).to(dev)
+        csr, _ = ops.topk_to_csr(probs, keep, k, target_width=T_SRC, is_causal=True)
+        t = csr.to_sparse_csr()
+        ok = (np.array_equal(t.crow_indices().cpu().numpy(), g["crow"]) and np.array_equal(t.col_indices().cpu().numpy(), g["col"]))
+        res["csr_bit_exact"] &= bool(ok)
+        q, kk, v = (torch.from_numpy(g[n_]).to(dev) for n_ in ("q", "k", "v"))
+        out = ops.sparse_attention(q, kk, v, csr, row_scale=torch.from_numpy(g["scaler"]).to(dev).contiguous()).cpu().numpy()
+        err = float(np.abs(out - g["sdbmm"]).max())
+        res["attention_max_abs_err"] = max(res["attention_max_abs_err"], err)
+        res["attention_within_tolerance"] &= bool(np.allclose(out, g["sdbmm"], atol=2e-5, rtol=1e-4))
+        res["cases"].append(f"{case}: N{N} H{H} T{T_DST} T_M{T_M} k{k} d{d}, nnz {int(g['crow'][:, -1].sum())}")
+    res["attention_max_abs_err"] = float(f"{res['attention_max_abs_err']:.3g}")
+    res["status"] = "ok" if (res["cases"] and res["csr_bit_exact"] and res["attention_within_tolerance"]) else ("skipped: no fixtures" if not res["cases"] else "FAILED")
+    res["note"] = ("tests/golden/*.npz = the reference's own operator outputs on seeded inputs (fp32 data): CSR indices bit-exact, "
+                   "fused attention within 2e-5 abs / 1e-4 rel")
+    return res
+
+
 def decode_leg(layer, q, kk, v, mask, NB, T, positions):
     """Generation (the reference's loop: src/main/opt_generate.py:131): one position per step from a prefix, the
     step's launches replayed as one HIP graph (DecodeSession); every sequence of the batch advances together."""
@@ -946,6 +984,13 @@ def main(argv=None):
                             "finite": finite, "items_checked": sorted({0, NB - 1}), "layer_item_alone_rel_diff": round(worst, 8)}
             if gathered_ok is not None:
                 output_check["gathered_shards_match_their_ranks"] = gathered_ok
+            if rank == 0:
+                try:
+                    output_check["reference_fixtures"] = reference_fixture_check(dev)
+                    if output_check["reference_fixtures"]["status"] == "FAILED":
+                        output_check["status"] = "FAILED"
+                except Exception as e:                       # (a missing fixture directory must not take the line down)
+                    output_check["reference_fixtures"] = {"status": f"error: {type(e).__name__}: {e}"[:200]}
 
     # ---- roofline of the dominant HIP kernel (fused sparse attention) ---------------------------------
     t_attn = t_attn_graph if t_attn_graph else regions.get('attention.sparse.fused')
