@@ -91,6 +91,7 @@ class FlatCSR:
         cut = lambda t: t[n0:n1] if t is not None else None
         sub = FlatCSR(self.crow[n0:n1], self._col[n0:n1], self.head_off[n0:n1], self.H, self.T_src, cut(self.bits), cut(self.row_nnz),
                       cut(self.vals))
+        sub.t_src_dev = self.t_src_dev
         if self._pending is not None:
             T_m, k, causal, _emit = self._pending
             sub._pending = (T_m, k, causal, lambda: self.col)
