@@ -165,6 +165,36 @@ def test_decode_attention_operator_forms_agree(dtype, H, d, T_src, k, heavy):
         assert torch.equal(ca.col[n, :int(row_nnz[n, 0])], cb.col[n, :int(row_nnz[n, 0])])
 
 
+@pytest.mark.parametrize("dtype,H,d,T_dst", [(torch.bfloat16, 4, 64, 3), (torch.float16, 4, 128, 8), (torch.bfloat16, 4, 80, 2)])
+def test_decode_attention_operator_few_rows(dtype, H, d, T_dst):
+    """T_dst = 2 .. 8 new rows per sequence through `sea_sparse_attention_fused_at`: the lane-group decode form (`DEC`
+    instantiations: expansion inside the launch, row widths from the device counter, lists warmed by the whole block) against
+    `sea_csr_emit_at` + the unfused launch -- bitwise."""
+    from sea_attention_amd.perlin_attention import ops
+    N, T_m, T_src, k = 2, 256, 1500, 16
+    T_cap = T_src + 24
+    S.seed(6)
+    probs = torch.rand((N, H, T_dst, T_m), device=DEV).to(dtype)
+    keep = torch.full((T_dst,), 61, dtype=torch.int32, device=DEV)
+    sel = ops.topk_to_csr(probs, keep, k, target_width=T_src, is_causal=True)[0]
+    ts = torch.tensor([T_src], dtype=torch.int32, device=DEV)
+    z_cap = max(int(sel.crow[:, -1].max().item()), 1)
+    q = torch.randn((N, H, T_dst, d), device=DEV).to(dtype)
+    kk = torch.randn((N, H, T_cap, d), device=DEV).to(dtype)
+    vv = torch.randn((N, H, T_cap, d), device=DEV).to(dtype)
+    rs = torch.rand((N, H, T_dst), device=DEV)
+    outs = []
+    for defer in (True, False):
+        csr = ops.csr_from_selection(sel.bits, sel.row_nnz, sel.head_off, H, T_m, T_cap, k, True, z_cap, t_src_dev=ts, defer_emit=defer)
+        outs.append((ops.sparse_attention(q, kk, vv, csr, row_scale=rs, path="gather", keep_columns_pending=True), csr))
+    (oa, ca), (ob, cb) = outs
+    assert ca.col_is_pending and not cb.col_is_pending
+    assert torch.isfinite(oa).all() and torch.equal(oa, ob), (oa - ob).abs().max().item()
+    for n in range(N):
+        z = int(sel.crow[n, -1])
+        assert z > 0 and torch.equal(ca.col[n, :z], cb.col[n, :z])
+
+
 def test_session_refuses_what_it_cannot_continue():
     dtype, N, H, d, T_M, k = torch.bfloat16, 1, 4, 64, 256, 16
     layer = _layer(H, d, T_M, k, 64, dtype)
