@@ -163,6 +163,12 @@ def test_decode_attention_operator_forms_agree(dtype, H, d, T_src, k, heavy):
         assert torch.equal(oa[1, 1].float(), ((1.0 - mix[1, 1]).view(1, 1) * avg[1, 1].float()).to(dtype).float())     # empty head: the average alone
     for n in range(N):                                                      # the pending handle's columns, emitted on first read
         assert torch.equal(ca.col[n, :int(row_nnz[n, 0])], cb.col[n, :int(row_nnz[n, 0])])
+    # ... and written by the launch itself when the caller does not keep them pending (write_columns = 1)
+    cw = ops.csr_from_selection(bits, row_nnz, head_off, H, T_m, T_cap, k, True, z_cap, t_src_dev=ts, crow=crow, defer_emit=True)
+    ow = ops.sparse_attention(q, kk, vv, cw, row_scale=rs, avg=avg, mix=mix, path="gather", out_dtype=dtype)
+    assert not cw.col_is_pending and torch.equal(ow, oa)
+    for n in range(N):
+        assert torch.equal(cw.col[n, :int(row_nnz[n, 0])], cb.col[n, :int(row_nnz[n, 0])])
 
 
 @pytest.mark.parametrize("dtype,H,d,T_dst", [(torch.bfloat16, 4, 64, 3), (torch.float16, 4, 128, 8), (torch.bfloat16, 4, 80, 2)])
